@@ -1,0 +1,481 @@
+// C-ABI layer of libboojum_hip.so: context management + argument validation + kernel orchestration.
+// Public contract: include/boojum_hip.h.  No CPU fallback anywhere in this file: every entry point either
+// enqueues HIP work on the context's device or returns an error.
+#include "../../include/boojum_hip.h"
+#include "gl.cuh"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using gl::u64;
+
+struct bj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // twiddle caches (bit-reversed tables; a table for 2^k serves every smaller size as a prefix)
+    u64 *tw_fwd = nullptr, *tw_inv = nullptr;
+    unsigned tw_fwd_log = 0, tw_inv_log = 0;
+    // small device scratch: coset shifts + per-round scales, column pointer lists
+    u64 *d_small = nullptr;  // 64 shifts + 64*32 scales
+    const u64 **d_ptrs = nullptr;
+    size_t d_ptrs_cap = 0;
+    // big scratch for out-of-place steps
+    u64 *d_scratch = nullptr;
+    size_t scratch_elems = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(bj_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define BJ_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? BJ_ERR_OOM : BJ_ERR_HIP, "%s failed: %s", #call,   \
+                        hipGetErrorString(e_));                                                             \
+    } while (0)
+
+#define BJ_CHECK_LAUNCH(ctx)                                                                                \
+    do {                                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                                  \
+        if (e_ != hipSuccess) return fail(ctx, BJ_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+int bind(bj_ctx *ctx) {
+    if (!ctx) return BJ_ERR_INVALID_ARG;
+    BJ_HIP(ctx, hipSetDevice(ctx->device));
+    return BJ_OK;
+}
+
+int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse) {
+    u64 *&tab = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    unsigned &have = inverse ? ctx->tw_inv_log : ctx->tw_fwd_log;
+    if (log_n <= have && tab) return BJ_OK;
+    if (log_n == 0) log_n = 1;
+    if (tab) {
+        BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BJ_HIP(ctx, hipFree(tab));
+        tab = nullptr;
+        have = 0;
+    }
+    size_t half = (size_t)1 << (log_n - 1);
+    BJ_HIP(ctx, hipMalloc((void **)&tab, half * sizeof(u64)));
+    bj::launch_twiddles(tab, log_n, inverse, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    have = log_n;
+    return BJ_OK;
+}
+
+int ensure_scratch(bj_ctx *ctx, size_t elems) {
+    if (elems <= ctx->scratch_elems) return BJ_OK;
+    if (ctx->d_scratch) {
+        BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BJ_HIP(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_elems = 0;
+    }
+    BJ_HIP(ctx, hipMalloc((void **)&ctx->d_scratch, elems * sizeof(u64)));
+    ctx->scratch_elems = elems;
+    return BJ_OK;
+}
+
+unsigned log2_exact(size_t x) {
+    unsigned r = 0;
+    while (((size_t)1 << r) < x) r++;
+    return r;
+}
+bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+
+}  // namespace
+
+extern "C" {
+
+int bj_abi_version(void) { return BJ_ABI_VERSION; }
+
+int bj_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *bj_status_string(int status) {
+    switch (status) {
+        case BJ_OK: return "ok";
+        case BJ_ERR_INVALID_ARG: return "invalid argument";
+        case BJ_ERR_NO_DEVICE: return "no usable HIP device";
+        case BJ_ERR_HIP: return "HIP runtime error";
+        case BJ_ERR_OOM: return "out of device memory";
+        case BJ_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}
+
+int bj_ctx_create(int device, bj_ctx **out) {
+    if (!out) return BJ_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BJ_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return BJ_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return BJ_ERR_NO_DEVICE;
+    bj_ctx *ctx = new bj_ctx();
+    ctx->device = device;
+    if (hipMalloc((void **)&ctx->d_small, (64 + 64 * 32) * sizeof(u64)) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return BJ_ERR_HIP;
+    }
+    *out = ctx;
+    return BJ_OK;
+}
+
+void bj_ctx_destroy(bj_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->tw_fwd) (void)hipFree(ctx->tw_fwd);
+    if (ctx->tw_inv) (void)hipFree(ctx->tw_inv);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->d_ptrs) (void)hipFree((void *)ctx->d_ptrs);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+int bj_ctx_set_stream(bj_ctx *ctx, void *hip_stream) {
+    if (!ctx) return BJ_ERR_INVALID_ARG;
+    ctx->stream = (hipStream_t)hip_stream;
+    return BJ_OK;
+}
+
+const char *bj_last_error(const bj_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int bj_sync(bj_ctx *ctx) {
+    if (int rc = bind(ctx)) return rc;
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJ_OK;
+}
+
+int bj_malloc(bj_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!d_ptr) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_malloc: null out pointer");
+    if (int rc = bind(ctx)) return rc;
+    BJ_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 8));
+    return BJ_OK;
+}
+int bj_free(bj_ctx *ctx, void *d_ptr) {
+    if (int rc = bind(ctx)) return rc;
+    if (d_ptr) {
+        BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BJ_HIP(ctx, hipFree(d_ptr));
+    }
+    return BJ_OK;
+}
+int bj_memcpy_h2d(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (int rc = bind(ctx)) return rc;
+    if (!bytes) return BJ_OK;
+    if (!d_dst || !h_src) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_memcpy_h2d: null pointer");
+    BJ_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJ_OK;
+}
+int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (int rc = bind(ctx)) return rc;
+    if (!bytes) return BJ_OK;
+    if (!h_dst || !d_src) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_memcpy_d2h: null pointer");
+    BJ_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJ_OK;
+}
+
+int bj_timer_start(bj_ctx *ctx) {
+    if (int rc = bind(ctx)) return rc;
+    BJ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return BJ_OK;
+}
+int bj_timer_stop_ms(bj_ctx *ctx, float *ms) {
+    if (int rc = bind(ctx)) return rc;
+    if (!ms) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_timer_stop_ms: null out pointer");
+    BJ_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    BJ_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    BJ_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return BJ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- NTT family
+
+static int check_ntt_args(bj_ctx *ctx, const char *fn, const void *in, const void *out, unsigned log_n,
+                          unsigned n_cols, size_t col_stride) {
+    if (!in || !out) return fail(ctx, BJ_ERR_INVALID_ARG, "%s: null device pointer", fn);
+    if (log_n > 32) return fail(ctx, BJ_ERR_INVALID_ARG, "%s: log_n %u exceeds the field's two-adicity (32)", fn, log_n);
+    if (log_n > 30) return fail(ctx, BJ_ERR_UNSUPPORTED, "%s: log_n %u > 30 not supported", fn, log_n);
+    if (n_cols > 65535) return fail(ctx, BJ_ERR_UNSUPPORTED, "%s: more than 65535 columns per call", fn);
+    if (n_cols > 1 && col_stride < ((size_t)1 << log_n))
+        return fail(ctx, BJ_ERR_INVALID_ARG, "%s: col_stride smaller than the column length", fn);
+    return BJ_OK;
+}
+
+int bj_ntt_forward_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
+                         size_t col_stride, uint64_t coset) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_ntt_forward_batch", d_in, d_out, log_n, n_cols, col_stride)) return rc;
+    if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
+    coset = gl::canon(coset);
+    if (coset == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ntt_forward_batch: coset shift must be non-zero");
+    const u64 *scales = nullptr;
+    if (coset != 1 && log_n > 0) {
+        bj::launch_round_scales(ctx->d_small + 64, &coset, 1, log_n, ctx->stream);
+        scales = ctx->d_small + 64;
+    }
+    bj::launch_ntt_passes(d_in, d_out, ctx->tw_fwd, scales, log_n, n_cols, 1, col_stride, col_stride, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
+                  size_t col_stride, uint64_t coset) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_intt_batch", d_in, d_out, log_n, n_cols, col_stride)) return rc;
+    if (int rc = ensure_twiddles(ctx, log_n, true)) return rc;
+    coset = gl::canon(coset);
+    if (coset == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_intt_batch: coset shift must be non-zero");
+    const size_t n = (size_t)1 << log_n;
+    // butterflies with inverse twiddles into scratch (bit-reversed), then un-reverse + scale into d_out
+    if (int rc = ensure_scratch(ctx, (size_t)n_cols * n)) return rc;
+    bj::launch_ntt_passes(d_in, ctx->d_scratch, ctx->tw_inv, nullptr, log_n, n_cols, 1, col_stride, n, ctx->stream);
+    u64 n_inv = log_n ? gl::inv(gl::canon((u64)n % gl::P)) : 1;
+    u64 step = coset == 1 ? 1 : gl::inv(coset);
+    bj::launch_bitrev_scale(ctx->d_scratch, d_out, log_n, n_cols, n, col_stride, n_inv, step, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_lde_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                 unsigned n_cols, unsigned log_lde) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_lde_batch", d_mono, d_out, log_n, n_cols, col_stride)) return rc;
+    if (log_lde == 0 || log_lde > 6) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: lde factor must be 2..64");
+    if (log_n + log_lde > 32) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: LDE domain exceeds two-adicity");
+    if (d_out == d_mono) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: output must not alias the monomials");
+    if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
+    const unsigned L = 1u << log_lde;
+    const size_t n = (size_t)1 << log_n;
+    // shift_c = g * w_{nL}^{bitrev(c)}   (utils.rs:345-346, 370-373)
+    u64 shifts[64];
+    u64 w = gl::omega(log_n + log_lde);
+    for (unsigned c = 0; c < L; c++) shifts[c] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(c, log_lde)));
+    bj::launch_round_scales(ctx->d_small + 64, shifts, L, log_n ? log_n : 1, ctx->stream);
+    bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, L, col_stride,
+                          (size_t)L * n, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_trace_to_lde_batch(bj_ctx *ctx, uint64_t *d_cols, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                          unsigned n_cols, unsigned log_lde) {
+    if (int rc = bj_intt_batch(ctx, d_cols, d_cols, log_n, n_cols, col_stride, 1)) return rc;
+    return bj_lde_batch(ctx, d_cols, col_stride, d_out, log_n, n_cols, log_lde);
+}
+
+int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
+                        size_t col_stride) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_bitreverse_batch", d_in, d_out, log_n, n_cols, col_stride)) return rc;
+    const size_t n = (size_t)1 << log_n;
+    if (d_in == d_out) {
+        if (int rc = ensure_scratch(ctx, (size_t)n_cols * n)) return rc;
+        bj::launch_bitrev_scale(d_in, ctx->d_scratch, log_n, n_cols, col_stride, n, 1, 1, ctx->stream);
+        if (col_stride == n) {
+            BJ_HIP(ctx, hipMemcpyAsync(d_out, ctx->d_scratch, (size_t)n_cols * n * sizeof(u64),
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            BJ_HIP(ctx, hipMemcpy2DAsync(d_out, col_stride * sizeof(u64), ctx->d_scratch, n * sizeof(u64),
+                                         n * sizeof(u64), n_cols, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    } else {
+        bj::launch_bitrev_scale(d_in, d_out, log_n, n_cols, col_stride, col_stride, 1, 1, ctx->stream);
+    }
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_canonicalize(bj_ctx *ctx, uint64_t *d_data, size_t n) {
+    if (int rc = bind(ctx)) return rc;
+    if (n == 0) return BJ_OK;
+    if (!d_data) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_canonicalize: null device pointer");
+    bj::launch_canonicalize(d_data, n, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+static int host_roundtrip(bj_ctx *ctx, uint64_t *h, unsigned log_n, unsigned n_cols, uint64_t coset, bool inverse) {
+    if (int rc = bind(ctx)) return rc;
+    if (!h) return fail(ctx, BJ_ERR_INVALID_ARG, "host NTT: null host pointer");
+    if (log_n > 30) return fail(ctx, BJ_ERR_UNSUPPORTED, "host NTT: log_n > 30");
+    size_t bytes = ((size_t)n_cols << log_n) * sizeof(u64);
+    if (!bytes) return BJ_OK;
+    u64 *d = nullptr;
+    BJ_HIP(ctx, hipMalloc((void **)&d, bytes));
+    int rc = bj_memcpy_h2d(ctx, d, h, bytes);
+    if (!rc)
+        rc = inverse ? bj_intt_batch(ctx, d, d, log_n, n_cols, (size_t)1 << log_n, coset)
+                     : bj_ntt_forward_batch(ctx, d, d, log_n, n_cols, (size_t)1 << log_n, coset);
+    if (!rc) rc = bj_memcpy_d2h(ctx, h, d, bytes);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}
+int bj_ntt_forward_host(bj_ctx *ctx, uint64_t *h_inout, unsigned log_n, unsigned n_cols, uint64_t coset) {
+    return host_roundtrip(ctx, h_inout, log_n, n_cols, coset, false);
+}
+int bj_intt_host(bj_ctx *ctx, uint64_t *h_inout, unsigned log_n, unsigned n_cols, uint64_t coset) {
+    return host_roundtrip(ctx, h_inout, log_n, n_cols, coset, true);
+}
+
+// ------------------------------------------------------------------------------------------- Poseidon2 Merkle
+
+size_t bj_merkle_tree_digests(size_t num_leaves, size_t cap_size) { return 2 * num_leaves - cap_size; }
+
+static int check_tree_args(bj_ctx *ctx, const char *fn, size_t num_leaves, size_t cap_size, const void *d_tree) {
+    if (!d_tree) return fail(ctx, BJ_ERR_INVALID_ARG, "%s: null tree pointer", fn);
+    if (!is_pow2(num_leaves) || !is_pow2(cap_size))
+        return fail(ctx, BJ_ERR_INVALID_ARG, "%s: num_leaves and cap_size must be powers of two", fn);
+    if (cap_size > num_leaves) return fail(ctx, BJ_ERR_INVALID_ARG, "%s: cap_size larger than the tree", fn);
+    return BJ_OK;
+}
+
+int bj_merkle_tree_nodes(bj_ctx *ctx, uint64_t *d_tree, size_t num_leaves, size_t cap_size) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_tree_args(ctx, "bj_merkle_tree_nodes", num_leaves, cap_size, d_tree)) return rc;
+    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_merkle_tree_build(bj_ctx *ctx, const uint64_t *d_cols, size_t col_stride, unsigned n_cols, size_t num_leaves,
+                         size_t cap_size, uint64_t *d_tree) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_tree_args(ctx, "bj_merkle_tree_build", num_leaves, cap_size, d_tree)) return rc;
+    if (!d_cols || n_cols == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build: no columns");
+    if (n_cols > 1 && col_stride < num_leaves)
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build: col_stride smaller than num_leaves");
+    bj::launch_poseidon2_leaves(d_cols, col_stride, nullptr, n_cols, num_leaves, d_tree, ctx->stream);
+    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_merkle_tree_build_ptrs(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, unsigned n_cols, size_t num_leaves,
+                              size_t cap_size, uint64_t *d_tree) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_tree_args(ctx, "bj_merkle_tree_build_ptrs", num_leaves, cap_size, d_tree)) return rc;
+    if (!h_col_ptrs || n_cols == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build_ptrs: no columns");
+    for (unsigned c = 0; c < n_cols; c++)
+        if (!h_col_ptrs[c]) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build_ptrs: null column %u", c);
+    if (n_cols > ctx->d_ptrs_cap) {
+        if (ctx->d_ptrs) {
+            BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            BJ_HIP(ctx, hipFree((void *)ctx->d_ptrs));
+            ctx->d_ptrs = nullptr;
+            ctx->d_ptrs_cap = 0;
+        }
+        size_t cap = n_cols < 1024 ? 1024 : n_cols;
+        BJ_HIP(ctx, hipMalloc((void **)&ctx->d_ptrs, cap * sizeof(u64 *)));
+        ctx->d_ptrs_cap = cap;
+    }
+    BJ_HIP(ctx, hipMemcpyAsync((void *)ctx->d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *), hipMemcpyHostToDevice,
+                               ctx->stream));
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's pointer array may be transient
+    bj::launch_poseidon2_leaves(nullptr, 0, ctx->d_ptrs, n_cols, num_leaves, d_tree, ctx->stream);
+    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_merkle_tree_build_chunked(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len,
+                                 unsigned log_elems_per_leaf, size_t cap_size, uint64_t *d_tree) {
+    if (int rc = bind(ctx)) return rc;
+    if (!d_c0 || !d_c1) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build_chunked: null source");
+    if (!is_pow2(len) || log_elems_per_leaf > 6 || ((size_t)1 << log_elems_per_leaf) > len)
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build_chunked: bad length / elements per leaf");
+    size_t num_leaves = len >> log_elems_per_leaf;
+    if (int rc = check_tree_args(ctx, "bj_merkle_tree_build_chunked", num_leaves, cap_size, d_tree)) return rc;
+    bj::launch_poseidon2_leaves_chunked(d_c0, d_c1, 2, log_elems_per_leaf, num_leaves, d_tree, ctx->stream);
+    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_merkle_tree_cap(bj_ctx *ctx, const uint64_t *d_tree, size_t num_leaves, size_t cap_size, uint64_t *h_cap) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_tree_args(ctx, "bj_merkle_tree_cap", num_leaves, cap_size, d_tree)) return rc;
+    if (!h_cap) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_cap: null host pointer");
+    return bj_memcpy_d2h(ctx, h_cap, d_tree + 4 * (2 * num_leaves - 2 * cap_size), 4 * cap_size * sizeof(u64));
+}
+
+int bj_merkle_tree_proof(bj_ctx *ctx, const uint64_t *d_tree, size_t num_leaves, size_t cap_size, size_t idx,
+                         uint64_t *h_leaf_digest, uint64_t *h_path) {
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_tree_args(ctx, "bj_merkle_tree_proof", num_leaves, cap_size, d_tree)) return rc;
+    if (idx >= num_leaves) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_proof: leaf index out of range");
+    if (!h_leaf_digest || (!h_path && num_leaves > cap_size))
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_proof: null host pointer");
+    BJ_HIP(ctx, hipMemcpyAsync(h_leaf_digest, d_tree + 4 * idx, 32, hipMemcpyDeviceToHost, ctx->stream));
+    const u64 *layer = d_tree;
+    size_t len = num_leaves, depth = 0;
+    while (len > cap_size) {
+        BJ_HIP(ctx, hipMemcpyAsync(h_path + 4 * depth, layer + 4 * (idx ^ 1), 32, hipMemcpyDeviceToHost, ctx->stream));
+        layer += 4 * len;
+        len /= 2;
+        idx >>= 1;
+        depth++;
+    }
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJ_OK;
+}
+
+int bj_poseidon2_permute(bj_ctx *ctx, uint64_t *d_states, size_t n_states) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_states == 0) return BJ_OK;
+    if (!d_states) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_poseidon2_permute: null device pointer");
+    bj::launch_poseidon2_permute_states(d_states, n_states, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------- FRI
+
+int bj_fri_fold(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len, uint64_t *d_o0, uint64_t *d_o1,
+                unsigned log_full, uint64_t coset_inv, uint64_t ch0, uint64_t ch1) {
+    if (int rc = bind(ctx)) return rc;
+    if (!d_c0 || !d_c1 || !d_o0 || !d_o1) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold: null device pointer");
+    if (!is_pow2(len) || len < 2) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold: length must be a power of two >= 2");
+    if (log_full > 32 || len > ((size_t)1 << log_full))
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold: array longer than the initial domain");
+    if (int rc = ensure_twiddles(ctx, log_full, true)) return rc;
+    (void)log2_exact;
+    bj::launch_fri_fold(d_c0, d_c1, len, d_o0, d_o1, ctx->tw_inv, coset_inv, ch0, ch1, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+}  // extern "C"

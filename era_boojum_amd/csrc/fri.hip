@@ -1,0 +1,45 @@
+// FRI fold over F_p^2 (two base columns c0, c1 in bit-reversed order) for gfx950.
+//
+// Must equal fold_multiple (src/cs/implementations/fri/mod.rs:362-474) as driven by interpolate_independent_cosets
+// (:476-585) / interpolate_flattened_cosets (:587-678):
+//     out[i] = (a + b) + alpha * ((a - b) * roots[i] * coset_inv),   a = in[2i], b = in[2i+1]      (no 1/2 factor)
+// roots = the inverse bit-reversed twiddle table of the FULL initial LDE domain (prefix reused at every level),
+// coset_inv is squared by the caller after every fold and alpha squared between the folds of one schedule step.
+// HBM-bound pointwise kernel: 32 B read + 16 B written per output element, one F_p^2 multiplication.
+#include "gl.cuh"
+#include "kernels.h"
+
+using gl::u64;
+
+namespace bj {
+
+__global__ void __launch_bounds__(256)
+fri_fold_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 *roots, size_t half, u64 coset_inv, u64 ch0,
+                u64 ch1) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    const gl::e2 alpha{ch0, ch1};
+    for (; i < half; i += stride) {
+        ulonglong2 p0 = reinterpret_cast<const ulonglong2 *>(c0)[i];
+        ulonglong2 p1 = reinterpret_cast<const ulonglong2 *>(c1)[i];
+        u64 a0 = gl::canon(p0.x), b0 = gl::canon(p0.y), a1 = gl::canon(p1.x), b1 = gl::canon(p1.y);
+        u64 r = gl::mul(gl::canon(roots[i]), coset_inv);
+        gl::e2 diff{gl::mul(gl::sub(a0, b0), r), gl::mul(gl::sub(a1, b1), r)};
+        gl::e2 m = gl::e2_mul(diff, alpha);
+        o0[i] = gl::add(gl::add(m.c0, a0), b0);
+        o1[i] = gl::add(gl::add(m.c1, a1), b1);
+    }
+}
+
+void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u64 *d_o1, const u64 *d_roots,
+                     u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s) {
+    size_t half = len / 2;
+    if (!half) return;
+    unsigned tpb = 256;
+    size_t blocks = (half + tpb - 1) / tpb;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, half,
+                       gl::canon(coset_inv), gl::canon(ch0), gl::canon(ch1));
+}
+
+}  // namespace bj

@@ -1,0 +1,31 @@
+// Internal launch interface between the kernel translation units (*.hip) and the C-ABI layer (boojum_hip.cpp).
+// Not part of the public boundary (that is include/boojum_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace bj {
+typedef uint64_t u64;
+
+// ntt.hip
+void launch_twiddles(u64 *d_out, unsigned log_n, bool inverse, hipStream_t s);
+void launch_round_scales(u64 *d_out, const u64 *h_shifts, unsigned n_cosets, unsigned log_n, hipStream_t s);
+void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
+                       unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s);
+void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n_cols, size_t in_col_stride,
+                         size_t out_col_stride, u64 scale, u64 step, hipStream_t s);
+void launch_canonicalize(u64 *d, size_t n, hipStream_t s);
+
+// poseidon2.hip
+void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
+                             size_t num_leaves, u64 *d_digests, hipStream_t s);
+void launch_poseidon2_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsigned n_srcs, unsigned log_e,
+                                     size_t num_leaves, u64 *d_digests, hipStream_t s);
+void launch_poseidon2_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s);
+void launch_poseidon2_permute_states(u64 *d_states, size_t n_states, hipStream_t s);
+
+// fri.hip
+void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u64 *d_o1, const u64 *d_roots,
+                     u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s);
+}  // namespace bj

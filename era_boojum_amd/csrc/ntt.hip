@@ -1,0 +1,210 @@
+// Batched radix-2 Goldilocks NTT / coset LDE / iNTT kernels for gfx950 (hand-written HIP, no CUDA shims).
+//
+// What is computed (must equal, as canonical residues, the reference's CPU path):
+//   forward  : fft_natural_to_bitreversed        src/fft/mod.rs:398-411 + serial_ct_ntt :659-734
+//   inverse  : ifft_natural_to_natural           src/fft/mod.rs:464-491
+//   LDE      : transform_monomials_to_lde        src/cs/implementations/utils.rs:311-403
+//   twiddles : precompute_twiddles_for_fft       src/cs/implementations/utils.rs:88-125  (T[j] = w^bitrev(j), j < n/2)
+//
+// Structure.  The reference's in-place algorithm has round r (0-based) pair elements n/2^(r+1) apart, 2^r groups,
+// group k using T[k].  A transform is cut into passes of consecutive rounds [r0, r0+R); within a pass, index
+// i = hi * 2^(log_n-r0) + mid * 2^(log_n-r0-R) + lo, only the R "mid" bits interact.  One workgroup owns one tile
+// = (hi, 2^Wl consecutive lo) x all 2^R mid, staged in LDS, so every HBM access is a contiguous run of 2^Wl
+// elements (Wl = 0 in the last pass, whose tile is 2^R contiguous elements).
+//
+// Coset evaluation needs no separate "distribute powers" sweep: scaling the input by shift^i is equivalent to
+// multiplying the round-r twiddle by shift^(n/2^(r+1)) (the factor shift^(i mod n/2^(r+1)) commutes through the
+// butterfly), so the kernel takes a per-round scale table instead.  Same residues, one HBM pass fewer.
+#include "gl.cuh"
+#include "kernels.h"
+
+using gl::u64;
+using gl::u32;
+
+namespace bj {
+
+// ---------------------------------------------------------------------------------------------------------
+// twiddle table generation:  T[j] = w^(bitrev_{log_n-1}(j))
+// ---------------------------------------------------------------------------------------------------------
+__global__ void twiddle_kernel(u64 *out, unsigned log_n, u64 w) {
+    size_t half = (size_t)1 << (log_n - 1);
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= half) return;
+    u32 e = gl::bitrev32((u32)j, log_n - 1);
+    out[j] = gl::pow(w, e);
+}
+
+void launch_twiddles(u64 *d_out, unsigned log_n, bool inverse, hipStream_t s) {
+    if (log_n == 0) return;
+    u64 w = gl::omega(log_n);
+    if (inverse) w = gl::inv(w);
+    size_t half = (size_t)1 << (log_n - 1);
+    unsigned tpb = 256;
+    hipLaunchKernelGGL(twiddle_kernel, dim3((unsigned)((half + tpb - 1) / tpb)), dim3(tpb), 0, s, d_out, log_n, w);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// generic LDS pass (any R + Wl <= 13).  v0 kernel: correct for every shape, used for small sizes and as the
+// fallback; the specialised register-radix kernels below take over for the big shapes.
+// ---------------------------------------------------------------------------------------------------------
+struct PassArgs {
+    const u64 *in;
+    u64 *out;
+    const u64 *tw;           // bit-reversed twiddle table (>= 2^(r0+R-1) entries)
+    const u64 *round_scale;  // [n_cosets][32] per-round twiddle scale, or nullptr (plain subgroup transform)
+    unsigned log_n, r0, R, Wl;
+    size_t in_col_stride;    // elements between input columns
+    size_t in_coset_stride;  // 0 when every coset reads the same input column (first LDE pass), n when in place
+    size_t out_col_stride;   // elements between output columns (each column holds n_cosets * n outputs)
+};
+
+__global__ void __launch_bounds__(256) ntt_pass_generic_kernel(PassArgs a) {
+    extern __shared__ u64 tile[];
+    const unsigned R = a.R, Wl = a.Wl;
+    const unsigned tile_log = R + Wl;
+    const u32 tile_elems = 1u << tile_log;
+    const unsigned rem_log = a.log_n - a.r0 - R;        // bits of "lo"
+    const u32 tiles_per_hi = 1u << (rem_log - Wl);
+    const u32 hi = blockIdx.x / tiles_per_hi;
+    const u32 lo_tile = blockIdx.x % tiles_per_hi;
+    const size_t n = (size_t)1 << a.log_n;
+    const unsigned col = blockIdx.y, coset = blockIdx.z;
+    const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride;
+    u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n;
+    const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << Wl);
+    const u64 *rs = a.round_scale ? a.round_scale + (size_t)coset * 32 : nullptr;
+
+    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+        u32 mid = e >> Wl, lo = e & ((1u << Wl) - 1);
+        tile[e] = gl::canon(src[base + ((size_t)mid << rem_log) + lo]);
+    }
+    __syncthreads();
+    for (unsigned s = 0; s < R; s++) {
+        const unsigned r = a.r0 + s;
+        const u64 sc = rs ? rs[r] : 1;
+        const unsigned jbits = R - 1 - s;               // bits of "j" inside a group
+        for (u32 q = threadIdx.x; q < (tile_elems >> 1); q += blockDim.x) {
+            u32 lo = q & ((1u << Wl) - 1);
+            u32 qm = q >> Wl;                           // (g, j)
+            u32 g = qm >> jbits, j = qm & ((1u << jbits) - 1);
+            u32 mid_u = (g << (R - s)) | j;
+            u32 iu = (mid_u << Wl) | lo, iv = iu + (1u << (jbits + Wl));
+            u32 k = (hi << s) | g;
+            u64 u = tile[iu], v = tile[iv];
+            if (r != 0 || rs) {                         // round 0 twiddle is 1 unless coset-scaled
+                u64 t = a.tw[k];
+                if (rs) t = gl::mul(t, sc);
+                v = gl::mul(v, t);
+            }
+            tile[iu] = gl::add(u, v);
+            tile[iv] = gl::sub(u, v);
+        }
+        __syncthreads();
+    }
+    for (u32 e = threadIdx.x; e < tile_elems; e += blockDim.x) {
+        u32 mid = e >> Wl, lo = e & ((1u << Wl) - 1);
+        dst[base + ((size_t)mid << rem_log) + lo] = tile[e];
+    }
+}
+
+// per-round twiddle scale for a coset shift: sc[r] = shift^(n / 2^(r+1)); shifts travel by value (kernarg)
+struct ShiftArgs {
+    u64 v[64];
+};
+__global__ void round_scale_kernel(u64 *out, ShiftArgs shifts, unsigned n_cosets, unsigned log_n) {
+    unsigned c = blockIdx.x, r = threadIdx.x;
+    if (c >= n_cosets || r >= 32) return;
+    u64 v = 1;
+    if (r < log_n) {
+        v = gl::canon(shifts.v[c]);
+        for (unsigned i = 0; i < log_n - 1 - r; i++) v = gl::sqr(v);
+    }
+    out[(size_t)c * 32 + r] = v;
+}
+void launch_round_scales(u64 *d_out, const u64 *h_shifts, unsigned n_cosets, unsigned log_n, hipStream_t s) {
+    ShiftArgs a;
+    for (unsigned c = 0; c < 64; c++) a.v[c] = c < n_cosets ? h_shifts[c] : 1;
+    hipLaunchKernelGGL(round_scale_kernel, dim3(n_cosets), dim3(32), 0, s, d_out, a, n_cosets, log_n);
+}
+
+// Plan: last pass local with up to LOCAL_MAX rounds; earlier rounds in strided passes of <= STRIDED_MAX rounds.
+static constexpr unsigned LOCAL_MAX = 12, STRIDED_MAX = 8, TILE_LOG = 12;
+
+void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
+                       unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride,
+                       hipStream_t s) {
+    const size_t n = (size_t)1 << log_n;
+    if (log_n == 0) {  // size-1 transform: canonicalising copy
+        PassArgs a{d_in, d_out, d_tw, nullptr, 0, 0, 0, 0, in_col_stride, 0, out_col_stride};
+        hipLaunchKernelGGL(ntt_pass_generic_kernel, dim3(1, n_cols, n_cosets), dim3(64), 8, s, a);
+        return;
+    }
+    unsigned local = log_n < LOCAL_MAX ? log_n : LOCAL_MAX;
+    unsigned rest = log_n - local;
+    unsigned n_strided = (rest + STRIDED_MAX - 1) / STRIDED_MAX;
+    unsigned r0 = 0;
+    // the first pass reads the caller's column (shared by all cosets); later passes run in place on d_out
+    const u64 *src = d_in;
+    size_t src_col_stride = in_col_stride, src_coset_stride = 0;
+    for (unsigned p = 0; p <= n_strided; p++) {
+        unsigned R, Wl;
+        if (p < n_strided) {
+            R = rest / n_strided + (p < rest % n_strided ? 1 : 0);
+            unsigned rem_log = log_n - r0 - R;
+            Wl = TILE_LOG - R;
+            if (Wl > rem_log) Wl = rem_log;
+        } else {
+            R = local;
+            Wl = 0;
+        }
+        PassArgs a{src, d_out, d_tw, d_round_scale, log_n, r0, R, Wl, src_col_stride, src_coset_stride, out_col_stride};
+        unsigned tiles = 1u << (log_n - R - Wl);
+        size_t lds = ((size_t)8) << (R + Wl);
+        unsigned tpb = (1u << (R + Wl)) / 2;
+        if (tpb > 256) tpb = 256;
+        if (tpb < 64) tpb = 64;
+        hipLaunchKernelGGL(ntt_pass_generic_kernel, dim3(tiles, n_cols, n_cosets), dim3(tpb), lds, s, a);
+        r0 += R;
+        src = d_out;
+        src_col_stride = out_col_stride;
+        src_coset_stride = n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bit-reversal permutation (+ optional scaling by scale * step^i), out-of-place:  out[i] = in[bitrev(i)] * ...
+// (bitreverse_enumeration_inplace fft/mod.rs:41-155; the n^-1 and coset^-i factors of ifft_natural_to_natural)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void bitrev_scale_kernel(const u64 *in, u64 *out, unsigned log_n, size_t in_col_stride,
+                                    size_t out_col_stride, u64 scale, u64 step) {
+    size_t n = (size_t)1 << log_n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 *src = in + (size_t)blockIdx.y * in_col_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_col_stride;
+    u64 v = gl::canon(src[gl::bitrev32((u32)i, log_n)]);
+    if (scale != 1) v = gl::mul(v, scale);
+    if (step != 1) v = gl::mul(v, gl::pow(step, i));
+    dst[i] = v;
+}
+void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n_cols, size_t in_col_stride,
+                         size_t out_col_stride, u64 scale, u64 step, hipStream_t s) {
+    size_t n = (size_t)1 << log_n;
+    unsigned tpb = 256;
+    hipLaunchKernelGGL(bitrev_scale_kernel, dim3((unsigned)((n + tpb - 1) / tpb), n_cols), dim3(tpb), 0, s, d_in,
+                       d_out, log_n, in_col_stride, out_col_stride, scale, step);
+}
+
+__global__ void canonicalize_kernel(u64 *a, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = gl::canon(a[i]);
+}
+void launch_canonicalize(u64 *d, size_t n, hipStream_t s) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s, d, n);
+}
+
+}  // namespace bj

@@ -1,0 +1,151 @@
+/* boojum_hip.h — C ABI of the MI355X-native Boojum proving hot path (libboojum_hip.so).
+ *
+ * The reference (matter-labs/era-boojum, pure Rust) has no FFI boundary of its own; this
+ * header IS the boundary a Rust host binds with `extern "C"` (see INTEGRATION.md for the shim).  Every entry point
+ * names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - All field data are Goldilocks elements (p = 2^64 - 2^32 + 1) stored as little-endian u64.  Inputs may be any
+ *    u64 (the reference tolerates non-canonical values in memory, src/field/goldilocks/mod.rs:98-107); every output
+ *    is the canonical residue in [0, p).  Parity with the reference = equality of canonical residues.
+ *  - F_p^2 = F_p[u]/(u^2-7) values are two separate base columns (c0, c1), never interleaved
+ *    (src/field/traits/field_like.rs:617-642).
+ *  - "d_" pointers are device (HBM) pointers on the context's GPU, "h_" pointers are host pointers.  Plain
+ *    pointers and sizes only; no torch / C++ types cross this boundary.
+ *  - Column batches are column-major: column c starts at base + c*col_stride (in elements).  An LDE column is
+ *    [coset][n] with each coset in bit-reversed order, i.e. global index I = coset*n + i is the bit-reversed
+ *    enumeration of g*<w_{nL}> (src/cs/implementations/utils.rs:311-403, src/cs/implementations/proof.rs:89-91).
+ *  - Work is enqueued on the context's HIP stream and is asynchronous unless stated; bj_sync() drains it.
+ *  - Errors: functions return BJ_OK (0) or a negative bj_status; the reference panics/asserts instead
+ *    (e.g. src/cs/implementations/prover.rs:1425-1438).  bj_last_error() gives the message for the context.
+ *  - There is NO CPU fallback: without a usable HIP device bj_ctx_create fails with BJ_ERR_NO_DEVICE.
+ */
+#ifndef BOOJUM_HIP_H
+#define BOOJUM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bj_status {
+    BJ_OK = 0,
+    BJ_ERR_INVALID_ARG = -1,
+    BJ_ERR_NO_DEVICE = -2,
+    BJ_ERR_HIP = -3,
+    BJ_ERR_OOM = -4,
+    BJ_ERR_UNSUPPORTED = -5
+} bj_status;
+
+/* Opaque per-GPU context: device id, HIP stream, cached twiddle tables, scratch.  Replaces the role of the
+ * reference's `Worker` (src/worker/mod.rs:5-87, a rayon pool) + `P::Context` at the call sites. */
+typedef struct bj_ctx bj_ctx;
+
+#define BJ_ABI_VERSION 1
+int bj_abi_version(void);
+int bj_device_count(void);
+const char *bj_status_string(int status);
+
+int bj_ctx_create(int device, bj_ctx **out);
+void bj_ctx_destroy(bj_ctx *ctx);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream) for all subsequent work; NULL = the default stream. */
+int bj_ctx_set_stream(bj_ctx *ctx, void *hip_stream);
+const char *bj_last_error(const bj_ctx *ctx);
+int bj_sync(bj_ctx *ctx);
+
+/* Device memory helpers for hosts that do not bring their own allocator (the reference threads `A: GoodAllocator`,
+ * src/cs/traits/mod.rs:13, through every buffer for exactly this purpose). */
+int bj_malloc(bj_ctx *ctx, size_t bytes, void **d_ptr);
+int bj_free(bj_ctx *ctx, void *d_ptr);
+int bj_memcpy_h2d(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* HIP-event stopwatch on the context's stream (used by bench.py to time the kernels where they are launched). */
+int bj_timer_start(bj_ctx *ctx);
+int bj_timer_stop_ms(bj_ctx *ctx, float *ms); /* synchronises on the stop event */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * NTT family.  Replaces PrimeFieldLikeVectorized::{fft_natural_to_bitreversed, ifft_natural_to_natural,
+ * precompute_forward/inverse_twiddles_for_fft} (src/field/traits/field_like.rs:139-161), which the reference calls
+ * once per polynomial from rayon workers (src/cs/implementations/utils.rs:295-304, 363-379); here one call
+ * transforms a whole batch of columns.  Twiddle tables (utils.rs:88-125) are cached inside the context.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* fft_natural_to_bitreversed (src/fft/mod.rs:398-411): for each column, natural-order coefficients ->
+ * evaluations on coset*<w_n> in bit-reversed order.  In place when d_out == d_in. */
+int bj_ntt_forward_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
+                         size_t col_stride, uint64_t coset);
+
+/* ifft_natural_to_natural (src/fft/mod.rs:464-491): natural-order evaluations on coset*<w_n> -> natural-order
+ * monomial coefficients (includes the n^-1 and coset^-i factors).  In place when d_out == d_in. */
+int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
+                  size_t col_stride, uint64_t coset);
+
+/* transform_monomials_to_lde (src/cs/implementations/utils.rs:311-403): monomials [n_cols][n] (col_stride apart)
+ * -> d_out [n_cols][2^log_lde][n]; coset c is evaluated on g*w_{nL}^{bitrev(c)} * <w_n>, bit-reversed.
+ * d_out must not alias d_mono. */
+int bj_lde_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                 unsigned n_cols, unsigned log_lde);
+
+/* transform_raw_storages_to_lde (utils.rs:270-309): natural-order trace columns -> monomials (written back to
+ * d_cols) -> LDE in d_out, i.e. bj_intt_batch(coset 1) followed by bj_lde_batch. */
+int bj_trace_to_lde_batch(bj_ctx *ctx, uint64_t *d_cols, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                          unsigned n_cols, unsigned log_lde);
+
+/* bitreverse_enumeration_inplace (src/fft/mod.rs:41-155), out of place or in place per column. */
+int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
+                        size_t col_stride);
+
+/* Reduce every element to its canonical residue (what the reference does on serialisation, goldilocks/mod.rs:98-107). */
+int bj_canonicalize(bj_ctx *ctx, uint64_t *d_data, size_t n);
+
+/* Host-memory convenience for single-polynomial plumbing (what a Rust `impl PrimeFieldLikeVectorized` would call);
+ * synchronous, includes the PCIe copies. */
+int bj_ntt_forward_host(bj_ctx *ctx, uint64_t *h_inout, unsigned log_n, unsigned n_cols, uint64_t coset);
+int bj_intt_host(bj_ctx *ctx, uint64_t *h_inout, unsigned log_n, unsigned n_cols, uint64_t coset);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Poseidon2 Merkle trees.  Replaces TreeHasher::{hash_into_leaf, hash_into_node} for the Poseidon2 sponge
+ * (src/cs/oracle/mod.rs:84-176) and MerkleTreeWithCap::{construct, construct_by_chunking[_from_flat_sources],
+ * continue_from_leaf_hashes, get_cap} (src/cs/oracle/merkle_tree.rs:78-460).
+ * A tree is stored as all its layers back to back, 4 u64 per digest: layer 0 = num_leaves leaf digests, layer 1 =
+ * num_leaves/2, ..., last layer = cap_size digests (the cap).  Size: bj_merkle_tree_digests() * 4 u64.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t bj_merkle_tree_digests(size_t num_leaves, size_t cap_size); /* = 2*num_leaves - cap_size */
+
+/* construct: leaf I = hash(col_0[I], col_1[I], ...); columns at d_cols + c*col_stride, each num_leaves long
+ * (= lde_factor * n, the [coset][n] layout). */
+int bj_merkle_tree_build(bj_ctx *ctx, const uint64_t *d_cols, size_t col_stride, unsigned n_cols, size_t num_leaves,
+                         size_t cap_size, uint64_t *d_tree);
+/* same, columns given as a HOST array of n_cols DEVICE pointers (leaf order = array order; lets one tree span
+ * several column batches, e.g. variables || witness || multiplicities, prover.rs:317-343). */
+int bj_merkle_tree_build_ptrs(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, unsigned n_cols, size_t num_leaves,
+                              size_t cap_size, uint64_t *d_tree);
+/* construct_by_chunking over an F_p^2 codeword: leaf j = hash(c0[jE..(j+1)E) || c1[jE..(j+1)E)), E = 2^log_elems. */
+int bj_merkle_tree_build_chunked(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len,
+                                 unsigned log_elems_per_leaf, size_t cap_size, uint64_t *d_tree);
+/* continue_from_leaf_hashes: layer 0 of d_tree already holds the leaf digests; fill the upper layers. */
+int bj_merkle_tree_nodes(bj_ctx *ctx, uint64_t *d_tree, size_t num_leaves, size_t cap_size);
+/* get_cap: copy the cap (cap_size * 4 u64) to the host; synchronous. */
+int bj_merkle_tree_cap(bj_ctx *ctx, const uint64_t *d_tree, size_t num_leaves, size_t cap_size, uint64_t *h_cap);
+/* get_proof (merkle_tree.rs:462-480): leaf digest + sibling path (depth*4 u64, depth = log2(num_leaves/cap_size))
+ * for leaf idx, copied to the host; synchronous. */
+int bj_merkle_tree_proof(bj_ctx *ctx, const uint64_t *d_tree, size_t num_leaves, size_t cap_size, size_t idx,
+                         uint64_t *h_leaf_digest, uint64_t *h_path);
+/* Raw permutation on n_states 12-word states in device memory (testing / transcript offload). */
+int bj_poseidon2_permute(bj_ctx *ctx, uint64_t *d_states, size_t n_states);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * FRI.  Replaces fold_multiple / interpolate_* (src/cs/implementations/fri/mod.rs:362-678).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* One fold by 2 of the bit-reversed F_p^2 array (c0, c1) of length len into (o0, o1) of length len/2:
+ *   out[i] = (a + b) + (ch0 + ch1*u) * ((a - b) * roots[i] * coset_inv),  a = in[2i], b = in[2i+1].
+ * roots = inverse bit-reversed twiddles of the initial LDE domain of size 2^log_full (cached in the context). */
+int bj_fri_fold(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len, uint64_t *d_o0, uint64_t *d_o1,
+                unsigned log_full, uint64_t coset_inv, uint64_t ch0, uint64_t ch1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOOJUM_HIP_H */

@@ -1,0 +1,48 @@
+"""Shared helpers for the -m gpu parity tests (HIP path through the C ABI vs the CPU oracle)."""
+import numpy as np
+
+import era_boojum_amd as E
+
+P = E.P
+_ctx = None
+
+
+def ctx():
+    """One context for the whole test session; raises (no skip, no fallback) when there is no GPU."""
+    global _ctx
+    if _ctx is None:
+        _ctx = E.Context(0)
+    return _ctx
+
+
+def rand_gl(rng, shape, noncanonical=False):
+    a = rng.integers(0, P, size=shape, dtype=np.uint64)
+    if noncanonical:
+        mask = rng.random(size=shape) < 0.05
+        a = np.where(mask, np.uint64(P) + rng.integers(0, (1 << 32) - 1, size=shape, dtype=np.uint64), a)
+        flat = a.reshape(-1)
+        if flat.size:
+            flat[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        if flat.size > 1:
+            flat[-1] = np.uint64(P)
+    return a
+
+
+class DevBuf:
+    def __init__(self, arr=None, nelems=None):
+        c = ctx()
+        if arr is not None:
+            arr = np.ascontiguousarray(arr, dtype=np.uint64)
+            self.n = arr.size
+            self.ptr = c.upload(arr)
+        else:
+            self.n = nelems
+            self.ptr = c.malloc(max(8, 8 * nelems))
+
+    def get(self, shape=None):
+        return ctx().d2h(self.ptr, shape if shape is not None else (self.n,))
+
+    def free(self):
+        if self.ptr:
+            ctx().free(self.ptr)
+            self.ptr = None

@@ -1,0 +1,132 @@
+"""-m gpu parity: HIP NTT / iNTT / LDE (through the C ABI) vs the CPU oracle, bit-exact canonical residues.
+Mirrors the reference's differential tests (fft/mod.rs:1345-1709) incl. non-canonical inputs and coset 7."""
+import numpy as np
+import pytest
+
+import oracle as O
+from gpu_util import DevBuf, ctx, rand_gl, P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 17])
+@pytest.mark.parametrize("coset", [1, 7])
+def test_forward_matches_oracle(log_n, coset):
+    rng = np.random.default_rng(1000 + log_n)
+    n_cols = 3 if log_n < 16 else 2
+    a = rand_gl(rng, (n_cols, 1 << log_n), noncanonical=True)
+    want = O.fft_batch(a, coset, threads=4)
+    d_in, d_out = DevBuf(a), DevBuf(nelems=a.size)
+    ctx().ntt_forward_batch(d_in.ptr, d_out.ptr, log_n, n_cols, coset=coset)
+    got = d_out.get(a.shape)
+    assert np.array_equal(got, want)
+    # in place
+    ctx().ntt_forward_batch(d_in.ptr, d_in.ptr, log_n, n_cols, coset=coset)
+    assert np.array_equal(d_in.get(a.shape), want)
+    d_in.free(); d_out.free()
+
+
+def test_forward_random_coset_and_strided_columns():
+    log_n, n_cols, stride = 11, 5, (1 << 11) + 64
+    rng = np.random.default_rng(5)
+    buf = rand_gl(rng, (n_cols, stride))
+    coset = 0x123456789ABCDEF % P
+    want = O.fft_batch(np.ascontiguousarray(buf[:, :1 << log_n]), coset)
+    d = DevBuf(buf)
+    ctx().ntt_forward_batch(d.ptr, d.ptr, log_n, n_cols, col_stride=stride, coset=coset)
+    got = d.get(buf.shape)
+    assert np.array_equal(got[:, :1 << log_n], want)
+    assert np.array_equal(got[:, 1 << log_n:], buf[:, 1 << log_n:])  # gap between columns untouched
+    d.free()
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 12, 13, 16])
+@pytest.mark.parametrize("coset", [1, 7])
+def test_inverse_matches_oracle_and_roundtrips(log_n, coset):
+    rng = np.random.default_rng(2000 + log_n)
+    a = rand_gl(rng, (2, 1 << log_n), noncanonical=True)
+    want = O.ifft_batch(a, coset, threads=2)
+    d = DevBuf(a)
+    out = DevBuf(nelems=a.size)
+    ctx().intt_batch(d.ptr, out.ptr, log_n, 2, coset=coset)
+    assert np.array_equal(out.get(a.shape), want)
+    # NTT(iNTT(x)) on the same coset, un-bit-reversed, is x
+    ctx().ntt_forward_batch(out.ptr, out.ptr, log_n, 2, coset=coset)
+    ctx().bitreverse_batch(out.ptr, out.ptr, log_n, 2)
+    assert np.array_equal(out.get(a.shape), O.canonical(a))
+    d.free(); out.free()
+
+
+@pytest.mark.parametrize("log_n,log_lde", [(0, 1), (3, 1), (6, 3), (10, 2), (13, 3), (14, 1)])
+def test_lde_matches_oracle(log_n, log_lde):
+    rng = np.random.default_rng(3000 + log_n)
+    n_cols = 3
+    mono = rand_gl(rng, (n_cols, 1 << log_n), noncanonical=True)
+    want = O.lde_batch(mono, log_lde, threads=4)
+    d_m, d_o = DevBuf(mono), DevBuf(nelems=want.size)
+    ctx().lde_batch(d_m.ptr, d_o.ptr, log_n, n_cols, log_lde)
+    assert np.array_equal(d_o.get(want.shape), want)
+    d_m.free(); d_o.free()
+
+
+def test_trace_to_lde_matches_oracle():
+    log_n, log_lde, n_cols = 12, 3, 4
+    rng = np.random.default_rng(77)
+    trace = rand_gl(rng, (n_cols, 1 << log_n))
+    mono = O.ifft_batch(trace, 1, threads=4)
+    want = O.lde_batch(mono, log_lde, threads=4)
+    d_t, d_o = DevBuf(trace), DevBuf(nelems=want.size)
+    ctx().trace_to_lde_batch(d_t.ptr, d_o.ptr, log_n, n_cols, log_lde)
+    assert np.array_equal(d_o.get(want.shape), want)
+    assert np.array_equal(d_t.get(trace.shape), mono)      # monomials are left in the input buffer
+    # first coset of an LDE with shift g equals a plain coset-7 NTT (utils.rs:345-346 with bitrev(0) = 0)
+    assert np.array_equal(want[:, 0, :], O.fft_batch(mono, 7))
+    d_t.free(); d_o.free()
+
+
+def test_host_convenience_path():
+    rng = np.random.default_rng(9)
+    a = rand_gl(rng, (2, 1 << 10), noncanonical=True)
+    assert np.array_equal(ctx().ntt_forward_host(a, 7), O.fft_batch(a, 7))
+    assert np.array_equal(ctx().intt_host(a, 7), O.ifft_batch(a, 7))
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    import era_boojum_amd as E
+    d = DevBuf(nelems=16)
+    with pytest.raises(E.BoojumHipError):
+        ctx().ntt_forward_batch(d.ptr, d.ptr, 33, 1)
+    with pytest.raises(E.BoojumHipError):
+        ctx().ntt_forward_batch(d.ptr, d.ptr, 3, 2, col_stride=4)
+    with pytest.raises(E.BoojumHipError):
+        ctx().lde_batch(d.ptr, d.ptr, 2, 1, 1)
+    with pytest.raises(E.BoojumHipError):
+        ctx().ntt_forward_batch(d.ptr, d.ptr, 2, 1, coset=0)
+    d.free()
+
+
+def test_full_size_2_20_properties_and_spot_columns():
+    """BASELINE cfg2 shape (2^20 rows; 16 of the 256 columns here): spot columns vs the oracle, plus the
+    size-independent properties linearity and iNTT∘NTT = id on all columns."""
+    log_n, n_cols = 20, 16
+    rng = np.random.default_rng(20240807)
+    a = rand_gl(rng, (n_cols, 1 << log_n), noncanonical=True)
+    d_a, d_o = DevBuf(a), DevBuf(nelems=a.size)
+    for coset in (1, 7):
+        ctx().ntt_forward_batch(d_a.ptr, d_o.ptr, log_n, n_cols, coset=coset)
+        got = d_o.get(a.shape)
+        want = O.fft_batch(a[[0, 7, 15]], coset, threads=3)
+        assert np.array_equal(got[[0, 7, 15]], want)
+        # linearity: NTT(col0 + col1) == NTT(col0) + NTT(col1)
+        s = ((a[0].astype(object) + a[1].astype(object)) % P).astype(np.uint64)
+        d_s = DevBuf(s)
+        ctx().ntt_forward_batch(d_s.ptr, d_s.ptr, log_n, 1, coset=coset)
+        lhs = d_s.get()
+        rhs = ((got[0].astype(object) + got[1].astype(object)) % P).astype(np.uint64)
+        assert np.array_equal(lhs, rhs)
+        d_s.free()
+        # round trip on all columns
+        ctx().bitreverse_batch(d_o.ptr, d_o.ptr, log_n, n_cols)
+        ctx().intt_batch(d_o.ptr, d_o.ptr, log_n, n_cols, coset=coset)
+        assert np.array_equal(d_o.get(a.shape), O.canonical(a))
+    d_a.free(); d_o.free()
