@@ -124,7 +124,8 @@ def main():
 
     if rank == 0 and not args.no_cpu_baseline:
         import oracle as O
-        threads = os.cpu_count() or 1
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        threads = min(threads, 64)
         host = src[: min(n_cols, 4 * threads)].cpu().numpy().view(np.uint64)
         # parity spot check of what was just timed (2 columns), then the timed CPU leg
         got = dst[:2].cpu().numpy().view(np.uint64)

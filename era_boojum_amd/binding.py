@@ -49,7 +49,8 @@ class BoojumHipError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libboojum_hip.so")
+    # BOOJUM_HIP_LIB lets tuning experiments point at an alternative build of the SAME library (never a fallback)
+    return os.environ.get("BOOJUM_HIP_LIB") or os.path.join(_HERE, "libboojum_hip.so")
 
 
 def exported_symbols():

@@ -17,6 +17,17 @@ void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s);
 void launch_canonicalize(u64 *d, size_t n, hipStream_t s);
 
+// ntt_r16.hip (register-radix-16 passes)
+void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n,
+                        unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
+                        size_t out_col_stride, hipStream_t s);
+void launch_ntt_strided8(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
+                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
+                         size_t out_col_stride, hipStream_t s);
+void launch_ntt_strided4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
+                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
+                         size_t out_col_stride, hipStream_t s);
+
 // poseidon2.hip
 void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
                              size_t num_leaves, u64 *d_digests, hipStream_t s);

@@ -17,6 +17,7 @@
 // butterfly), so the kernel takes a per-round scale table instead.  Same residues, one HBM pass fewer.
 #include "gl.cuh"
 #include "kernels.h"
+#include <cstdlib>
 
 using gl::u64;
 using gl::u32;
@@ -130,45 +131,89 @@ void launch_round_scales(u64 *d_out, const u64 *h_shifts, unsigned n_cosets, uns
 // Plan: last pass local with up to LOCAL_MAX rounds; earlier rounds in strided passes of <= STRIDED_MAX rounds.
 static constexpr unsigned LOCAL_MAX = 12, STRIDED_MAX = 8, TILE_LOG = 12;
 
+static void launch_generic_pass(const u64 *src, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale,
+                                unsigned log_n, unsigned r0, unsigned R, unsigned Wl, unsigned n_cols,
+                                unsigned n_cosets, size_t src_col_stride, size_t src_coset_stride,
+                                size_t out_col_stride, hipStream_t s) {
+    PassArgs a{src, d_out, d_tw, d_round_scale, log_n, r0, R, Wl, src_col_stride, src_coset_stride, out_col_stride};
+    unsigned tiles = 1u << (log_n - R - Wl);
+    size_t lds = ((size_t)8) << (R + Wl);
+    unsigned tpb = (1u << (R + Wl)) / 2;
+    if (tpb > 256) tpb = 256;
+    if (tpb < 64) tpb = 64;
+    hipLaunchKernelGGL(ntt_pass_generic_kernel, dim3(tiles, n_cols, n_cosets), dim3(tpb), lds, s, a);
+}
+
+static bool force_generic() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("BJ_NTT_GENERIC");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+// Pass plan.  log_n < 12 (or BJ_NTT_GENERIC=1): generic LDS passes.  Otherwise the last 12 rounds run in
+// ntt_local12, the rounds in front of it in radix-16 strided passes of 8 or 4 rounds, and a remainder of 1..3
+// rounds (log_n not of the form 12 + 4k) in one generic strided pass at the very front.
 void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
                        unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride,
                        hipStream_t s) {
     const size_t n = (size_t)1 << log_n;
     if (log_n == 0) {  // size-1 transform: canonicalising copy
-        PassArgs a{d_in, d_out, d_tw, nullptr, 0, 0, 0, 0, in_col_stride, 0, out_col_stride};
-        hipLaunchKernelGGL(ntt_pass_generic_kernel, dim3(1, n_cols, n_cosets), dim3(64), 8, s, a);
+        launch_generic_pass(d_in, d_out, d_tw, nullptr, 0, 0, 0, 0, n_cols, n_cosets, in_col_stride, 0,
+                            out_col_stride, s);
         return;
     }
-    unsigned local = log_n < LOCAL_MAX ? log_n : LOCAL_MAX;
-    unsigned rest = log_n - local;
-    unsigned n_strided = (rest + STRIDED_MAX - 1) / STRIDED_MAX;
-    unsigned r0 = 0;
     // the first pass reads the caller's column (shared by all cosets); later passes run in place on d_out
     const u64 *src = d_in;
     size_t src_col_stride = in_col_stride, src_coset_stride = 0;
-    for (unsigned p = 0; p <= n_strided; p++) {
-        unsigned R, Wl;
-        if (p < n_strided) {
-            R = rest / n_strided + (p < rest % n_strided ? 1 : 0);
-            unsigned rem_log = log_n - r0 - R;
-            Wl = TILE_LOG - R;
-            if (Wl > rem_log) Wl = rem_log;
-        } else {
-            R = local;
-            Wl = 0;
-        }
-        PassArgs a{src, d_out, d_tw, d_round_scale, log_n, r0, R, Wl, src_col_stride, src_coset_stride, out_col_stride};
-        unsigned tiles = 1u << (log_n - R - Wl);
-        size_t lds = ((size_t)8) << (R + Wl);
-        unsigned tpb = (1u << (R + Wl)) / 2;
-        if (tpb > 256) tpb = 256;
-        if (tpb < 64) tpb = 64;
-        hipLaunchKernelGGL(ntt_pass_generic_kernel, dim3(tiles, n_cols, n_cosets), dim3(tpb), lds, s, a);
+    unsigned r0 = 0;
+    auto advance = [&](unsigned R) {
         r0 += R;
         src = d_out;
         src_col_stride = out_col_stride;
         src_coset_stride = n;
+    };
+    if (log_n < 12 || force_generic()) {
+        unsigned local = log_n < LOCAL_MAX ? log_n : LOCAL_MAX;
+        unsigned rest = log_n - local;
+        unsigned n_strided = (rest + STRIDED_MAX - 1) / STRIDED_MAX;
+        for (unsigned p = 0; p < n_strided; p++) {
+            unsigned R = rest / n_strided + (p < rest % n_strided ? 1 : 0);
+            unsigned rem_log = log_n - r0 - R;
+            unsigned Wl = TILE_LOG - R;
+            if (Wl > rem_log) Wl = rem_log;
+            launch_generic_pass(src, d_out, d_tw, d_round_scale, log_n, r0, R, Wl, n_cols, n_cosets, src_col_stride,
+                                src_coset_stride, out_col_stride, s);
+            advance(R);
+        }
+        launch_generic_pass(src, d_out, d_tw, d_round_scale, log_n, r0, local, 0, n_cols, n_cosets, src_col_stride,
+                            src_coset_stride, out_col_stride, s);
+        return;
     }
+    unsigned front = log_n - 12;
+    if (front % 4) {
+        unsigned R = front % 4;
+        unsigned Wl = TILE_LOG - R;
+        launch_generic_pass(src, d_out, d_tw, d_round_scale, log_n, r0, R, Wl, n_cols, n_cosets, src_col_stride,
+                            src_coset_stride, out_col_stride, s);
+        advance(R);
+        front -= R;
+    }
+    while (front >= 8) {
+        launch_ntt_strided8(src, d_out, d_tw, d_round_scale, log_n, r0, n_cols, n_cosets, src_col_stride,
+                            src_coset_stride, out_col_stride, s);
+        advance(8);
+        front -= 8;
+    }
+    if (front == 4) {
+        launch_ntt_strided4(src, d_out, d_tw, d_round_scale, log_n, r0, n_cols, n_cosets, src_col_stride,
+                            src_coset_stride, out_col_stride, s);
+        advance(4);
+    }
+    launch_ntt_local12(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
+                       out_col_stride, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------

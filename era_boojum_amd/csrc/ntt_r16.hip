@@ -1,0 +1,277 @@
+// Register-radix-16 NTT pass kernels for gfx950 — the fast path of launch_ntt_passes (ntt.hip holds the generic
+// fallback and the documentation of the pass decomposition).
+//
+// Every thread keeps 16 field elements in VGPRs and performs 4 butterfly rounds ("one radix-16 step") on them
+// without touching memory; steps are separated by a transpose through LDS.  Three kernels:
+//   ntt_local12_kernel   last 12 rounds on a contiguous 4096-element chunk   (3 steps, 3 LDS transposes, the last
+//                        one only to make the HBM store coalesced)
+//   ntt_strided8_kernel  8 rounds at stride 2^rem_log, tile = 256 x 16 elems (2 steps, 1 LDS transpose; every HBM
+//                        access is a 128-byte run)
+//   ntt_strided4_kernel  4 rounds at stride 2^rem_log, tile = 16 x 256 elems (1 step, no LDS)
+// Twiddles: round r of group k needs T[k] * shift^(n/2^(r+1)).  Per step a thread needs 15 of them
+// (1 + 2 + 4 + 8); they are fetched (and coset-scaled) ONCE per workgroup and reused for every column the
+// workgroup loops over: the block-uniform ones are staged in LDS, the per-thread ones stay in VGPRs.
+// All LDS indices go through pad(l) = l + l/16, which makes every transpose below bank-conflict free for
+// ds_read_b64 / ds_write_b64 (64 x 4-byte banks).
+#include "gl.cuh"
+#include "kernels.h"
+
+using gl::u64;
+using gl::u32;
+
+namespace bj {
+
+struct R16Args {
+    const u64 *in;
+    u64 *out;
+    const u64 *tw;           // bit-reversed twiddle table
+    const u64 *round_scale;  // [n_cosets][32] or nullptr
+    unsigned log_n, r0;      // r0 = first round of this pass
+    unsigned n_cols, cols_per_block;
+    size_t in_col_stride, in_coset_stride, out_col_stride;
+};
+
+#ifndef BJ_R16_WAVES
+#define BJ_R16_WAVES 2   // min waves per SIMD requested from the register allocator (tuned on MI355X)
+#endif
+static constexpr u32 TILE = 4096;
+static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
+
+__device__ __forceinline__ u32 pad(u32 l) { return l + (l >> 4); }
+
+// tw[(1<<s)-1+g] = T[(kb<<s)+g] * sc[r+s],  s = 0..3, g < 2^s
+template <bool SCALED>
+__device__ __forceinline__ void load_step_twiddles(u64 (&tw)[15], const u64 *__restrict__ T, u32 kb, unsigned r,
+                                                   const u64 *__restrict__ sc) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        u64 scale = SCALED ? sc[r + s] : 1;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            u64 t = T[((size_t)kb << s) + g];
+            if (SCALED) t = gl::mul(t, scale);
+            tw[(1 << s) - 1 + g] = t;
+        }
+    }
+}
+
+// 4 rounds on 16 register-resident elements; round s pairs x[i], x[i + (8>>s)] inside groups of 16>>s
+template <bool UNIT_FIRST>
+__device__ __forceinline__ void radix16(u64 (&x)[16], const u64 (&tw)[15]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const u64 w = tw[(1 << s) - 1 + g];
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const int iu = g * 2 * half + j, iv = iu + half;
+                u64 u = x[iu];
+                u64 v = (UNIT_FIRST && s == 0) ? x[iv] : gl::mul(x[iv], w);
+                x[iu] = gl::add(u, v);
+                x[iv] = gl::sub(u, v);
+            }
+        }
+    }
+}
+
+// block-uniform step twiddles: 15 lanes compute them once, everyone reads them back as LDS broadcasts
+template <bool SCALED>
+__device__ __forceinline__ void stage_uniform_twiddles(u64 *lds_tw, const u64 *__restrict__ T, u32 kb, unsigned r,
+                                                       const u64 *__restrict__ sc) {
+    const u32 t = threadIdx.x;
+    if (t < 15) {
+        const int s = 31 - __clz(t + 1);          // 0,1,1,2,2,2,2,3...
+        const int g = (int)(t + 1) - (1 << s);
+        u64 v = T[((size_t)kb << s) + g];
+        if (SCALED) v = gl::mul(v, sc[r + s]);
+        lds_tw[t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool SCALED>
+__global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args a) {
+    __shared__ u64 lds[LDS_ELEMS + 16];
+    u64 *lds_tw = lds + LDS_ELEMS;
+    const u32 t = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const unsigned coset = blockIdx.z;
+    const unsigned r0 = a.log_n - 12;
+    const size_t n = (size_t)1 << a.log_n;
+    const u64 *sc = SCALED ? a.round_scale + (size_t)coset * 32 : nullptr;
+
+    u64 twB[15], twC[15];
+    load_step_twiddles<SCALED>(twB, a.tw, b * 16 + (t >> 4), r0 + 4, sc);
+    load_step_twiddles<SCALED>(twC, a.tw, b * 256 + t, r0 + 8, sc);
+    stage_uniform_twiddles<SCALED>(lds_tw, a.tw, b, r0, sc);
+    __syncthreads();
+
+    const unsigned col0 = blockIdx.y * a.cols_per_block;
+    const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
+    const u32 ta = t >> 4, tc = t & 15;
+    for (unsigned col = col0; col < col1; col++) {
+        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + (size_t)b * TILE;
+        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + (size_t)b * TILE;
+        u64 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = gl::canon(src[j * 256 + t]);
+        {   // step A: bits 11..8 in registers, twiddles uniform
+            u64 twA[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) twA[i] = lds_tw[i];
+            radix16<false>(x, twA);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = lds[pad(ta * 256 + j * 16 + tc)];
+        __syncthreads();
+        radix16<false>(x, twB);   // step B: bits 7..4
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[pad(ta * 256 + j * 16 + tc)] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = lds[pad(t * 16 + j)];
+        __syncthreads();
+        radix16<false>(x, twC);   // step C: bits 3..0
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[pad(t * 16 + j)] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) dst[j * 256 + t] = lds[pad(j * 256 + t)];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool SCALED, bool UNIT_FIRST>
+__global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_strided8_kernel(R16Args a) {
+    __shared__ u64 lds[LDS_ELEMS + 16];
+    u64 *lds_tw = lds + LDS_ELEMS;
+    const u32 t = threadIdx.x;
+    const unsigned coset = blockIdx.z;
+    const unsigned rem_log = a.log_n - a.r0 - 8;          // bits of "lo" (>= 4)
+    const u32 tiles_per_hi = 1u << (rem_log - 4);
+    const u32 hi = blockIdx.x / tiles_per_hi, lo_tile = blockIdx.x % tiles_per_hi;
+    const size_t n = (size_t)1 << a.log_n;
+    const u64 *sc = SCALED ? a.round_scale + (size_t)coset * 32 : nullptr;
+    const u32 tm = t >> 4, tl = t & 15;
+
+    u64 tw2[15];
+    load_step_twiddles<SCALED>(tw2, a.tw, hi * 16 + tm, a.r0 + 4, sc);
+    stage_uniform_twiddles<SCALED>(lds_tw, a.tw, hi, a.r0, sc);
+    __syncthreads();
+
+    const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 4) + tl;
+    const unsigned col0 = blockIdx.y * a.cols_per_block;
+    const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
+    for (unsigned col = col0; col < col1; col++) {
+        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + base;
+        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + base;
+        u64 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = gl::canon(src[(size_t)(j * 16 + tm) << rem_log]);
+        {
+            u64 tw1[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) tw1[i] = lds_tw[i];
+            radix16<UNIT_FIRST>(x, tw1);   // mid bits 7..4
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = lds[pad(tm * 256 + j * 16 + tl)];
+        __syncthreads();
+        radix16<false>(x, tw2);            // mid bits 3..0
+#pragma unroll
+        for (int j = 0; j < 16; j++) dst[(size_t)(tm * 16 + j) << rem_log] = x[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool SCALED, bool UNIT_FIRST>
+__global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
+    __shared__ u64 lds_tw[16];
+    const u32 t = threadIdx.x;
+    const unsigned coset = blockIdx.z;
+    const unsigned rem_log = a.log_n - a.r0 - 4;          // >= 8
+    const u32 tiles_per_hi = 1u << (rem_log - 8);
+    const u32 hi = blockIdx.x / tiles_per_hi, lo_tile = blockIdx.x % tiles_per_hi;
+    const size_t n = (size_t)1 << a.log_n;
+    const u64 *sc = SCALED ? a.round_scale + (size_t)coset * 32 : nullptr;
+    stage_uniform_twiddles<SCALED>(lds_tw, a.tw, hi, a.r0, sc);
+    __syncthreads();
+    u64 tw1[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) tw1[i] = lds_tw[i];
+    const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 8) + t;
+    const unsigned col0 = blockIdx.y * a.cols_per_block;
+    const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
+    for (unsigned col = col0; col < col1; col++) {
+        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + base;
+        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + base;
+        u64 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = gl::canon(src[(size_t)j << rem_log]);
+        radix16<UNIT_FIRST>(x, tw1);
+#pragma unroll
+        for (int j = 0; j < 16; j++) dst[(size_t)j << rem_log] = x[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_cosets) {
+    // amortise the per-workgroup twiddle preparation over several columns, but keep >= ~4096 workgroups in flight
+    unsigned cpb = 8;
+    while (cpb > 1 && (size_t)tiles * ((n_cols + cpb - 1) / cpb) * n_cosets < 4096) cpb >>= 1;
+    return cpb;
+}
+
+void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n,
+                        unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
+                        size_t out_col_stride, hipStream_t s) {
+    unsigned tiles = 1u << (log_n - 12);
+    unsigned cpb = pick_cols_per_block(tiles, n_cols, n_cosets);
+    R16Args a{in, out, tw, round_scale, log_n, log_n - 12, n_cols, cpb, in_col_stride, in_coset_stride, out_col_stride};
+    dim3 grid(tiles, (n_cols + cpb - 1) / cpb, n_cosets);
+    if (round_scale)
+        hipLaunchKernelGGL(ntt_local12_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(ntt_local12_kernel<false>, grid, dim3(256), 0, s, a);
+}
+
+void launch_ntt_strided8(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
+                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
+                         size_t out_col_stride, hipStream_t s) {
+    unsigned tiles = 1u << (log_n - 12);
+    unsigned cpb = pick_cols_per_block(tiles, n_cols, n_cosets);
+    R16Args a{in, out, tw, round_scale, log_n, r0, n_cols, cpb, in_col_stride, in_coset_stride, out_col_stride};
+    dim3 grid(tiles, (n_cols + cpb - 1) / cpb, n_cosets);
+    if (round_scale)
+        hipLaunchKernelGGL((ntt_strided8_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else if (r0 == 0)
+        hipLaunchKernelGGL((ntt_strided8_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((ntt_strided8_kernel<false, false>), grid, dim3(256), 0, s, a);
+}
+
+void launch_ntt_strided4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
+                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
+                         size_t out_col_stride, hipStream_t s) {
+    unsigned tiles = 1u << (log_n - 12);
+    unsigned cpb = pick_cols_per_block(tiles, n_cols, n_cosets);
+    R16Args a{in, out, tw, round_scale, log_n, r0, n_cols, cpb, in_col_stride, in_coset_stride, out_col_stride};
+    dim3 grid(tiles, (n_cols + cpb - 1) / cpb, n_cosets);
+    if (round_scale)
+        hipLaunchKernelGGL((ntt_strided4_kernel<true, false>), grid, dim3(256), 0, s, a);
+    else if (r0 == 0)
+        hipLaunchKernelGGL((ntt_strided4_kernel<false, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((ntt_strided4_kernel<false, false>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace bj
