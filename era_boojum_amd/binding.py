@@ -41,6 +41,23 @@ _SIGNATURES = {
     "bj_merkle_tree_proof": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bj_poseidon2_permute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_fri_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "bj_transcript_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "bj_transcript_destroy": (None, [C.c_void_p]),
+    "bj_transcript_absorb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bj_transcript_challenge": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "bj_transcript_query_index": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]),
+    "bj_fri_schedule": (C.c_int, [C.c_uint32, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bj_fri_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint32), C.c_size_t,
+                               C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_fri_destroy": (None, [C.c_void_p]),
+    "bj_fri_num_oracles": (C.c_size_t, [C.c_void_p]),
+    "bj_fri_final_degree": (C.c_size_t, [C.c_void_p]),
+    "bj_fri_cap": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bj_fri_challenge": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bj_fri_final_monomials": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_fri_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -221,3 +238,119 @@ class Context:
     # -- FRI
     def fri_fold(self, d_c0, d_c1, length, d_o0, d_o1, log_full, coset_inv, ch):
         self._check(self._lib.bj_fri_fold(self._h, d_c0, d_c1, length, d_o0, d_o1, log_full, coset_inv, ch[0], ch[1]))
+
+    def fri_fold_step(self, d_c0, d_c1, length, k, d_o0, d_o1, log_full, coset_inv, ch):
+        self._check(self._lib.bj_fri_fold_step(self._h, d_c0, d_c1, length, k, d_o0, d_o1, log_full, coset_inv, ch[0], ch[1]))
+
+    def fri_prove(self, d_c0, d_c1, log_n, log_lde, schedule, cap_size, transcript):
+        """do_fri on the device; returns a FriProof handle (oracles stay in HBM)."""
+        sched = (C.c_uint32 * len(schedule))(*schedule)
+        h = C.c_void_p()
+        self._check(self._lib.bj_fri_prove(self._h, d_c0, d_c1, log_n, log_lde, sched, len(schedule), cap_size,
+                                           transcript._h, C.byref(h)))
+        return FriProof(self, h, cap_size, list(schedule))
+
+
+class Transcript:
+    """Host-side Poseidon2 Fiat–Shamir transcript of the product (bj_transcript_*); needs no GPU."""
+
+    def __init__(self):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.bj_transcript_create(1, C.byref(h))
+        if rc != 0:
+            raise BoojumHipError("bj_transcript_create failed: %d" % rc)
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.bj_transcript_destroy(self._h)
+            self._h = None
+
+    def absorb(self, els):
+        a = np.ascontiguousarray(np.asarray(els, dtype=np.uint64)).reshape(-1)
+        if a.size:
+            rc = self._lib.bj_transcript_absorb(self._h, _np_ptr(a), a.size)
+            if rc != 0:
+                raise BoojumHipError("bj_transcript_absorb failed: %d" % rc)
+
+    def absorb_cap(self, cap):
+        self.absorb(cap)
+
+    def challenge(self):
+        out = C.c_uint64()
+        rc = self._lib.bj_transcript_challenge(self._h, C.byref(out))
+        if rc != 0:
+            raise BoojumHipError("bj_transcript_challenge failed: %d" % rc)
+        return out.value
+
+    def challenge_ext(self):
+        return (self.challenge(), self.challenge())
+
+    def query_index(self, log_n, log_lde):
+        out = C.c_uint64()
+        rc = self._lib.bj_transcript_query_index(self._h, log_n, log_lde, C.byref(out))
+        if rc != 0:
+            raise BoojumHipError("bj_transcript_query_index failed: %d" % rc)
+        return out.value
+
+
+def fri_schedule(security_bits, cap_size, pow_bits, rate_log2, initial_degree_log2):
+    """compute_fri_schedule (prover.rs:2281-2372) through the C ABI: (new_pow_bits, num_queries, schedule, final_degree)."""
+    lib = load_library()
+    sched = (C.c_uint32 * 32)()
+    new_pow, nq, ln, fd = C.c_uint32(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    rc = lib.bj_fri_schedule(security_bits, cap_size, pow_bits, rate_log2, initial_degree_log2, C.byref(new_pow),
+                             C.byref(nq), sched, C.byref(ln), C.byref(fd))
+    if rc != 0:
+        raise BoojumHipError("bj_fri_schedule failed: %d" % rc)
+    return new_pow.value, nq.value, [int(sched[i]) for i in range(ln.value)], fd.value
+
+
+class FriProof:
+    def __init__(self, ctx, handle, cap_size, schedule):
+        self._ctx, self._h, self.cap_size, self.schedule = ctx, handle, cap_size, schedule
+        self._lib = ctx._lib
+
+    def close(self):
+        if self._h:
+            self._lib.bj_fri_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_oracles(self):
+        return self._lib.bj_fri_num_oracles(self._h)
+
+    @property
+    def final_degree(self):
+        return self._lib.bj_fri_final_degree(self._h)
+
+    def cap(self, i):
+        out = np.empty((self.cap_size, 4), dtype=np.uint64)
+        self._ctx._check(self._lib.bj_fri_cap(self._h, i, _np_ptr(out)))
+        return out
+
+    def challenge(self, i):
+        out = np.empty(2, dtype=np.uint64)
+        self._ctx._check(self._lib.bj_fri_challenge(self._h, i, _np_ptr(out)))
+        return (int(out[0]), int(out[1]))
+
+    def final_monomials(self):
+        fd = self.final_degree
+        c0, c1 = np.empty(fd, dtype=np.uint64), np.empty(fd, dtype=np.uint64)
+        self._ctx._check(self._lib.bj_fri_final_monomials(self._h, _np_ptr(c0), _np_ptr(c1)))
+        return c0, c1
+
+    def query(self, oracle, index, oracle_len):
+        e = 1 << self.schedule[oracle]
+        leaf = np.empty(2 * e, dtype=np.uint64)
+        depth = ((oracle_len >> self.schedule[oracle]) // self.cap_size).bit_length() - 1
+        path = np.empty((max(depth, 1), 4), dtype=np.uint64)
+        self._ctx._check(self._lib.bj_fri_query(self._ctx._h, self._h, oracle, index, _np_ptr(leaf), _np_ptr(path)))
+        return leaf, path[:depth]

@@ -1,9 +1,7 @@
 // C-ABI layer of libboojum_hip.so: context management + argument validation + kernel orchestration.
 // Public contract: include/boojum_hip.h.  No CPU fallback anywhere in this file: every entry point either
 // enqueues HIP work on the context's device or returns an error.
-#include "../../include/boojum_hip.h"
-#include "gl.cuh"
-#include "kernels.h"
+#include "ctx.h"
 
 #include <hip/hip_runtime.h>
 #include <cstdarg>
@@ -14,24 +12,7 @@
 
 using gl::u64;
 
-struct bj_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // twiddle caches (bit-reversed tables; a table for 2^k serves every smaller size as a prefix)
-    u64 *tw_fwd = nullptr, *tw_inv = nullptr;
-    unsigned tw_fwd_log = 0, tw_inv_log = 0;
-    // small device scratch: coset shifts + per-round scales, column pointer lists
-    u64 *d_small = nullptr;  // 64 shifts + 64*32 scales
-    const u64 **d_ptrs = nullptr;
-    size_t d_ptrs_cap = 0;
-    // big scratch for out-of-place steps
-    u64 *d_scratch = nullptr;
-    size_t scratch_elems = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
-
-namespace {
+namespace bj {
 
 int fail(bj_ctx *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -42,20 +23,6 @@ int fail(bj_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) ctx->err = buf;
     return code;
 }
-
-#define BJ_HIP(ctx, call)                                                                                   \
-    do {                                                                                                    \
-        hipError_t e_ = (call);                                                                             \
-        if (e_ != hipSuccess)                                                                               \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? BJ_ERR_OOM : BJ_ERR_HIP, "%s failed: %s", #call,   \
-                        hipGetErrorString(e_));                                                             \
-    } while (0)
-
-#define BJ_CHECK_LAUNCH(ctx)                                                                                \
-    do {                                                                                                    \
-        hipError_t e_ = hipGetLastError();                                                                  \
-        if (e_ != hipSuccess) return fail(ctx, BJ_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
-    } while (0)
 
 int bind(bj_ctx *ctx) {
     if (!ctx) return BJ_ERR_INVALID_ARG;
@@ -95,14 +62,14 @@ int ensure_scratch(bj_ctx *ctx, size_t elems) {
     return BJ_OK;
 }
 
-unsigned log2_exact(size_t x) {
-    unsigned r = 0;
-    while (((size_t)1 << r) < x) r++;
-    return r;
-}
-bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+}  // namespace bj
 
-}  // namespace
+using bj::bind;
+using bj::ensure_scratch;
+using bj::ensure_twiddles;
+using bj::fail;
+using bj::is_pow2;
+using bj::log2_exact;
 
 extern "C" {
 
@@ -474,6 +441,20 @@ int bj_fri_fold(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t 
     if (int rc = ensure_twiddles(ctx, log_full, true)) return rc;
     (void)log2_exact;
     bj::launch_fri_fold(d_c0, d_c1, len, d_o0, d_o1, ctx->tw_inv, coset_inv, ch0, ch1, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_fri_fold_step(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len, unsigned k, uint64_t *d_o0,
+                     uint64_t *d_o1, unsigned log_full, uint64_t coset_inv, uint64_t ch0, uint64_t ch1) {
+    if (int rc = bind(ctx)) return rc;
+    if (!d_c0 || !d_c1 || !d_o0 || !d_o1) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold_step: null device pointer");
+    if (k < 1 || k > 3) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold_step: k must be 1..3");
+    if (!is_pow2(len) || (len >> k) == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold_step: bad length");
+    if (log_full > 32 || len > ((size_t)1 << log_full))
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_fold_step: array longer than the initial domain");
+    if (int rc = ensure_twiddles(ctx, log_full, true)) return rc;
+    bj::launch_fri_fold_step(d_c0, d_c1, len, k, d_o0, d_o1, ctx->tw_inv, coset_inv, ch0, ch1, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

@@ -1,0 +1,52 @@
+// Internal: the context object behind the opaque `bj_ctx` of include/boojum_hip.h, shared by the C-ABI translation
+// units (abi.hip, fri_prover.hip, ...).
+#pragma once
+#include "../../include/boojum_hip.h"
+#include "gl.cuh"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <string>
+
+struct bj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // twiddle caches (bit-reversed tables; a table for 2^k serves every smaller size as a prefix)
+    gl::u64 *tw_fwd = nullptr, *tw_inv = nullptr;
+    unsigned tw_fwd_log = 0, tw_inv_log = 0;
+    gl::u64 *d_small = nullptr;  // 64 shifts + 64*32 per-round scales
+    const gl::u64 **d_ptrs = nullptr;
+    size_t d_ptrs_cap = 0;
+    gl::u64 *d_scratch = nullptr;  // big scratch for out-of-place steps
+    size_t scratch_elems = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace bj {
+int fail(bj_ctx *ctx, int code, const char *fmt, ...);
+int bind(bj_ctx *ctx);
+int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
+int ensure_scratch(bj_ctx *ctx, size_t elems);
+inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+inline unsigned log2_exact(size_t x) {
+    unsigned r = 0;
+    while (((size_t)1 << r) < x) r++;
+    return r;
+}
+}  // namespace bj
+
+#define BJ_HIP(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            return bj::fail(ctx, e_ == hipErrorOutOfMemory ? BJ_ERR_OOM : BJ_ERR_HIP, "%s failed: %s", #call,   \
+                            hipGetErrorString(e_));                                                             \
+    } while (0)
+
+#define BJ_CHECK_LAUNCH(ctx)                                                                                    \
+    do {                                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                                      \
+        if (e_ != hipSuccess)                                                                                   \
+            return bj::fail(ctx, BJ_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_));                \
+    } while (0)

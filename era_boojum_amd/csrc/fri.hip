@@ -31,6 +31,64 @@ fri_fold_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 *roots
     }
 }
 
+// K consecutive folds (one schedule step of 2^K) fused in registers: a lane reads 2^K adjacent values of c0 and of
+// c1 (64-512 contiguous bytes), folds them pairwise K times with challenges alpha, alpha^2, alpha^4 and coset
+// factors kappa, kappa^2, kappa^4, and writes ONE output.  Intermediate arrays never touch HBM.
+template <int K>
+__global__ void __launch_bounds__(256)
+fri_fold_fused_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 *roots, size_t out_len, u64 coset_inv,
+                      u64 ch0, u64 ch1) {
+    constexpr int E = 1 << K;
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; j < out_len; j += stride) {
+        gl::e2 v[E];
+#pragma unroll
+        for (int i = 0; i < E; i += 2) {
+            ulonglong2 p0 = reinterpret_cast<const ulonglong2 *>(c0 + j * E)[i / 2];
+            ulonglong2 p1 = reinterpret_cast<const ulonglong2 *>(c1 + j * E)[i / 2];
+            v[i] = {gl::canon(p0.x), gl::canon(p1.x)};
+            v[i + 1] = {gl::canon(p0.y), gl::canon(p1.y)};
+        }
+        gl::e2 alpha{ch0, ch1};
+        u64 kappa = coset_inv;
+#pragma unroll
+        for (int f = 0; f < K; f++) {
+            const int outs = E >> (f + 1);
+#pragma unroll
+            for (int m = 0; m < outs; m++) {
+                gl::e2 a = v[2 * m], b = v[2 * m + 1];
+                u64 r = gl::mul(gl::canon(roots[j * outs + m]), kappa);
+                gl::e2 diff = gl::e2_sub(a, b);
+                diff = {gl::mul(diff.c0, r), gl::mul(diff.c1, r)};
+                gl::e2 t = gl::e2_mul(diff, alpha);
+                v[m] = {gl::add(gl::add(t.c0, a.c0), b.c0), gl::add(gl::add(t.c1, a.c1), b.c1)};
+            }
+            alpha = gl::e2_sqr(alpha);
+            kappa = gl::sqr(kappa);
+        }
+        o0[j] = v[0].c0;
+        o1[j] = v[0].c1;
+    }
+}
+
+// fold by 2^k in one launch (k = 1..3); len = input length
+void launch_fri_fold_step(const u64 *d_c0, const u64 *d_c1, size_t len, unsigned k, u64 *d_o0, u64 *d_o1,
+                          const u64 *d_roots, u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s) {
+    size_t out_len = len >> k;
+    if (!out_len) return;
+    unsigned tpb = 256;
+    size_t blocks = (out_len + tpb - 1) / tpb;
+    if (blocks > 16384) blocks = 16384;
+    coset_inv = gl::canon(coset_inv); ch0 = gl::canon(ch0); ch1 = gl::canon(ch1);
+    if (k == 1)
+        hipLaunchKernelGGL(fri_fold_fused_kernel<1>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, coset_inv, ch0, ch1);
+    else if (k == 2)
+        hipLaunchKernelGGL(fri_fold_fused_kernel<2>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, coset_inv, ch0, ch1);
+    else
+        hipLaunchKernelGGL(fri_fold_fused_kernel<3>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, coset_inv, ch0, ch1);
+}
+
 void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u64 *d_o1, const u64 *d_roots,
                      u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s) {
     size_t half = len / 2;

@@ -145,6 +145,51 @@ int bj_poseidon2_permute(bj_ctx *ctx, uint64_t *d_states, size_t n_states);
 int bj_fri_fold(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len, uint64_t *d_o0, uint64_t *d_o1,
                 unsigned log_full, uint64_t coset_inv, uint64_t ch0, uint64_t ch1);
 
+/* fold by 2^k (k = 1..3) in ONE launch — one step of the folding schedule; alpha and coset_inv are squared between
+ * the inner folds inside the kernel exactly as interpolate_flattened_cosets does (fri/mod.rs:587-678). */
+int bj_fri_fold_step(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, size_t len, unsigned k, uint64_t *d_o0,
+                     uint64_t *d_o1, unsigned log_full, uint64_t coset_inv, uint64_t ch0, uint64_t ch1);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fiat–Shamir transcript (host side, tiny data, order-critical).  Replaces `Transcript` impls
+ * (src/cs/implementations/transcript.rs:7-42): BJ_TRANSCRIPT_POSEIDON2 = GoldilocksPoisedon2Transcript
+ * (transcript.rs:144-151: algebraic sponge, rate 8, overwrite mode, "1"-padding).  query_index = BoolsBuffer::get_bits
+ * (transcript.rs:369-417) + the inner/coset split of prover.rs:2161-2182; returns coset*n + inner.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct bj_transcript bj_transcript;
+#define BJ_TRANSCRIPT_POSEIDON2 1
+int bj_transcript_create(int kind, bj_transcript **out);
+void bj_transcript_destroy(bj_transcript *t);
+int bj_transcript_absorb(bj_transcript *t, const uint64_t *els, size_t n);
+int bj_transcript_challenge(bj_transcript *t, uint64_t *out);
+int bj_transcript_query_index(bj_transcript *t, unsigned log_n, unsigned log_lde, uint64_t *out_index);
+
+/* compute_fri_schedule (src/cs/implementations/prover.rs:2281-2372); `schedule` must hold >= 32 entries. */
+int bj_fri_schedule(uint32_t security_bits, size_t cap_size, uint32_t pow_bits, uint32_t rate_log2,
+                    uint32_t initial_degree_log2, uint32_t *new_pow_bits, size_t *num_queries, uint32_t *schedule,
+                    size_t *schedule_len, size_t *final_degree);
+
+/* do_fri (src/cs/implementations/fri/mod.rs:49-358): commit phase over the F_p^2 codeword (d_c0, d_c1) of length
+ * 2^(log_n+log_lde) laid out [coset][n] bit-reversed.  For every schedule step: Poseidon2 oracle with 2^k values per
+ * leaf -> cap into the transcript -> challenge (c0, c1) -> fold by 2^k.  Finally bit-reverse + iNTT of the last
+ * layer, final monomials into the transcript.  The returned object keeps oracles and leaf sources in HBM for the
+ * query phase; the caller's codeword must stay alive until bj_fri_destroy.  Returns BJ_ERR_INVALID_ARG if the
+ * codeword is not of low degree (the reference asserts, fri/mod.rs:327-336). */
+typedef struct bj_fri bj_fri;
+int bj_fri_prove(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, unsigned log_n, unsigned log_lde,
+                 const uint32_t *schedule, size_t schedule_len, size_t cap_size, bj_transcript *transcript,
+                 bj_fri **out);
+void bj_fri_destroy(bj_fri *f);
+size_t bj_fri_num_oracles(const bj_fri *f);
+size_t bj_fri_final_degree(const bj_fri *f);
+int bj_fri_cap(const bj_fri *f, size_t oracle, uint64_t *h_cap);          /* cap_size*4 u64 */
+int bj_fri_challenge(const bj_fri *f, size_t oracle, uint64_t *h_ch2);    /* the (c0,c1) drawn after that cap */
+int bj_fri_final_monomials(const bj_fri *f, uint64_t *h_c0, uint64_t *h_c1); /* final_degree u64 each */
+/* OracleQuery::construct for FRI oracles (proof.rs:65-100, fri/mod.rs:829-895): `index` is the flat index into that
+ * oracle's own source array; returns 2*2^k leaf elements (c0 run then c1 run) + the path (depth*4 u64). */
+int bj_fri_query(bj_ctx *ctx, const bj_fri *f, size_t oracle, size_t index, uint64_t *h_leaf_elements,
+                 uint64_t *h_path);
+
 #ifdef __cplusplus
 }
 #endif

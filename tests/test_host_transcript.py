@@ -1,0 +1,54 @@
+"""CPU tests of the product's host-side Fiat–Shamir code (bj_transcript_*, bj_fri_schedule: host C++ inside
+libboojum_hip.so, no GPU needed) against the oracle and the reference's golden proof."""
+import numpy as np
+
+import era_boojum_amd as E
+import oracle as O
+
+
+def _replay(t, fx):
+    t.absorb_cap(np.array(fx["setup_merkle_tree_cap"], dtype=np.uint64))
+    t.absorb(fx["public_inputs"])
+    t.absorb_cap(np.array(fx["witness_oracle_cap"], dtype=np.uint64))
+    chal = [t.challenge_ext() for _ in range(4)]
+    t.absorb_cap(np.array(fx["stage_2_oracle_cap"], dtype=np.uint64)); chal.append(t.challenge_ext())
+    t.absorb_cap(np.array(fx["quotient_oracle_cap"], dtype=np.uint64)); chal.append(t.challenge_ext())
+    for k in ("values_at_z", "values_at_z_omega", "values_at_0"):
+        t.absorb(np.array(fx[k], dtype=np.uint64))
+    chal.append(t.challenge_ext())
+    t.absorb_cap(np.array(fx["fri_base_oracle_cap"], dtype=np.uint64)); chal.append(t.challenge_ext())
+    for cap in fx["fri_intermediate_oracles_caps"]:
+        t.absorb_cap(np.array(cap, dtype=np.uint64)); chal.append(t.challenge_ext())
+    t.absorb(fx["final_fri_monomials"][0]); t.absorb(fx["final_fri_monomials"][1])
+    return chal
+
+
+def test_product_transcript_replays_golden_proof(fixture_json):
+    fx = fixture_json
+    tp, to = E.Transcript(), O.Transcript()
+    assert _replay(tp, fx) == _replay(to, fx)
+    qi = O.QueryIndexer(20, 1)
+    got = [tp.query_index(20, 1) for _ in range(6)]
+    assert got == [qi.next(to) for _ in range(6)]
+    assert got[:4] == [1192677, 1852513, 74792, 367254]     # fixture KAT
+
+
+def test_product_transcript_edge_cases_match_oracle():
+    rng = np.random.default_rng(0)
+    tp, to = E.Transcript(), O.Transcript()
+    # challenge with an empty buffer, draining all 8, multi-block absorb, non-canonical input, exact multiple of 8
+    seq = [("c", 9), ("a", 1), ("c", 3), ("a", 8), ("c", 1), ("a", 7), ("c", 17), ("a", 23), ("c", 2)]
+    for kind, n in seq:
+        if kind == "a":
+            els = rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)
+            els[0] = np.uint64(2**64 - 1)
+            tp.absorb(els); to.absorb(els)
+        else:
+            assert [tp.challenge() for _ in range(n)] == [to.challenge() for _ in range(n)]
+
+
+def test_fri_schedule_matches_oracle_and_reference_shapes():
+    for args in [(100, 32, 0, 1, 20), (100, 16, 0, 3, 16), (100, 16, 0, 3, 20), (100, 16, 0, 3, 22), (100, 16, 20, 3, 18),
+                 (80, 4, 7, 2, 10), (100, 64, 0, 1, 8), (63, 1, 0, 4, 13), (100, 16, 0, 3, 4), (100, 2, 0, 1, 1)]:
+        assert E.fri_schedule(*args) == O.fri_schedule(*args), args
+    assert E.fri_schedule(100, 32, 0, 1, 20) == (0, 100, [3, 3, 3, 3, 3, 1], 16)   # the golden proof's shape
