@@ -27,6 +27,7 @@ _SIGNATURES = {
     "bj_ntt_forward_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t, C.c_uint64]),
     "bj_intt_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t, C.c_uint64]),
     "bj_lde_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
+    "bj_lde_cosets_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "bj_trace_to_lde_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
     "bj_bitreverse_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t]),
     "bj_canonicalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -178,6 +179,11 @@ class Context:
     def lde_batch(self, d_mono, d_out, log_n, n_cols, log_lde, col_stride=None):
         col_stride = (1 << log_n) if col_stride is None else col_stride
         self._check(self._lib.bj_lde_batch(self._h, d_mono, col_stride, d_out, log_n, n_cols, log_lde))
+
+    def lde_cosets_batch(self, d_mono, d_out, log_n, n_cols, log_lde, coset_begin, coset_count, col_stride=None):
+        col_stride = (1 << log_n) if col_stride is None else col_stride
+        self._check(self._lib.bj_lde_cosets_batch(self._h, d_mono, col_stride, d_out, log_n, n_cols, log_lde,
+                                                  coset_begin, coset_count))
 
     def trace_to_lde_batch(self, d_cols, d_out, log_n, n_cols, log_lde, col_stride=None):
         col_stride = (1 << log_n) if col_stride is None else col_stride

@@ -234,26 +234,35 @@ int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned l
     return BJ_OK;
 }
 
-int bj_lde_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
-                 unsigned n_cols, unsigned log_lde) {
+int bj_lde_cosets_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                        unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count) {
     if (int rc = bind(ctx)) return rc;
-    if (n_cols == 0) return BJ_OK;
-    if (int rc = check_ntt_args(ctx, "bj_lde_batch", d_mono, d_out, log_n, n_cols, col_stride)) return rc;
-    if (log_lde == 0 || log_lde > 6) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: lde factor must be 2..64");
-    if (log_n + log_lde > 32) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: LDE domain exceeds two-adicity");
-    if (d_out == d_mono) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: output must not alias the monomials");
-    if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
+    if (n_cols == 0 || coset_count == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_lde_cosets_batch", d_mono, d_out, log_n, n_cols, col_stride)) return rc;
+    if (log_lde == 0 || log_lde > 6) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch: lde factor must be 2..64");
+    if (log_n + log_lde > 32) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch: LDE domain exceeds two-adicity");
     const unsigned L = 1u << log_lde;
+    if (coset_begin >= L || coset_count > L - coset_begin)
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch: coset range outside [0, lde_factor)");
+    if (d_out == d_mono) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch: output must not alias the monomials");
+    if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
     const size_t n = (size_t)1 << log_n;
     // shift_c = g * w_{nL}^{bitrev(c)}   (utils.rs:345-346, 370-373)
     u64 shifts[64];
     u64 w = gl::omega(log_n + log_lde);
-    for (unsigned c = 0; c < L; c++) shifts[c] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(c, log_lde)));
-    bj::launch_round_scales(ctx->d_small + 64, shifts, L, log_n ? log_n : 1, ctx->stream);
-    bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, L, col_stride,
-                          (size_t)L * n, ctx->stream);
+    for (unsigned i = 0; i < coset_count; i++)
+        shifts[i] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(coset_begin + i, log_lde)));
+    bj::launch_round_scales(ctx->d_small + 64, shifts, coset_count, log_n ? log_n : 1, ctx->stream);
+    bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, coset_count,
+                          col_stride, (size_t)coset_count * n, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
+}
+
+int bj_lde_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                 unsigned n_cols, unsigned log_lde) {
+    if (log_lde == 0 || log_lde > 6) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_batch: lde factor must be 2..64");
+    return bj_lde_cosets_batch(ctx, d_mono, col_stride, d_out, log_n, n_cols, log_lde, 0, 1u << log_lde);
 }
 
 int bj_trace_to_lde_batch(bj_ctx *ctx, uint64_t *d_cols, size_t col_stride, uint64_t *d_out, unsigned log_n,

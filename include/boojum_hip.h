@@ -88,6 +88,12 @@ int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned l
 int bj_lde_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
                  unsigned n_cols, unsigned log_lde);
 
+/* The same for the cosets [coset_begin, coset_begin + coset_count) only: d_out is [n_cols][coset_count][n].
+ * This is the unit of multi-GPU sharding: GPU g owns a contiguous range of cosets of every column,
+ * i.e. a contiguous range of Merkle leaves (leaf index = coset*n + i, proof.rs:89-91). */
+int bj_lde_cosets_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                        unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count);
+
 /* transform_raw_storages_to_lde (utils.rs:270-309): natural-order trace columns -> monomials (written back to
  * d_cols) -> LDE in d_out, i.e. bj_intt_batch(coset 1) followed by bj_lde_batch. */
 int bj_trace_to_lde_batch(bj_ctx *ctx, uint64_t *d_cols, size_t col_stride, uint64_t *d_out, unsigned log_n,
