@@ -42,6 +42,10 @@ _SIGNATURES = {
     "bj_merkle_tree_proof": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bj_poseidon2_permute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_fri_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "bj_barycentric_weights": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_barycentric_eval_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_deep_quotient_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
     "bj_transcript_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "bj_transcript_destroy": (None, [C.c_void_p]),
@@ -244,6 +248,28 @@ class Context:
     # -- FRI
     def fri_fold(self, d_c0, d_c1, length, d_o0, d_o1, log_full, coset_inv, ch):
         self._check(self._lib.bj_fri_fold(self._h, d_c0, d_c1, length, d_o0, d_o1, log_full, coset_inv, ch[0], ch[1]))
+
+    # -- openings
+    def barycentric_weights(self, log_n, coset, at, d_w0, d_w1):
+        a = np.array(at, dtype=np.uint64)
+        self._check(self._lib.bj_barycentric_weights(self._h, log_n, coset, _np_ptr(a), d_w0, d_w1))
+
+    def barycentric_eval_batch(self, col_ptrs, log_n, d_w0, d_w1):
+        arr = (C.c_void_p * len(col_ptrs))(*col_ptrs)
+        out = np.empty((len(col_ptrs), 2), dtype=np.uint64)
+        self._check(self._lib.bj_barycentric_eval_batch(self._h, arr, len(col_ptrs), log_n, d_w0, d_w1, _np_ptr(out)))
+        return out
+
+    def deep_quotient_accumulate(self, sources, values, challenges, at, log_n, log_lde, d_dst0, d_dst1, accumulate=True):
+        """sources: list of (d_c0, d_c1_or_None) device pointers of LDE columns."""
+        k = len(sources)
+        p0 = (C.c_void_p * k)(*[a for a, _ in sources])
+        p1 = (C.c_void_p * k)(*[b for _, b in sources])
+        v = np.ascontiguousarray(np.array(values, dtype=np.uint64).reshape(-1))
+        ch = np.ascontiguousarray(np.array(challenges, dtype=np.uint64).reshape(-1))
+        a = np.array(at, dtype=np.uint64)
+        self._check(self._lib.bj_deep_quotient_accumulate(self._h, p0, p1, k, _np_ptr(v), _np_ptr(ch), _np_ptr(a), log_n,
+                                                          log_lde, d_dst0, d_dst1, int(bool(accumulate))))
 
     def fri_fold_step(self, d_c0, d_c1, length, k, d_o0, d_o1, log_full, coset_inv, ch):
         self._check(self._lib.bj_fri_fold_step(self._h, d_c0, d_c1, length, k, d_o0, d_o1, log_full, coset_inv, ch[0], ch[1]))

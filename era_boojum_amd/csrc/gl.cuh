@@ -23,58 +23,113 @@ static constexpr u64 GEN = 7;              // multiplicative generator = LDE cos
 
 __host__ __device__ __forceinline__ u64 canon(u64 a) { return a >= P ? a - P : a; }
 
+// 32-bit limb helpers.  The device code is written as explicit 32-bit carry chains (v_add_co/v_addc, v_sub_co/v_subb):
+// on gfx950 a 32-bit VALU op issues in ~2 cycles per wave64, a 64-bit one (v_lshl_add_u64, v_cmp_*_u64) in ~4 and
+// v_mad_u64_u32 in ~5, so carry chains beat "64-bit add + 64-bit compare + select" by a wide margin
+// (tools/microbench.hip: field mul 90 -> ~60 cycles, add/sub 26 -> ~14).
+__host__ __device__ __forceinline__ u32 lo32(u64 a) { return (u32)a; }
+__host__ __device__ __forceinline__ u32 hi32(u64 a) { return (u32)(a >> 32); }
+__host__ __device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
 // a, b in [0,p) -> (a + b) mod p
 __host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
-    u64 s = a + b;
-    u64 t = s + EPS;  // s - p (mod 2^64)
-    // s >= p  <=>  s + EPS wraps; a + b wrapped <=> s < a
-    return (s < a || t < s) ? t : s;
+    u32 c1, c2, c3, c4;
+    u32 s0 = __builtin_addc(lo32(a), lo32(b), 0u, &c1);
+    u32 s1 = __builtin_addc(hi32(a), hi32(b), c1, &c2);
+    u32 t0 = __builtin_addc(s0, 0xFFFFFFFFu, 0u, &c3);  // s + EPS = s - p (mod 2^64)
+    u32 t1 = __builtin_addc(s1, 0u, c3, &c4);
+    // a + b wrapped (c2)  or  s >= p (s + EPS wraps, c4)  ->  take s - p
+    return (c2 | c4) ? pack(t0, t1) : pack(s0, s1);
 }
 // a, b in [0,p) -> (a - b) mod p
 __host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
-    u64 d = a - b;
-    return (a < b) ? d - EPS : d;  // + p == - EPS (mod 2^64)
+    u32 b1, b2, b3, b4;
+    u32 d0 = __builtin_subc(lo32(a), lo32(b), 0u, &b1);
+    u32 d1 = __builtin_subc(hi32(a), hi32(b), b1, &b2);
+    u32 e = b2 ? 0xFFFFFFFFu : 0u;  // + p == - EPS (mod 2^64)
+    d0 = __builtin_subc(d0, e, 0u, &b3);
+    d1 = __builtin_subc(d1, 0u, b3, &b4);
+    return pack(d0, d1);
 }
 __host__ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }
 __host__ __device__ __forceinline__ u64 dbl(u64 a) { return add(a, a); }
 
-// (hi:lo) 128-bit -> canonical residue
-__host__ __device__ __forceinline__ u64 reduce128(u64 hi, u64 lo) {
-    u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
-    u64 t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= EPS;
-    u64 t1 = (hi_lo << 32) - hi_lo;  // hi_lo * (2^32 - 1), no multiplier needed
-    u64 r = t0 + t1;
-    if (r < t1) r += EPS;
-    return canon(r);
+// (hi_hi : hi_lo : lo) = 128-bit value -> canonical residue, using 2^64 = 2^32 - 1 and 2^96 = -1 (mod p)
+__host__ __device__ __forceinline__ u64 reduce_limbs(u32 hi_hi, u32 hi_lo, u64 lo) {
+    u32 b1, b2, b3, b4, b5, b6, c1, c2, c3, c4;
+    // t0 = lo - hi_hi  (+p on borrow)
+    u32 d0 = __builtin_subc(lo32(lo), hi_hi, 0u, &b1);
+    u32 d1 = __builtin_subc(hi32(lo), 0u, b1, &b2);
+    u32 e = b2 ? 0xFFFFFFFFu : 0u;
+    d0 = __builtin_subc(d0, e, 0u, &b3);
+    d1 = __builtin_subc(d1, 0u, b3, &b4);
+    // t1 = hi_lo * (2^32 - 1) = (hi_lo << 32) - hi_lo
+    u32 m0 = __builtin_subc(0u, hi_lo, 0u, &b5);
+    u32 m1 = __builtin_subc(hi_lo, 0u, b5, &b6);
+    // r = t0 + t1, then the carry fix and the canonicalisation share one "+ EPS"
+    u32 r0 = __builtin_addc(d0, m0, 0u, &c1);
+    u32 r1 = __builtin_addc(d1, m1, c1, &c2);
+    u32 q0 = __builtin_addc(r0, 0xFFFFFFFFu, 0u, &c3);
+    u32 q1 = __builtin_addc(r1, 0u, c3, &c4);
+    return (c2 | c4) ? pack(q0, q1) : pack(r0, r1);
 }
+__host__ __device__ __forceinline__ u64 reduce128(u64 hi, u64 lo) { return reduce_limbs(hi32(hi), lo32(hi), lo); }
 
-__host__ __device__ __forceinline__ void mul_wide(u64 a, u64 b, u64 &hi, u64 &lo) {
+// 64x64 -> (hi_hi, hi_lo, lo) limbs of the 128-bit product.
+// Device: four v_mad_u64_u32 issued from one inline-asm block so that the cross-term accumulation keeps its
+// carry-out (the C++ formulation costs five extra v_mov to build {x,0} addend pairs).  The two independent mads
+// between the carry-producing mad and the v_cndmask that reads it cover the 2 wait states gfx950 requires between a
+// VALU SGPR write and a VALU read of that SGPR (the compiler cannot see inside the asm string).
+__host__ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32 &hi_hi, u32 &hi_lo, u64 &lo) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    u64 p00 = (u64)a0 * b0;
-    u64 mid = (u64)a0 * b1 + (p00 >> 32);        // v_mad_u64_u32, cannot overflow
-    u64 mid2 = (u64)a1 * b0 + (mid & EPS);       // v_mad_u64_u32, cannot overflow
-    hi = (u64)a1 * b1 + (mid >> 32) + (mid2 >> 32);
-    lo = (mid2 << 32) | (p00 & EPS);
+    u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    u64 L, X, H, cmask;
+    u32 cx;
+    asm("v_mad_u64_u32 %[X], vcc, %[a0], %[b1], 0\n\t"
+        "v_mad_u64_u32 %[X], %[cm], %[a1], %[b0], %[X]\n\t"
+        "v_mad_u64_u32 %[L], vcc, %[a0], %[b0], 0\n\t"
+        "v_mad_u64_u32 %[H], vcc, %[a1], %[b1], 0\n\t"
+        "v_cndmask_b32 %[cx], 0, 1, %[cm]"
+        : [L] "=&v"(L), [X] "=&v"(X), [H] "=&v"(H), [cx] "=v"(cx), [cm] "=&s"(cmask)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1)
+        : "vcc");
+    // product = L + X*2^32 + cx*2^96 + H*2^64
+    u32 c1, c2, c3;
+    u32 lo_hi = __builtin_addc(hi32(L), lo32(X), 0u, &c1);
+    hi_lo = __builtin_addc(lo32(H), hi32(X), c1, &c2);
+    hi_hi = __builtin_addc(hi32(H), cx, c2, &c3);  // cannot overflow: the product is < 2^128
+    lo = pack(lo32(L), lo_hi);
 #else
     unsigned __int128 x = (unsigned __int128)a * b;
-    hi = (u64)(x >> 64);
+    u64 hi = (u64)(x >> 64);
+    hi_hi = hi32(hi);
+    hi_lo = lo32(hi);
     lo = (u64)x;
 #endif
 }
 
 __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
-    u64 hi, lo;
-    mul_wide(a, b, hi, lo);
-    return reduce128(hi, lo);
+    u32 hi_hi, hi_lo;
+    u64 lo;
+    mul_limbs(a, b, hi_hi, hi_lo, lo);
+    return reduce_limbs(hi_hi, hi_lo, lo);
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 
-// a * 2^k mod p for 0 <= k < 64 (shift instead of multiply; used by Poseidon2's internal matrix)
+// a * 2^k mod p for 0 <= k < 32 (shift instead of multiply; used by Poseidon2's internal matrix): the part shifted
+// out is < 2^32, so the reduction is  lo + out*(2^32-1)  with one wrap/canonicalisation fix
 __host__ __device__ __forceinline__ u64 mul_pow2(u64 a, unsigned k) {
     if (k == 0) return a;
-    return reduce128(a >> (64 - k), a << k);
+    u32 out = (u32)(a >> (64 - k));
+    u64 lo = a << k;
+    u32 b5, b6, c1, c2, c3, c4;
+    u32 m0 = __builtin_subc(0u, out, 0u, &b5);
+    u32 m1 = __builtin_subc(out, 0u, b5, &b6);
+    u32 r0 = __builtin_addc(lo32(lo), m0, 0u, &c1);
+    u32 r1 = __builtin_addc(hi32(lo), m1, c1, &c2);
+    u32 q0 = __builtin_addc(r0, 0xFFFFFFFFu, 0u, &c3);
+    u32 q1 = __builtin_addc(r1, 0u, c3, &c4);
+    return (c2 | c4) ? pack(q0, q1) : pack(r0, r1);
 }
 
 __host__ __device__ inline u64 pow(u64 a, u64 e) {

@@ -157,6 +157,29 @@ int bj_fri_fold_step(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, si
                      uint64_t *d_o1, unsigned log_full, uint64_t coset_inv, uint64_t ch0, uint64_t ch1);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Openings (prover round 4 and the DEEP part of round 5, prover.rs:1501-2067).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* precompute_for_barycentric_evaluation_in_extension (src/cs/implementations/utils.rs:907-1021): weights for
+ * evaluating at at = (at2[0] + at2[1] u) from the 2^log_n values on coset*<w_n> given in BIT-REVERSED order
+ * (i.e. coset 0 of an LDE column when coset = 7).  d_w0/d_w1 receive 2^log_n values each. */
+int bj_barycentric_weights(bj_ctx *ctx, unsigned log_n, uint64_t coset, const uint64_t *at2, uint64_t *d_w0,
+                           uint64_t *d_w1);
+/* barycentric_evaluate_base_at_extension_for_bitreversed_parallel (utils.rs:1085-1158) for a batch of base-field
+ * columns: h_out[2c], h_out[2c+1] = sum_i col_c[i] * w[i].  For an F_p^2 polynomial stored as columns (c0, c1) the
+ * value is (E(c0).0 + 7*E(c1).1, E(c0).1 + E(c1).0) (= the _extension_at_extension_ variant, utils.rs:1160-1242).
+ * h_col_ptrs: host array of device pointers.  Synchronous (results are needed by the transcript). */
+int bj_barycentric_eval_batch(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, unsigned n_cols, unsigned log_n,
+                              const uint64_t *d_w0, const uint64_t *d_w1, uint64_t *h_out);
+/* quotening_operation_in_extension (src/cs/implementations/prover.rs:2523-2706):
+ *   dst[I] (+)= [ sum_k ch_k * (f_k[I] - v_k) ] / (x_I - at),  x_I = g*w_{nL}^{bitrev(I)}, I < 2^(log_n+log_lde).
+ * Source k is the LDE column h_src_c0[k] (and h_src_c1[k] for an F_p^2 polynomial; NULL entry or NULL array = base
+ * field).  h_values / h_challenges are [n_src][2].  accumulate = 0 overwrites dst, otherwise adds to it. */
+int bj_deep_quotient_accumulate(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1,
+                                size_t n_src, const uint64_t *h_values, const uint64_t *h_challenges,
+                                const uint64_t *at2, unsigned log_n, unsigned log_lde, uint64_t *d_dst_c0,
+                                uint64_t *d_dst_c1, int accumulate);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Fiat–Shamir transcript (host side, tiny data, order-critical).  Replaces `Transcript` impls
  * (src/cs/implementations/transcript.rs:7-42): BJ_TRANSCRIPT_POSEIDON2 = GoldilocksPoisedon2Transcript
  * (transcript.rs:144-151: algebraic sponge, rate 8, overwrite mode, "1"-padding).  query_index = BoolsBuffer::get_bits

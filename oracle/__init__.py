@@ -320,3 +320,56 @@ def batch_inverse(a):
     out = np.zeros_like(a)
     lib().orc_batch_inverse(_p(a), _p(out), C.c_size_t(a.size))
     return out
+
+
+# ---------------- openings: barycentric evaluation + DEEP ----------------
+def barycentric_weights(log_n, coset, at):
+    n = 1 << log_n
+    w0, w1 = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    lib().orc_barycentric_weights(C.c_uint(log_n), C.c_uint64(coset), _p(_arr(at)), _p(w0), _p(w1))
+    return w0, w1
+
+
+def barycentric_eval_base(values, w0, w1):
+    v = _arr(values)
+    out = np.zeros(2, dtype=np.uint64)
+    lib().orc_barycentric_eval_base(_p(v), _p(w0), _p(w1), C.c_size_t(v.size), _p(out))
+    return (int(out[0]), int(out[1]))
+
+
+def barycentric_eval_ext(v0, v1, w0, w1):
+    v0, v1 = _arr(v0), _arr(v1)
+    out = np.zeros(2, dtype=np.uint64)
+    lib().orc_barycentric_eval_ext(_p(v0), _p(v1), _p(w0), _p(w1), C.c_size_t(v0.size), _p(out))
+    return (int(out[0]), int(out[1]))
+
+
+def deep_quotient_accumulate(sources, values, challenges, at, log_n, log_lde, dst0, dst1, threads=1):
+    """sources: list of (c0_array, c1_array_or_None) each of length 2^(log_n+log_lde); dst updated in place."""
+    k = len(sources)
+    keep = []
+    p0 = (u64p * k)()
+    p1 = (u64p * k)()
+    for i, (a, b) in enumerate(sources):
+        a = _arr(a); keep.append(a); p0[i] = _p(a)
+        if b is None:
+            p1[i] = None
+        else:
+            b = _arr(b); keep.append(b); p1[i] = _p(b)
+    vals = _arr(values).reshape(-1)
+    chs = _arr(challenges).reshape(-1)
+    lib().orc_deep_quotient_accumulate(p0, p1, C.c_size_t(k), _p(vals), _p(chs), _p(_arr(at)), C.c_uint(log_n),
+                                       C.c_uint(log_lde), _p(dst0), _p(dst1), C.c_int(threads))
+
+
+def deep_quotient_point(f, values, challenges, at, x):
+    """f: list of (c0, c1_or_None) python ints at ONE LDE point x; returns the (c0, c1) contribution."""
+    k = len(f)
+    f0 = _arr([a for a, _ in f])
+    f1 = _arr([0 if b is None else b for _, b in f])
+    ie = np.array([0 if b is None else 1 for _, b in f], dtype=np.uint8)
+    out = np.zeros(2, dtype=np.uint64)
+    lib().orc_deep_quotient_point(_p(f0), _p(f1), ie.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_size_t(k),
+                                  _p(_arr(values).reshape(-1)), _p(_arr(challenges).reshape(-1)), _p(_arr(at)),
+                                  C.c_uint64(x), _p(out))
+    return (int(out[0]), int(out[1]))

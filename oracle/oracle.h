@@ -80,6 +80,15 @@ void orc_fri_result_free(orc_fri_result *r);
 /* ---- pointwise.c ---- */
 void orc_batch_inverse(const uint64_t *in, uint64_t *out, size_t n);
 void orc_ext_batch_inverse(const uint64_t *in0, const uint64_t *in1, uint64_t *o0, uint64_t *o1, size_t n);
+void orc_barycentric_weights(unsigned log_n, uint64_t coset, const uint64_t *at, uint64_t *w0, uint64_t *w1);
+void orc_barycentric_eval_base(const uint64_t *values, const uint64_t *w0, const uint64_t *w1, size_t n, uint64_t *out2);
+void orc_barycentric_eval_ext(const uint64_t *v0, const uint64_t *v1, const uint64_t *w0, const uint64_t *w1, size_t n, uint64_t *out2);
+void orc_deep_quotient_point(const uint64_t *f0, const uint64_t *f1, const unsigned char *is_ext, size_t n_src,
+                             const uint64_t *values, const uint64_t *challenges, const uint64_t *at, uint64_t x,
+                             uint64_t *out2);
+void orc_deep_quotient_accumulate(const uint64_t *const *src_c0, const uint64_t *const *src_c1, size_t n_src,
+                                  const uint64_t *values, const uint64_t *challenges, const uint64_t *at, unsigned log_n,
+                                  unsigned log_lde, uint64_t *dst0, uint64_t *dst1, int threads);
 
 #ifdef __cplusplus
 }

@@ -133,6 +133,42 @@ def _deep_value(fx, rp, q, idx):
     return h
 
 
+def test_c_oracle_deep_quotient_matches_fixture(fixture_json, replay):
+    """The C oracle's DEEP point function (oracle/pointwise.c, restating prover.rs:2523-2706) summed over the four
+    opening sets must reproduce the value committed in the FRI base oracle of the golden proof."""
+    fx, rp = fixture_json, replay
+    n_log, LOGN = rp["n_log"], rp["n_log"] + rp["log_lde"]
+    g = fx["geometry"]
+    NV, NW, NM, NS, NT, NI, NA = 155, 0, 1, 155, 4, 19, 8
+    NC = g["num_constant_columns"] + g["extra_constant_polys_for_selectors"] + 1
+    vz = [tuple(e) for e in fx["values_at_z"]]
+    vzo = [tuple(e) for e in fx["values_at_z_omega"]]
+    v0 = [tuple(e) for e in fx["values_at_0"]]
+    pubs = [(cr[0], cr[1], v) for cr, v in zip(g["public_inputs_locations"], fx["public_inputs"])]
+    total = len(vz) + len(vzo) + len(v0) + len(pubs)
+    chs = [(1, 0), rp["c"]]
+    while len(chs) < total:
+        chs.append(emul(chs[-1], rp["c"]))
+    for q, idx in zip(fx["queries"], rp["idxs"]):
+        W, S2, Q, SU = (q[k]["leaf_elements"] for k in ("witness_query", "stage_2_query", "quotient_query", "setup_query"))
+        base = lambda l: [(e, None) for e in l]
+        ext = lambda l: [(l[i], l[i + 1]) for i in range(0, len(l), 2)]
+        src = (base(W[0:NV]) + base(W[NV:NV + NW]) + base(SU[NS:NS + NC]) + base(SU[0:NS]) + ext(S2[0:2])
+               + ext(S2[2:2 + 2 * NI]) + base(W[NV + NW:NV + NW + NM]) + ext(S2[2 + 2 * NI:2 + 2 * NI + 2 * NA])
+               + ext(S2[2 + 2 * NI + 2 * NA:]) + base(SU[NS + NC:NS + NC + NT]) + ext(Q))
+        x = pow(O.omega(LOGN), O.bitrev(idx, LOGN), P) * 7 % P
+        o = 0
+        h = O.deep_quotient_point(src, vz, chs[o:o + len(vz)], rp["z"], x); o += len(vz)
+        h = eadd(h, O.deep_quotient_point(ext(S2[0:2]), vzo, chs[o:o + 1], escale(rp["z"], O.omega(n_log)), x)); o += 1
+        h = eadd(h, O.deep_quotient_point(ext(S2[2 + 2 * NI:]), v0, chs[o:o + len(v0)], (0, 0), x)); o += len(v0)
+        at = (pow(O.omega(n_log), pubs[0][1], P), 0)
+        h = eadd(h, O.deep_quotient_point([(W[ci], None) for ci, _, _ in pubs], [(v, 0) for _, _, v in pubs],
+                                          chs[o:o + len(pubs)], at, x))
+        assert h == _deep_value(fx, rp, q, idx)
+        le = q["fri_queries"][0]["leaf_elements"]
+        assert h == (le[idx % 8], le[8 + idx % 8])
+
+
 def test_fri_chain_fold_and_final_monomials(fixture_json, replay):
     fx, rp = fixture_json, replay
     LOGN = rp["n_log"] + rp["log_lde"]
