@@ -1,0 +1,71 @@
+"""Vectorised Goldilocks arithmetic on numpy uint64 arrays (host-side input synthesis only — never on the proving path).
+
+Used by era_boojum_amd.synthetic to build satisfiable circuits for benches and tests; kept independent of oracle/."""
+import numpy as np
+
+P = (1 << 64) - (1 << 32) + 1
+_P = np.uint64(P)
+_EPS = np.uint64(0xFFFFFFFF)
+_M32 = np.uint64(0xFFFFFFFF)
+_S32 = np.uint64(32)
+
+
+def canon(a):
+    a = np.asarray(a, dtype=np.uint64)
+    return np.where(a >= _P, a - _P, a)
+
+
+def add(a, b):
+    a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        s = a + b
+        t = s + _EPS
+    return np.where((s < a) | (t < s), t, s)
+
+
+def sub(a, b):
+    a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        d = a - b
+        return np.where(a < b, d - _EPS, d)
+
+
+def mul(a, b):
+    a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        a0, a1, b0, b1 = a & _M32, a >> _S32, b & _M32, b >> _S32
+        p00 = a0 * b0
+        mid = a0 * b1 + (p00 >> _S32)
+        mid2 = a1 * b0 + (mid & _M32)
+        lo = (mid2 << _S32) | (p00 & _M32)
+        hi = a1 * b1 + (mid >> _S32) + (mid2 >> _S32)
+        hi_hi, hi_lo = hi >> _S32, hi & _M32
+        t0 = lo - hi_hi
+        t0 = np.where(lo < hi_hi, t0 - _EPS, t0)
+        t1 = hi_lo * _EPS
+        r = t0 + t1
+        r = np.where(r < t1, r + _EPS, r)
+    return np.where(r >= _P, r - _P, r)
+
+
+def powers(base, count):
+    """[1, base, base^2, ...] (count entries) by repeated doubling of the prefix."""
+    out = np.ones(count, dtype=np.uint64)
+    if count <= 1:
+        return out
+    base = int(base) % P
+    filled = 1
+    step = base
+    while filled < count:
+        take = min(filled, count - filled)
+        out[filled:filled + take] = mul(out[:take], np.uint64(step))
+        filled += take
+        step = step * step % P
+    return out
+
+
+def omega(log_n):
+    w = 0x185629DCDA58878C
+    for _ in range(32 - log_n):
+        w = w * w % P
+    return w

@@ -1,0 +1,337 @@
+"""SHA-shaped satisfiable synthetic circuits (input synthesis for benches and tests; not on the proving path).
+
+The reference's SHA-256 bench circuit (src/gadgets/sha256/mod.rs:296-375) cannot be synthesised without its Rust CS
+machinery, so this module builds a circuit with the SAME geometry and gate mix and a random
+satisfying assignment; prover cost is data-independent, so timings are representative ("SHA-shaped synthetic"):
+
+  * 60 general-purpose variable columns, 4 constant columns in the geometry, max constraint degree 4
+  * specialized lookups `UseSpecializedColumnsWithTableIdAsConstant { width 4, 8 repetitions, share_table_id }`
+    -> 32 more variable columns, one table-id constant column, one multiplicity column, 5 table setup columns
+  * gates over general-purpose columns, in the bench's configuration order: ConstantsAllocatorGate,
+    FmaGateInBaseFieldWithoutConstant, ReductionGate<4>, NopGate (src/cs/gates/*.rs)
+  * selector tree computed with the reference's own placement algorithm (setup.rs:504-728, 1346-1572), which for this
+    gate set yields paths FMA=[1], Reduction=[0,1], ConstantsAllocator=[0,0,1], Nop=[0,0,0], 7 constant columns for
+    gates (+1 table id = 8) and quotient degree 4
+  * sigma polynomials per SURVEY appendix A.1 (setup.rs:24-75, 419-503): sigma = id except on linked cells
+  * tables TriXor / Ch / Maj / Split<1> / Split<2> over `table_bits`-bit limbs (4 in the real bench, smaller in tests)
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import field_np as F
+
+P = F.P
+
+GATE_CONSTANT_ALLOCATOR, GATE_FMA, GATE_REDUCTION4, GATE_NOP = 1, 2, 3, 4
+
+
+@dataclass
+class GateDesc:
+    kind: int
+    name: str
+    degree: int              # max_constraint_degree
+    num_constants: int       # num_required_constants_in_geometry
+    principal_width: int     # variables per repetition
+    reps: int                # num_repetitions_in_geometry
+    var_stride: int          # per_chunk_offset.variables_offset
+    const_stride: int        # per_chunk_offset.constants_offset
+    num_terms: int           # quotient terms per repetition
+    needs_selector: bool
+    path: list = field(default_factory=list)   # selector path, True = constant, False = 1 - constant
+
+
+def sha_bench_gates(num_gp_vars=60, num_constant_cols=4):
+    """Evaluator order of the SHA bench (sha256/mod.rs:340-375)."""
+    return [
+        GateDesc(GATE_CONSTANT_ALLOCATOR, "ConstantsAllocatorGate", 1, num_constant_cols, 1,
+                 min(num_constant_cols, num_gp_vars), 1, 1, 1, True),
+        GateDesc(GATE_FMA, "FmaGateInBaseFieldWithoutConstant", 3, 2, 4, num_gp_vars // 4, 4, 0, 1, True),
+        GateDesc(GATE_REDUCTION4, "ReductionGate<4>", 2, 4, 5, num_gp_vars // 5, 5, 0, 1, True),
+        GateDesc(GATE_NOP, "NopGate", 0, 0, 0, 1, 0, 0, 0, True),
+    ]
+
+
+# ---- selector placement: restatement of TreeNode::try_add_gate / try_find_placement_for_degree (setup.rs:1346-1572) ----
+def _stats(node, depth):
+    if node[0] == "gate":
+        g = node[1]
+        return depth + g.degree, g.num_constants + depth
+    l, r = _stats(node[1], depth + 1), _stats(node[2], depth + 1)
+    return max(l[0], r[0]), max(l[1], r[1])
+
+
+def _try_add(node, gate, max_deg, max_consts, depth):
+    if node is None:
+        if depth + gate.degree > max_deg or gate.num_constants > max_consts:
+            return None
+        return ("gate", gate)
+    if node[0] == "gate":
+        for cand in (("fork", node, ("gate", gate)), ("fork", ("gate", gate), node)):
+            d, c = _stats(cand, depth)
+            if d <= max_deg and c <= max_consts:
+                return cand
+        return None
+    new_left = _try_add(node[1], gate, max_deg, max_consts, depth + 1)
+    if new_left is not None:
+        return ("fork", new_left, node[2])
+    new_right = _try_add(node[2], gate, max_deg, max_consts, depth + 1)
+    if new_right is not None:
+        return ("fork", node[1], new_right)
+    return None
+
+
+def _paths(node, prefix, out):
+    if node[0] == "gate":
+        out[id(node[1])] = list(prefix)
+    else:
+        _paths(node[1], prefix + [True], out)
+        _paths(node[2], prefix + [False], out)
+
+
+def place_selectors(gates, num_constant_cols_geometry):
+    """compute_selectors_and_constants_placement (setup.rs:504-728).  Returns (max degree incl. selectors, number of
+    constant columns needed by gates); fills gate.path."""
+    todo = [g for g in gates if g.degree > 0 or g.needs_selector]
+    max_degree = max(g.degree for g in todo) - 1
+    max_consts = max(g.num_constants for g in todo)
+    assert num_constant_cols_geometry >= max_consts
+    order = sorted(todo, key=lambda g: (-g.degree, -g.num_constants))   # stable, like sort_by
+    target = 1
+    while target < max(max_degree, 1):
+        target *= 2
+    bound_sel = (len(order) - 1).bit_length() if len(order) > 1 else 0   # ceil(log2(#gates))
+    for _ in range(4):
+        for i in range(bound_sel + 2):
+            tree, ok = None, True
+            for g in order:
+                tree = _try_add(tree, g, target, max_consts + i, 0)
+                if tree is None:
+                    ok = False
+                    break
+            if ok:
+                paths = {}
+                _paths(tree, [], paths)
+                for g in order:
+                    g.path = paths[id(g)]
+                return _stats(tree, 0)
+        target *= 2
+    raise ValueError("no selector placement found")
+
+
+# ---- non-residues for the copy permutation: make_non_residues (utils.rs:636-688) ----
+def non_residues(num_columns, domain_size):
+    out = [1]
+    current = 1
+    seen_pows = []
+    while len(out) < num_columns:
+        current += 1
+        if pow(current, (P - 1) // 2, P) != P - 1:     # not a quadratic non-residue
+            continue
+        t = pow(current, domain_size, P)
+        if t == 1 or t in seen_pows:
+            continue
+        seen_pows.append(t)
+        out.append(current)
+    return out
+
+
+# ---- lookup tables over b-bit limbs (sha256/mod.rs:433-446 uses b = 4) ----
+def make_tables(bits):
+    m = 1 << bits
+    a, b, c = np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij")
+    a, b, c = a.reshape(-1), b.reshape(-1), c.reshape(-1)
+    mask = m - 1
+    tri = np.stack([a, b, c, a ^ b ^ c], axis=1)
+    ch = np.stack([a, b, c, ((a & b) ^ (~a & c)) & mask], axis=1)
+    maj = np.stack([a, b, c, (a & b) ^ (a & c) ^ (b & c)], axis=1)
+    k = np.arange(m)
+    s1 = np.stack([k, k & 1, k >> 1, np.zeros_like(k)], axis=1)
+    s2 = np.stack([k, k & 3, k >> 2, np.zeros_like(k)], axis=1)
+    return [t.astype(np.uint64) for t in (tri, ch, maj, s1, s2)]
+
+
+@dataclass
+class Circuit:
+    log_n: int
+    num_gp_vars: int
+    num_lookup_vars: int
+    lookup_width: int
+    lookup_reps: int
+    gates: list
+    num_constant_cols: int          # total, incl. selector columns and the table-id column
+    num_constants_for_gates: int
+    table_id_col: int
+    quotient_degree: int
+    variables: np.ndarray           # [V, n] natural order
+    multiplicities: np.ndarray      # [1, n]
+    sigmas: np.ndarray              # [V, n]
+    constants: np.ndarray           # [Kc, n]
+    tables: np.ndarray              # [width+1, n]
+    non_residues: list
+    public_inputs: list             # [(col, row, value)]
+    total_tables_len: int
+
+    @property
+    def n(self):
+        return 1 << self.log_n
+
+    @property
+    def num_vars(self):
+        return self.num_gp_vars + self.num_lookup_vars
+
+
+def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
+                       lookup_width=4, lookup_reps=8, num_public_inputs=2):
+    """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
+    (ConstantsAllocator, FMA, Reduction); the rest are Nop rows."""
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    rand_f = lambda shape: rng.integers(0, P, size=shape, dtype=np.uint64)
+    gates = sha_bench_gates(num_gp_vars, num_constant_cols)
+    max_deg, consts_for_gates = place_selectors(gates, num_constant_cols)
+    q = 1
+    while q < max_deg - 1:
+        q *= 2
+    table_id_col = consts_for_gates
+    Kc = consts_for_gates + 1
+    V = num_gp_vars + lookup_width * lookup_reps
+    variables = np.zeros((V, n), dtype=np.uint64)
+    constants = np.zeros((Kc, n), dtype=np.uint64)
+    # link[c, r] = flat index (col * n + row) of the cell whose identity sigma takes at (c, r); default: itself
+    link = np.arange(V * n, dtype=np.int64).reshape(V, n)
+
+    # --- rows -> gate kinds
+    u = rng.random(n)
+    kind = np.full(n, 3, dtype=np.int64)                      # index into `gates`: default Nop
+    kind[u < mix[0]] = 0
+    kind[(u >= mix[0]) & (u < mix[0] + mix[1])] = 1
+    kind[(u >= mix[0] + mix[1]) & (u < sum(mix))] = 2
+    for gi, g in enumerate(gates):
+        rows = np.nonzero(kind == gi)[0]
+        d = len(g.path)
+        for i, bit in enumerate(g.path):
+            constants[i, rows] = 1 if bit else 0
+        if g.kind == GATE_CONSTANT_ALLOCATOR:
+            for r in range(g.reps):
+                c = rand_f(rows.size)
+                constants[d + r * g.const_stride, rows] = c
+                variables[r * g.var_stride, rows] = c
+        elif g.kind == GATE_FMA:
+            qc, lc = rand_f(rows.size), rand_f(rows.size)
+            constants[d, rows], constants[d + 1, rows] = qc, lc
+            prev_d = None
+            for r in range(g.reps):
+                a, b = rand_f(rows.size), rand_f(rows.size)
+                c = rand_f(rows.size) if prev_d is None else prev_d      # c_k is a copy of d_{k-1}
+                dd = F.add(F.mul(qc, F.mul(a, b)), F.mul(lc, c))
+                base = r * g.var_stride
+                variables[base, rows], variables[base + 1, rows] = a, b
+                variables[base + 2, rows], variables[base + 3, rows] = c, dd
+                if prev_d is not None:   # copy cycle of length 2: (row, base+2) <-> (row, base-1)
+                    link[base + 2, rows] = (base - 1) * n + rows
+                    link[base - 1, rows] = (base + 2) * n + rows
+                prev_d = dd
+        elif g.kind == GATE_REDUCTION4:
+            cs = [rand_f(rows.size) for _ in range(4)]
+            for i in range(4):
+                constants[d + i, rows] = cs[i]
+            for r in range(g.reps):
+                base = r * g.var_stride
+                acc = np.zeros(rows.size, dtype=np.uint64)
+                for i in range(4):
+                    v = rand_f(rows.size)
+                    variables[base + i, rows] = v
+                    acc = F.add(acc, F.mul(v, cs[i]))
+                variables[base + 4, rows] = acc
+    # --- lookups: every row looks 8 tuples up in ONE table (shared table id in a constant column)
+    tabs = make_tables(table_bits)
+    total_len = sum(t.shape[0] for t in tabs)
+    if total_len > n:
+        raise ValueError("tables (%d rows) do not fit the trace (%d rows): lower table_bits" % (total_len, n))
+    tables = np.zeros((lookup_width + 1, n), dtype=np.uint64)
+    offs, o = [], 0
+    for ti, t in enumerate(tabs):
+        tables[:lookup_width, o:o + t.shape[0]] = t.T
+        tables[lookup_width, o:o + t.shape[0]] = ti + 1         # table ids start at 1 (reference_cs.rs:24)
+        offs.append(o)
+        o += t.shape[0]
+    tid = rng.integers(0, len(tabs), size=n)
+    constants[table_id_col] = (tid + 1).astype(np.uint64)
+    sizes = np.array([t.shape[0] for t in tabs])
+    offs = np.array(offs)
+    mult = np.zeros(n, dtype=np.uint64)
+    for rep in range(lookup_reps):
+        pick = offs[tid] + (rng.integers(0, 1 << 62, size=n) % sizes[tid])
+        for j in range(lookup_width):
+            variables[num_gp_vars + rep * lookup_width + j] = tables[j, pick]
+        np.add.at(mult, pick, np.uint64(1))
+    # --- sigma = id o link,  id(c, r) = k_c * omega^r
+    ks = non_residues(V, n)
+    om = F.powers(F.omega(log_n), n)
+    sigmas = np.empty((V, n), dtype=np.uint64)
+    link_col, link_row = link // n, link % n
+    ks_arr = np.array(ks, dtype=np.uint64)
+    for c in range(V):
+        sigmas[c] = F.mul(ks_arr[link_col[c]], om[link_row[c]])
+    pubs = []
+    for i in range(num_public_inputs):
+        col, row = (7 * i + 3) % num_gp_vars, (11 * i + 5) % n
+        pubs.append((col, row, int(variables[col, row])))
+    return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
+                   table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len)
+
+
+def check_satisfied(c: Circuit):
+    """Row-level satisfiability (the semantics of check_if_satisfied, satisfiability_test.rs:15): gate terms vanish on
+    their rows, linked cells hold equal values, every lookup tuple is in its table, multiplicities are exact."""
+    n, V = c.n, c.num_vars
+    consts, var = c.constants, c.variables
+    sel_rows = {}
+    for g in c.gates:
+        m = np.ones(n, dtype=bool)
+        for i, bit in enumerate(g.path):
+            m &= consts[i] == (1 if bit else 0)
+        sel_rows[g.name] = m
+        d = len(g.path)
+        if g.kind == GATE_FMA:
+            for r in range(g.reps):
+                b = r * g.var_stride
+                t = F.sub(F.add(F.mul(consts[d], F.mul(var[b], var[b + 1])), F.mul(consts[d + 1], var[b + 2])), var[b + 3])
+                assert not t[m].any(), "FMA unsatisfied"
+        elif g.kind == GATE_REDUCTION4:
+            for r in range(g.reps):
+                b = r * g.var_stride
+                acc = np.zeros(n, dtype=np.uint64)
+                for i in range(4):
+                    acc = F.add(acc, F.mul(var[b + i], consts[d + i]))
+                assert not F.sub(acc, var[b + 4])[m].any(), "Reduction unsatisfied"
+        elif g.kind == GATE_CONSTANT_ALLOCATOR:
+            for r in range(g.reps):
+                assert not F.sub(var[r * g.var_stride], consts[d + r * g.const_stride])[m].any(), "ConstAlloc unsatisfied"
+    assert sum(m.sum() for m in sel_rows.values()) == n, "selector paths must partition the rows"
+    # copy constraints: sigma(c, r) = id(c', r')  =>  var[c, r] == var[c', r']
+    ks = np.array(c.non_residues, dtype=np.uint64)
+    om = F.powers(F.omega(c.log_n), n)
+    ids = np.stack([F.mul(ks[col], om) for col in range(V)])
+    order = np.argsort(ids.reshape(-1), kind="stable")
+    pos = np.searchsorted(ids.reshape(-1)[order], c.sigmas.reshape(-1))
+    tgt = order[pos]
+    assert np.array_equal(ids.reshape(-1)[tgt], c.sigmas.reshape(-1)), "sigma is not a permutation of the identities"
+    assert np.array_equal(np.sort(tgt), np.arange(V * n)), "sigma is not a bijection"
+    assert np.array_equal(var.reshape(-1)[tgt], var.reshape(-1)), "copy constraint violated"
+    # lookups
+    w = c.lookup_width
+    enc = lambda cols: sum(cols[j].astype(object) * (1 << (16 * j)) for j in range(len(cols)))
+    table_keys = enc(list(c.tables))          # includes the id column
+    lut = {}
+    for r in range(c.total_tables_len):
+        lut[table_keys[r]] = r
+    count = np.zeros(n, dtype=np.uint64)
+    for rep in range(c.lookup_reps):
+        cols = [var[c.num_gp_vars + rep * w + j] for j in range(w)] + [consts[c.table_id_col]]
+        keys = enc(cols)
+        for k in keys:
+            count[lut[k]] += 1
+    assert np.array_equal(count, c.multiplicities[0]), "multiplicities mismatch"
+    return True
