@@ -1,0 +1,77 @@
+"""End-to-end oracle tests: a satisfiable SHA-shaped synthetic circuit is proven by the CPU restatement of
+prove_cpu_basic (oracle/prover.py) and the proof is accepted by the restatement of Verifier::verify
+(oracle/verifier.py); corrupted witnesses / proofs are rejected (the reference's own test pattern 2:
+"verifier accepts", cs.rs:1076, 1465)."""
+import copy
+
+import numpy as np
+import pytest
+
+import oracle as O
+from era_boojum_amd import synthetic as S
+from oracle import prover as OP
+from oracle import verifier as OV
+
+
+@pytest.fixture(scope="module")
+def small_case():
+    c = S.sha_shaped_circuit(9, seed=7, table_bits=2)
+    assert S.check_satisfied(c)
+    fri_lde, cap = 8, 16
+    setup = OP.Setup(c, fri_lde, cap, threads=4)
+    proof, aux = OP.prove(c, setup, fri_lde, cap, security_level=30, threads=4, return_aux=True)
+    vk = OV.VerificationKey(c, setup.cap, fri_lde, cap)
+    return c, setup, proof, aux, vk
+
+
+def test_verifier_accepts_oracle_proof(small_case):
+    c, setup, proof, aux, vk = small_case
+    assert OV.verify(vk, proof, verbose=True)
+    assert len(proof["values_at_z"]) == 92 + 8 + 92 + 1 + 22 + (1 + 8 + 1 + 5) + 4     # SURVEY §8 counts
+    assert len(proof["queries_per_fri_repetition"][0]["witness_query"]["leaf_elements"]) == 93
+    assert len(proof["queries_per_fri_repetition"][0]["stage_2_query"]["leaf_elements"]) == 64
+    assert len(proof["queries_per_fri_repetition"][0]["setup_query"]["leaf_elements"]) == 105
+
+
+def test_grand_product_closes_and_quotient_is_low_degree(small_case):
+    c, setup, proof, aux, vk = small_case
+    # z(omega^n) = z(1) = 1: the shifted grand product returns to one (copy_permutation.rs:484)
+    z = aux["z_nat"]
+    assert int(z[0][0]) == 1 and int(z[1][0]) == 0
+    # quotient monomials: degree < q*n - 1 and not trivially zero
+    qm = aux["qmono"]
+    assert qm[0][-1] == 0 and qm[1][-1] == 0 and qm.any()
+
+
+def test_verifier_rejects_tampering(small_case):
+    c, setup, proof, aux, vk = small_case
+    bad = copy.deepcopy(proof)
+    bad["values_at_z"][3][0] = (bad["values_at_z"][3][0] + 1) % O.P
+    assert not OV.verify(vk, bad)
+    bad = copy.deepcopy(proof)
+    bad["queries_per_fri_repetition"][0]["witness_query"]["leaf_elements"][5] ^= 1
+    assert not OV.verify(vk, bad)
+    bad = copy.deepcopy(proof)
+    bad["final_fri_monomials"][0][0] = (bad["final_fri_monomials"][0][0] + 1) % O.P
+    assert not OV.verify(vk, bad)
+    bad = copy.deepcopy(proof)
+    bad["public_inputs"][0] = (bad["public_inputs"][0] + 1) % O.P
+    assert not OV.verify(vk, bad)
+
+
+def test_unsatisfied_witness_is_caught():
+    c = S.sha_shaped_circuit(8, seed=3, table_bits=2)
+    fma = [g for g in c.gates if g.kind == S.GATE_FMA][0]
+    rows = np.nonzero(c.constants[0] == 1)[0]          # FMA rows have path [1]
+    c.variables[3, rows[0]] = (int(c.variables[3, rows[0]]) + 1) % O.P   # break one FMA output
+    setup = OP.Setup(c, 8, 16, threads=4)
+    with pytest.raises(AssertionError):
+        OP.prove(c, setup, 8, 16, security_level=20, threads=4)
+
+
+def test_fri_lde_2_config_like_the_golden_proof():
+    """fri_lde_factor 2 < quotient degree 4 (the golden proof's regime: LDE for the quotient is wider than the FRI rate)."""
+    c = S.sha_shaped_circuit(8, seed=11, table_bits=2)
+    setup = OP.Setup(c, 2, 4, threads=4)
+    proof = OP.prove(c, setup, 2, 4, security_level=20, threads=4)
+    assert OV.verify(OV.VerificationKey(c, setup.cap, 2, 4), proof, verbose=True)
