@@ -46,6 +46,15 @@ _SIGNATURES = {
     "bj_barycentric_eval_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_deep_quotient_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]),
+    "bj_setup_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_setup_destroy": (None, [C.c_void_p]),
+    "bj_setup_cap": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_proof_destroy": (None, [C.c_void_p]),
+    "bj_proof_size_u64": (C.c_size_t, [C.c_void_p]),
+    "bj_proof_serialize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_proof_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
     "bj_transcript_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "bj_transcript_destroy": (None, [C.c_void_p]),
@@ -386,3 +395,103 @@ class FriProof:
         path = np.empty((max(depth, 1), 4), dtype=np.uint64)
         self._ctx._check(self._lib.bj_fri_query(self._ctx._h, self._h, oracle, index, _np_ptr(leaf), _np_ptr(path)))
         return leaf, path[:depth]
+
+
+class _GateDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("path_len", C.c_uint), ("path", C.c_ubyte * 8), ("num_repetitions", C.c_uint),
+                ("var_stride", C.c_uint), ("const_stride", C.c_uint), ("num_terms", C.c_uint)]
+
+
+class _Circuit(C.Structure):
+    _fields_ = [("log_n", C.c_uint), ("num_vars", C.c_uint), ("num_gp_vars", C.c_uint), ("num_witness_cols", C.c_uint),
+                ("num_constant_cols", C.c_uint), ("lookup_width", C.c_uint), ("lookup_reps", C.c_uint),
+                ("table_id_col", C.c_uint), ("quotient_degree", C.c_uint), ("num_gates", C.c_uint),
+                ("gates", C.POINTER(_GateDesc)), ("non_residues", C.POINTER(C.c_uint64)), ("num_public_inputs", C.c_uint),
+                ("public_input_cols", C.POINTER(C.c_uint)), ("public_input_rows", C.POINTER(C.c_uint))]
+
+
+class _ProofConfig(C.Structure):
+    _fields_ = [("fri_lde_factor", C.c_uint), ("cap_size", C.c_uint), ("security_level", C.c_uint), ("pow_bits", C.c_uint)]
+
+
+STAGE_NAMES = ["witness_lde_and_tree", "second_stage", "quotient_work_and_lde", "openings_at_z",
+               "batched_fri_opening_computation", "fri", "queries"]
+
+
+class ProverSetup:
+    """Device-resident setup for a circuit of era_boojum_amd.synthetic.Circuit shape (bj_setup_create)."""
+
+    def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0):
+        self._ctx, self._lib, self.circuit = ctx, ctx._lib, circuit
+        self.fri_lde_factor, self.cap_size, self.security_level, self.pow_bits = fri_lde_factor, cap_size, security_level, pow_bits
+        c = circuit
+        gates = (_GateDesc * len(c.gates))()
+        for i, g in enumerate(c.gates):
+            gates[i].kind = g.kind
+            gates[i].path_len = len(g.path)
+            for b, bit in enumerate(g.path):
+                gates[i].path[b] = 1 if bit else 0
+            gates[i].num_repetitions, gates[i].var_stride, gates[i].const_stride, gates[i].num_terms = \
+                g.reps, g.var_stride, g.const_stride, g.num_terms
+        nr = np.array(c.non_residues, dtype=np.uint64)
+        cols = (C.c_uint * max(1, len(c.public_inputs)))(*[p[0] for p in c.public_inputs])
+        rows = (C.c_uint * max(1, len(c.public_inputs)))(*[p[1] for p in c.public_inputs])
+        cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, 0, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
+                      c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
+                      cols, rows)
+        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits)
+        sig = np.ascontiguousarray(c.sigmas, dtype=np.uint64)
+        con = np.ascontiguousarray(c.constants, dtype=np.uint64)
+        tab = np.ascontiguousarray(c.tables, dtype=np.uint64)
+        h = C.c_void_p()
+        ctx._check(self._lib.bj_setup_create(ctx._h, C.byref(cc), _np_ptr(sig), _np_ptr(con),
+                                             _np_ptr(tab) if c.lookup_reps else None, C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bj_setup_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cap(self):
+        out = np.empty((self.cap_size, 4), dtype=np.uint64)
+        self._ctx._check(self._lib.bj_setup_cap(self._h, _np_ptr(out)))
+        return out
+
+    def _finish(self, h):
+        n = self._lib.bj_proof_size_u64(h)
+        buf = np.empty(n, dtype=np.uint64)
+        self._ctx._check(self._lib.bj_proof_serialize(h, _np_ptr(buf)))
+        ms = (C.c_float * 8)()
+        self._lib.bj_proof_stage_ms(h, ms)
+        self._lib.bj_proof_destroy(h)
+        return buf, dict(zip(STAGE_NAMES, [float(x) for x in ms][:7]))
+
+    def prove(self, variables=None, multiplicities=None, public_values=None):
+        """Host-memory entry point (bj_prove): returns (serialised proof u64 array, per-stage ms)."""
+        c = self.circuit
+        v = np.ascontiguousarray(c.variables if variables is None else variables, dtype=np.uint64)
+        m = np.ascontiguousarray(c.multiplicities if multiplicities is None else multiplicities, dtype=np.uint64)
+        pv = np.array([p[2] for p in c.public_inputs] if public_values is None else public_values, dtype=np.uint64)
+        if pv.size == 0:
+            pv = np.zeros(1, dtype=np.uint64)
+        h = C.c_void_p()
+        self._ctx._check(self._lib.bj_prove(self._ctx._h, self._h, _np_ptr(v), _np_ptr(m) if c.lookup_reps else None,
+                                            _np_ptr(pv), C.byref(h)))
+        return self._finish(h)
+
+    def prove_dev(self, d_variables, d_multiplicities, public_values=None):
+        """Witness already in HBM (bj_prove_dev)."""
+        c = self.circuit
+        pv = np.array([p[2] for p in c.public_inputs] if public_values is None else public_values, dtype=np.uint64)
+        if pv.size == 0:
+            pv = np.zeros(1, dtype=np.uint64)
+        h = C.c_void_p()
+        self._ctx._check(self._lib.bj_prove_dev(self._ctx._h, self._h, d_variables, d_multiplicities, _np_ptr(pv), C.byref(h)))
+        return self._finish(h)

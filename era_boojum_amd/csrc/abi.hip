@@ -234,6 +234,26 @@ int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned l
     return BJ_OK;
 }
 
+extern "C++" {
+namespace bj {
+// LDE of cosets [coset_begin, coset_begin+coset_count) of 2^log_lde with explicit input/output column strides;
+// output column c holds its cosets back to back starting at d_out + c*out_col_stride.
+int lde_cosets_strided(bj_ctx *ctx, const u64 *d_mono, size_t in_col_stride, u64 *d_out, size_t out_col_stride,
+                       unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count) {
+    if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
+    u64 shifts[64];
+    u64 w = gl::omega(log_n + log_lde);
+    for (unsigned i = 0; i < coset_count; i++)
+        shifts[i] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(coset_begin + i, log_lde)));  // utils.rs:345-346, 370-373
+    bj::launch_round_scales(ctx->d_small + 64, shifts, coset_count, log_n ? log_n : 1, ctx->stream);
+    bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, coset_count,
+                          in_col_stride, out_col_stride, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+}  // namespace bj
+}  // extern "C++"
+
 int bj_lde_cosets_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
                         unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count) {
     if (int rc = bind(ctx)) return rc;
@@ -245,18 +265,8 @@ int bj_lde_cosets_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, 
     if (coset_begin >= L || coset_count > L - coset_begin)
         return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch: coset range outside [0, lde_factor)");
     if (d_out == d_mono) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch: output must not alias the monomials");
-    if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
-    const size_t n = (size_t)1 << log_n;
-    // shift_c = g * w_{nL}^{bitrev(c)}   (utils.rs:345-346, 370-373)
-    u64 shifts[64];
-    u64 w = gl::omega(log_n + log_lde);
-    for (unsigned i = 0; i < coset_count; i++)
-        shifts[i] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(coset_begin + i, log_lde)));
-    bj::launch_round_scales(ctx->d_small + 64, shifts, coset_count, log_n ? log_n : 1, ctx->stream);
-    bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, coset_count,
-                          col_stride, (size_t)coset_count * n, ctx->stream);
-    BJ_CHECK_LAUNCH(ctx);
-    return BJ_OK;
+    return bj::lde_cosets_strided(ctx, d_mono, col_stride, d_out, ((size_t)coset_count) << log_n, log_n, n_cols, log_lde,
+                                  coset_begin, coset_count);
 }
 
 int bj_lde_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,

@@ -28,6 +28,8 @@ int fail(bj_ctx *ctx, int code, const char *fmt, ...);
 int bind(bj_ctx *ctx);
 int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
+int lde_cosets_strided(bj_ctx *ctx, const gl::u64 *d_mono, size_t in_col_stride, gl::u64 *d_out, size_t out_col_stride,
+                       unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count);
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 inline unsigned log2_exact(size_t x) {
     unsigned r = 0;

@@ -11,11 +11,6 @@
 
 using gl::u64;
 
-struct bj_transcript {
-    bj::host::Transcript t;
-    bj::host::BoolsBuffer bools;
-};
-
 struct bj_fri {
     int device = 0;
     size_t cap_size = 0;

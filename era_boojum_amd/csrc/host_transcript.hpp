@@ -109,3 +109,9 @@ struct BoolsBuffer {
 
 }  // namespace host
 }  // namespace bj
+
+// the object behind the opaque `bj_transcript` of include/boojum_hip.h (shared by fri_prover.hip and prover.hip)
+struct bj_transcript {
+    bj::host::Transcript t;
+    bj::host::BoolsBuffer bools;
+};

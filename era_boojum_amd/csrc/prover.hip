@@ -1,0 +1,597 @@
+// Whole-prover orchestration on one GPU: bj_setup_create / bj_prove_dev / bj_prove (seam S1 of SURVEY.md §8b).
+// Follows prove_cpu_basic (src/cs/implementations/prover.rs:153-2266) round by round; the host only runs the
+// Fiat–Shamir transcript and O(#columns) scalar arithmetic, every polynomial stays in HBM.
+//
+// Circuit class: general-purpose gates ConstantsAllocator / FMA-without-constant / Reduction<4> / Nop selected by a
+// selector tree over the first constant columns, specialized lookups with a shared constant table id
+// (LookupParameters::UseSpecializedColumnsWithTableIdAsConstant) or no lookups, no witness columns, Poseidon2 tree
+// hasher + Poseidon2 transcript, PoW off — the configuration of the reference's SHA-256 bench
+// (src/gadgets/sha256/mod.rs:284-375).
+#include "ctx.h"
+#include "host_transcript.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+using gl::u64;
+
+namespace bj {
+// stage2.hip
+void launch_copy_perm_stage2(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
+                             const u64 *d_non_res, unsigned V, unsigned chunk, unsigned log_n, const u64 *d_tw_fwd,
+                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s);
+void launch_lookup_polys(const u64 *d_lvars, size_t var_stride, const u64 *d_table_id, const u64 *d_tables,
+                         size_t tab_stride, const u64 *d_mult, unsigned reps, unsigned w, unsigned log_n,
+                         const u64 *beta, const u64 *gamma, u64 *d_A, u64 *d_B, hipStream_t s);
+// quotient.hip
+void launch_quotient_gates(const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                           const int *h_gates_flat, unsigned n_gates, const u64 *d_alphas, size_t Q, u64 *d_out0,
+                           u64 *d_out1, hipStream_t s);
+void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_table_id, const u64 *d_tables,
+                            size_t tab_stride, const u64 *d_mult, const u64 *d_A, const u64 *d_B, size_t s2_stride,
+                            unsigned reps, unsigned w, const u64 *lbeta, const u64 *lgamma, const u64 *d_alphas,
+                            size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s);
+void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
+                               const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
+                               unsigned log_n, unsigned log_q, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
+                               const u64 *alpha_l1, const u64 *d_alphas_cp, u64 *d_out0, u64 *d_out1, hipStream_t s);
+void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, const u64 *d_idx, unsigned n_idx,
+                        u64 *d_out, hipStream_t s);
+void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, const u64 *d_idx, unsigned n_idx,
+                         u64 *d_out, hipStream_t s);
+}  // namespace bj
+
+struct bj_setup {
+    int device = 0;
+    // circuit
+    unsigned log_n = 0, V = 0, num_gp_vars = 0, nC = 0, lookup_w = 0, lookup_reps = 0, table_id_col = 0, q = 0;
+    std::vector<int> gates_flat;   // 12 ints per gate
+    unsigned n_gates = 0;
+    std::vector<u64> non_residues;
+    std::vector<unsigned> pub_cols, pub_rows;
+    // proof config
+    unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0;
+    unsigned L = 0, log_L = 0, log_fri = 0, log_q = 0;
+    unsigned n_cols = 0;           // V sigmas + nC constants + (w+1) tables
+    u64 *d_nat = nullptr;          // [n_cols][n] natural-order values
+    u64 *d_lde = nullptr;          // [n_cols][L][n]
+    u64 *d_tree = nullptr;
+    u64 *d_non_res = nullptr;
+    std::vector<u64> cap;
+};
+
+struct bj_proof {
+    std::vector<u64> data;
+    float stage_ms[8] = {0};
+};
+
+namespace {
+
+struct DevBuf {
+    u64 *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(bj_ctx *ctx, size_t elems) {
+        if (hipMalloc((void **)&p, (elems ? elems : 1) * sizeof(u64)) != hipSuccess)
+            return bj::fail(ctx, BJ_ERR_OOM, "device allocation of %zu MiB failed", elems * 8 >> 20);
+        return BJ_OK;
+    }
+};
+
+gl::e2 e2c(const u64 *p) { return {gl::canon(p[0]), gl::canon(p[1])}; }
+
+struct StageTimer {
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(hipStream_t st) : s(st) {
+        (void)hipStreamSynchronize(s);
+        t0 = std::chrono::steady_clock::now();
+    }
+    float lap() {
+        (void)hipStreamSynchronize(s);
+        auto t1 = std::chrono::steady_clock::now();
+        float ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        t0 = t1;
+        return ms;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void bj_setup_destroy(bj_setup *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->d_nat) (void)hipFree(s->d_nat);
+    if (s->d_lde) (void)hipFree(s->d_lde);
+    if (s->d_tree) (void)hipFree(s->d_tree);
+    if (s->d_non_res) (void)hipFree(s->d_non_res);
+    delete s;
+}
+
+int bj_setup_create(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_sigmas, const uint64_t *h_constants,
+                    const uint64_t *h_tables, const bj_proof_config *cfg, bj_setup **out) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: null out pointer");
+    *out = nullptr;
+    if (!c || !cfg || !h_sigmas || !h_constants) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: null argument");
+    if (c->log_n < 1 || c->log_n > 26) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: log_n out of range");
+    if (c->num_witness_cols != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: witness columns are not supported");
+    if (c->num_gates == 0 || c->num_gates > 8 || !c->gates) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: 1..8 gates expected");
+    if (!bj::is_pow2(c->quotient_degree) || !bj::is_pow2(cfg->fri_lde_factor) || cfg->fri_lde_factor < 2 ||
+        !bj::is_pow2(cfg->cap_size))
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: quotient degree / fri_lde_factor / cap must be powers of two");
+    if (cfg->pow_bits != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: PoW is not supported (benches run with pow_bits = 0)");
+    if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || c->table_id_col >= c->num_constant_cols))
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad lookup parameters");
+    if (c->num_vars < c->num_gp_vars + c->lookup_width * c->lookup_reps || !c->non_residues)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad column counts");
+    unsigned n_chunks = (c->num_vars + c->quotient_degree - 1) / c->quotient_degree;
+    if (n_chunks < 2) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: a single copy-permutation chunk is not supported");
+    bj_setup *s = new bj_setup();
+    s->device = ctx->device;
+    s->log_n = c->log_n; s->V = c->num_vars; s->num_gp_vars = c->num_gp_vars; s->nC = c->num_constant_cols;
+    s->lookup_w = c->lookup_width; s->lookup_reps = c->lookup_reps; s->table_id_col = c->table_id_col;
+    s->q = c->quotient_degree;
+    s->n_gates = c->num_gates;
+    for (unsigned g = 0; g < c->num_gates; g++) {
+        const bj_gate_desc &G = c->gates[g];
+        if (G.kind < 1 || G.kind > 4 || G.path_len > 6) {
+            delete s;
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad gate descriptor %u", g);
+        }
+        int f[12] = {G.kind, (int)G.path_len, (int)G.num_repetitions, (int)G.var_stride, (int)G.const_stride,
+                     (int)G.num_terms, 0, 0, 0, 0, 0, 0};
+        for (unsigned b = 0; b < G.path_len; b++) f[6 + b] = G.path[b] ? 1 : 0;
+        s->gates_flat.insert(s->gates_flat.end(), f, f + 12);
+    }
+    s->non_residues.assign(c->non_residues, c->non_residues + c->num_vars);
+    for (unsigned i = 0; i < c->num_public_inputs; i++) {
+        s->pub_cols.push_back(c->public_input_cols[i]);
+        s->pub_rows.push_back(c->public_input_rows[i]);
+    }
+    s->fri_lde = cfg->fri_lde_factor; s->cap_size = cfg->cap_size; s->security = cfg->security_level; s->pow_bits = cfg->pow_bits;
+    s->L = s->fri_lde > s->q ? s->fri_lde : s->q;   // used_lde_degree (prover.rs:313)
+    s->log_L = bj::log2_exact(s->L); s->log_fri = bj::log2_exact(s->fri_lde); s->log_q = bj::log2_exact(s->q);
+    const size_t n = (size_t)1 << s->log_n;
+    const unsigned nT = s->lookup_reps ? s->lookup_w + 1 : 0;
+    s->n_cols = s->V + s->nC + nT;
+    int rc = BJ_OK;
+    auto bail = [&](int code) {
+        bj_setup_destroy(s);
+        return code;
+    };
+    if (hipMalloc((void **)&s->d_nat, (size_t)s->n_cols * n * 8) != hipSuccess ||
+        hipMalloc((void **)&s->d_lde, (size_t)s->n_cols * s->L * n * 8) != hipSuccess ||
+        hipMalloc((void **)&s->d_non_res, s->V * 8) != hipSuccess)
+        return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: device allocation failed"));
+    // leaf order of the setup oracle: sigma || constants || tables (polynomial_storage.rs:667-676)
+    rc = bj_memcpy_h2d(ctx, s->d_nat, h_sigmas, (size_t)s->V * n * 8);
+    if (!rc) rc = bj_memcpy_h2d(ctx, s->d_nat + (size_t)s->V * n, h_constants, (size_t)s->nC * n * 8);
+    if (!rc && nT) rc = bj_memcpy_h2d(ctx, s->d_nat + (size_t)(s->V + s->nC) * n, h_tables, (size_t)nT * n * 8);
+    if (!rc) rc = bj_memcpy_h2d(ctx, s->d_non_res, s->non_residues.data(), s->V * 8);
+    if (rc) return bail(rc);
+    {   // monomials in a temporary, LDE into d_lde
+        DevBuf mono;
+        if ((rc = mono.alloc(ctx, (size_t)s->n_cols * n))) return bail(rc);
+        rc = bj_intt_batch(ctx, s->d_nat, mono.p, s->log_n, s->n_cols, n, 1);
+        if (!rc) rc = bj_lde_batch(ctx, mono.p, n, s->d_lde, s->log_n, s->n_cols, s->log_L);
+        if (!rc) rc = bj_sync(ctx);
+        if (rc) return bail(rc);
+    }
+    const size_t leaves = n * s->fri_lde;
+    if (hipMalloc((void **)&s->d_tree, bj_merkle_tree_digests(leaves, s->cap_size) * 32) != hipSuccess)
+        return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: tree allocation failed"));
+    rc = bj_merkle_tree_build(ctx, s->d_lde, (size_t)s->L * n, s->n_cols, leaves, s->cap_size, s->d_tree);
+    s->cap.resize(4 * s->cap_size);
+    if (!rc) rc = bj_merkle_tree_cap(ctx, s->d_tree, leaves, s->cap_size, s->cap.data());
+    if (rc) return bail(rc);
+    *out = s;
+    return BJ_OK;
+}
+
+int bj_setup_cap(const bj_setup *s, uint64_t *h_cap) {
+    if (!s || !h_cap) return BJ_ERR_INVALID_ARG;
+    std::memcpy(h_cap, s->cap.data(), s->cap.size() * 8);
+    return BJ_OK;
+}
+
+void bj_proof_destroy(bj_proof *p) { delete p; }
+size_t bj_proof_size_u64(const bj_proof *p) { return p ? p->data.size() : 0; }
+int bj_proof_serialize(const bj_proof *p, uint64_t *out) {
+    if (!p || !out) return BJ_ERR_INVALID_ARG;
+    std::memcpy(out, p->data.data(), p->data.size() * 8);
+    return BJ_OK;
+}
+int bj_proof_stage_ms(const bj_proof *p, float *out8) {
+    if (!p || !out8) return BJ_ERR_INVALID_ARG;
+    std::memcpy(out8, p->stage_ms, sizeof(p->stage_ms));
+    return BJ_OK;
+}
+
+int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, const uint64_t *d_multiplicities,
+                 const uint64_t *h_public_values, bj_proof **out) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_dev: null out pointer");
+    *out = nullptr;
+    if (!S || !d_variables) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_dev: null argument");
+    const bool has_lookup = S->lookup_reps > 0;
+    if (has_lookup && !d_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_dev: multiplicities required");
+    if (!S->pub_cols.empty() && !h_public_values) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_dev: public input values required");
+    hipStream_t st = ctx->stream;
+    const unsigned log_n = S->log_n, V = S->V, q = S->q, L = S->L, fri = S->fri_lde, cap = S->cap_size;
+    const size_t n = (size_t)1 << log_n, N = n * fri, Q = n * q, Ln = n * L;
+    const unsigned nW = V + (has_lookup ? 1 : 0);
+    const unsigned n_chunks = (V + q - 1) / q, n_part = n_chunks - 1;
+    const unsigned nS2 = 2 * (1 + n_part) + (has_lookup ? 2 * (S->lookup_reps + 1) : 0);
+    const unsigned nT = has_lookup ? S->lookup_w + 1 : 0;
+    const unsigned nC = S->nC;
+    int rc = BJ_OK;
+    bj_proof *proof = new bj_proof();
+    struct Guard {
+        bj_proof *&p;
+        bool ok = false;
+        ~Guard() {
+            if (!ok) {
+                delete p;
+                p = nullptr;
+            }
+        }
+    } guard{proof};
+    StageTimer timer(st);
+    bj::host::Transcript tr;
+    tr.absorb(S->cap.data(), S->cap.size());                               // prover.rs:211
+    if (!S->pub_cols.empty()) tr.absorb(h_public_values, S->pub_cols.size());   // prover.rs:257-259
+    auto challenge2 = [&](u64 *o) {
+        o[0] = tr.challenge();
+        o[1] = tr.challenge();
+    };
+    if ((rc = bj::ensure_twiddles(ctx, log_n + (L > fri ? bj::log2_exact(L) : S->log_fri), false))) return rc;
+
+    // ---------------- round 1: witness LDE + tree (prover.rs:270-353) ----------------
+    DevBuf wit_lde, wit_tree, mono;
+    if ((rc = wit_lde.alloc(ctx, (size_t)nW * Ln))) return rc;
+    if ((rc = mono.alloc(ctx, (size_t)(nW > nS2 ? nW : nS2) * n))) return rc;
+    rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
+    if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
+    if (!rc) rc = bj_lde_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L);
+    if (rc) return rc;
+    if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
+    rc = bj_merkle_tree_build(ctx, wit_lde.p, Ln, nW, N, cap, wit_tree.p);
+    std::vector<u64> wit_cap(4 * cap), s2_cap(4 * cap), q_cap(4 * cap);
+    if (!rc) rc = bj_merkle_tree_cap(ctx, wit_tree.p, N, cap, wit_cap.data());
+    if (rc) return rc;
+    tr.absorb(wit_cap.data(), wit_cap.size());
+    proof->stage_ms[0] = timer.lap();
+
+    // ---------------- round 2: copy-permutation + lookup polys (prover.rs:360-554) ----------------
+    u64 beta[2], gamma[2], lbeta[2] = {0, 0}, lgamma[2] = {0, 0};
+    challenge2(beta);
+    challenge2(gamma);
+    DevBuf s2_nat, s2_lde, s2_tree, tmp;
+    if ((rc = s2_nat.alloc(ctx, (size_t)nS2 * n))) return rc;
+    if ((rc = tmp.alloc(ctx, (size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16))) return rc;
+    const u64 *d_sig_nat = S->d_nat, *d_con_nat = S->d_nat + (size_t)V * n, *d_tab_nat = S->d_nat + (size_t)(V + nC) * n;
+    bj::launch_copy_perm_stage2(d_variables, n, d_sig_nat, n, S->d_non_res, V, q, log_n, ctx->tw_fwd, beta, gamma, tmp.p,
+                                s2_nat.p, s2_nat.p + 2 * n, st);
+    if (has_lookup) {
+        challenge2(lbeta);
+        challenge2(lgamma);
+        u64 *dA = s2_nat.p + (size_t)(2 + 2 * n_part) * n, *dB = dA + (size_t)2 * S->lookup_reps * n;
+        bj::launch_lookup_polys(d_variables + (size_t)S->num_gp_vars * n, n, d_con_nat + (size_t)S->table_id_col * n, d_tab_nat,
+                                n, d_multiplicities, S->lookup_reps, S->lookup_w, log_n, lbeta, lgamma, dA, dB, st);
+    }
+    BJ_CHECK_LAUNCH(ctx);
+    if ((rc = s2_lde.alloc(ctx, (size_t)nS2 * Ln))) return rc;
+    rc = bj_intt_batch(ctx, s2_nat.p, mono.p, log_n, nS2, n, 1);
+    if (!rc) rc = bj_lde_batch(ctx, mono.p, n, s2_lde.p, log_n, nS2, S->log_L);
+    if (rc) return rc;
+    if ((rc = s2_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
+    rc = bj_merkle_tree_build(ctx, s2_lde.p, Ln, nS2, N, cap, s2_tree.p);
+    if (!rc) rc = bj_merkle_tree_cap(ctx, s2_tree.p, N, cap, s2_cap.data());
+    if (rc) return rc;
+    tr.absorb(s2_cap.data(), s2_cap.size());
+    proof->stage_ms[1] = timer.lap();
+
+    // ---------------- round 3: quotient (prover.rs:560-1495) ----------------
+    u64 alpha[2];
+    challenge2(alpha);
+    const unsigned n_lookup_terms = has_lookup ? S->lookup_reps + 1 : 0;
+    unsigned n_gate_terms = 0;
+    for (unsigned g = 0; g < S->n_gates; g++) n_gate_terms += (unsigned)(S->gates_flat[12 * g + 2] * S->gates_flat[12 * g + 5]);
+    const unsigned total_terms = n_lookup_terms + n_gate_terms + 1 + n_chunks;
+    std::vector<u64> alphas(2 * total_terms);
+    {
+        gl::e2 a = e2c(alpha), cur{1, 0};
+        for (unsigned i = 0; i < total_terms; i++) {   // materialize_powers_serial (utils.rs:31)
+            alphas[2 * i] = cur.c0;
+            alphas[2 * i + 1] = cur.c1;
+            cur = gl::e2_mul(cur, a);
+        }
+    }
+    DevBuf d_alphas, T;
+    if ((rc = d_alphas.alloc(ctx, alphas.size()))) return rc;
+    if ((rc = bj_memcpy_h2d(ctx, d_alphas.p, alphas.data(), alphas.size() * 8))) return rc;
+    if ((rc = T.alloc(ctx, 2 * Q))) return rc;
+    const u64 *a_lookup = d_alphas.p, *a_gates = d_alphas.p + 2 * n_lookup_terms, *a_l1 = a_gates + 2 * n_gate_terms;
+    const u64 *d_sig_lde = S->d_lde, *d_con_lde = S->d_lde + (size_t)V * Ln, *d_tab_lde = S->d_lde + (size_t)(V + nC) * Ln;
+    bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Q, T.p, T.p + Q, st);
+    if (has_lookup) {
+        const u64 *dA = s2_lde.p + (size_t)(2 + 2 * n_part) * Ln, *dB = dA + (size_t)2 * S->lookup_reps * Ln;
+        bj::launch_quotient_lookup(wit_lde.p + (size_t)S->num_gp_vars * Ln, Ln, d_con_lde + (size_t)S->table_id_col * Ln, d_tab_lde,
+                                   Ln, wit_lde.p + (size_t)V * Ln, dA, dB, Ln, S->lookup_reps, S->lookup_w, lbeta, lgamma,
+                                   a_lookup, Q, T.p, T.p + Q, st);
+    }
+    bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_q, ctx->tw_fwd,
+                                  beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_gate_terms), a_l1 + 2, T.p, T.p + Q, st);
+    BJ_CHECK_LAUNCH(ctx);
+    // flatten (= bit-reversal of the size-qn array), iNTT on coset g, chunk, LDE to fri_lde_factor (prover.rs:1386-1482)
+    const unsigned log_Q = log_n + S->log_q;
+    rc = bj_bitreverse_batch(ctx, T.p, T.p, log_Q, 2, Q);
+    if (!rc) rc = bj_intt_batch(ctx, T.p, T.p, log_Q, 2, Q, gl::GEN);
+    u64 top[2] = {1, 1};
+    if (!rc) rc = bj_memcpy_d2h(ctx, &top[0], T.p + Q - 1, 8);
+    if (!rc) rc = bj_memcpy_d2h(ctx, &top[1], T.p + 2 * Q - 1, 8);
+    if (rc) return rc;
+    if (top[0] != 0 || top[1] != 0)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: constraint system is not satisfied (quotient is not a polynomial; prover.rs:1425-1438)");
+    DevBuf q_lde, q_tree;
+    if ((rc = q_lde.alloc(ctx, (size_t)2 * q * N))) return rc;
+    for (unsigned e = 0; e < 2 && !rc; e++)   // chunk j of c_e -> column 2j+e (prover.rs:1445-1467)
+        rc = bj::lde_cosets_strided(ctx, T.p + (size_t)e * Q, n, q_lde.p + (size_t)e * N, 2 * N, log_n, q, S->log_fri, 0, fri);
+    if (rc) return rc;
+    if ((rc = q_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
+    rc = bj_merkle_tree_build(ctx, q_lde.p, N, 2 * q, N, cap, q_tree.p);
+    if (!rc) rc = bj_merkle_tree_cap(ctx, q_tree.p, N, cap, q_cap.data());
+    if (rc) return rc;
+    tr.absorb(q_cap.data(), q_cap.size());
+    proof->stage_ms[2] = timer.lap();
+
+    // ---------------- round 4: openings (prover.rs:1501-1802) ----------------
+    u64 z[2];
+    challenge2(z);
+    DevBuf w;
+    if ((rc = w.alloc(ctx, 2 * n))) return rc;
+    // base columns whose coset 0 is evaluated, in the order of prover.rs:1550-1683; F_p^2 polys contribute two columns
+    struct Src { const u64 *c0, *c1; };
+    std::vector<Src> srcs;
+    for (unsigned i = 0; i < V; i++) srcs.push_back({wit_lde.p + (size_t)i * Ln, nullptr});
+    for (unsigned i = 0; i < nC; i++) srcs.push_back({d_con_lde + (size_t)i * Ln, nullptr});
+    for (unsigned i = 0; i < V; i++) srcs.push_back({d_sig_lde + (size_t)i * Ln, nullptr});
+    for (unsigned j = 0; j < 1 + n_part; j++) srcs.push_back({s2_lde.p + (size_t)(2 * j) * Ln, s2_lde.p + (size_t)(2 * j + 1) * Ln});
+    if (has_lookup) {
+        srcs.push_back({wit_lde.p + (size_t)V * Ln, nullptr});
+        for (unsigned i = 0; i < S->lookup_reps + 1; i++) {
+            size_t o = (size_t)(2 + 2 * n_part + 2 * i);
+            srcs.push_back({s2_lde.p + o * Ln, s2_lde.p + (o + 1) * Ln});
+        }
+        for (unsigned i = 0; i < nT; i++) srcs.push_back({d_tab_lde + (size_t)i * Ln, nullptr});
+    }
+    for (unsigned j = 0; j < q; j++) srcs.push_back({q_lde.p + (size_t)(2 * j) * N, q_lde.p + (size_t)(2 * j + 1) * N});
+    auto evaluate = [&](const std::vector<Src> &ss, const u64 *at, std::vector<u64> &vals) -> int {
+        int r = bj_barycentric_weights(ctx, log_n, gl::GEN, at, w.p, w.p + n);
+        if (r) return r;
+        std::vector<const u64 *> ptrs;
+        for (auto &s : ss) {
+            ptrs.push_back(s.c0);
+            if (s.c1) ptrs.push_back(s.c1);
+        }
+        std::vector<u64> raw(2 * ptrs.size());
+        r = bj_barycentric_eval_batch(ctx, ptrs.data(), (unsigned)ptrs.size(), log_n, w.p, w.p + n, raw.data());
+        if (r) return r;
+        vals.clear();
+        size_t k = 0;
+        for (auto &s : ss) {
+            gl::e2 e0{raw[2 * k], raw[2 * k + 1]};
+            k++;
+            if (s.c1) {   // E(c0) + u * E(c1) = (a0 + 7 b1, a1 + b0)
+                gl::e2 e1{raw[2 * k], raw[2 * k + 1]};
+                k++;
+                e0 = {gl::add(e0.c0, gl::mul(gl::GEN, e1.c1)), gl::add(e0.c1, e1.c0)};
+            }
+            vals.push_back(e0.c0);
+            vals.push_back(e0.c1);
+        }
+        return BJ_OK;
+    };
+    std::vector<u64> vz, vzo, v0;
+    if ((rc = evaluate(srcs, z, vz))) return rc;
+    tr.absorb(vz.data(), vz.size());
+    u64 zo[2];
+    {
+        u64 om = gl::omega(log_n);
+        zo[0] = gl::mul(gl::canon(z[0]), om);
+        zo[1] = gl::mul(gl::canon(z[1]), om);
+    }
+    std::vector<Src> zsrc{srcs[V + nC + V]};
+    if ((rc = evaluate(zsrc, zo, vzo))) return rc;
+    tr.absorb(vzo.data(), vzo.size());
+    std::vector<Src> lsrc;
+    if (has_lookup) {
+        for (unsigned i = 0; i < S->lookup_reps + 1; i++) lsrc.push_back(srcs[V + nC + V + 1 + n_part + 1 + i]);
+        u64 zero2[2] = {0, 0};
+        if ((rc = evaluate(lsrc, zero2, v0))) return rc;
+        tr.absorb(v0.data(), v0.size());
+    }
+    proof->stage_ms[3] = timer.lap();
+
+    // ---------------- round 5a: DEEP (prover.rs:1803-2067) ----------------
+    struct PubSet { u64 at; std::vector<unsigned> cols; std::vector<u64> vals; };
+    std::vector<PubSet> pubs;
+    {
+        u64 om = gl::omega(log_n);
+        for (size_t i = 0; i < S->pub_cols.size(); i++) {
+            u64 at = gl::pow(om, S->pub_rows[i]);
+            size_t pos = 0;
+            for (; pos < pubs.size(); pos++)
+                if (pubs[pos].at == at) break;
+            if (pos == pubs.size()) pubs.push_back({at, {}, {}});
+            pubs[pos].cols.push_back(S->pub_cols[i]);
+            pubs[pos].vals.push_back(gl::canon(h_public_values[i]));
+        }
+    }
+    u64 cch[2];
+    challenge2(cch);
+    size_t total_ch = srcs.size() + 1 + lsrc.size();
+    for (auto &p : pubs) total_ch += p.cols.size();
+    std::vector<u64> chs(2 * total_ch);
+    {
+        gl::e2 c = e2c(cch), cur{1, 0};
+        for (size_t i = 0; i < total_ch; i++) {   // materialize_ext_challenge_powers (prover.rs:2374-2395)
+            chs[2 * i] = cur.c0;
+            chs[2 * i + 1] = cur.c1;
+            cur = gl::e2_mul(cur, c);
+        }
+    }
+    DevBuf deep;
+    if ((rc = deep.alloc(ctx, 2 * N))) return rc;
+    size_t choff = 0;
+    auto deep_call = [&](const std::vector<Src> &ss, const u64 *vals, const u64 *at, int accumulate) -> int {
+        std::vector<const u64 *> p0, p1;
+        for (auto &s : ss) {
+            p0.push_back(s.c0);
+            p1.push_back(s.c1);
+        }
+        int r = bj_deep_quotient_accumulate(ctx, p0.data(), p1.data(), ss.size(), vals, chs.data() + 2 * choff, at, log_n,
+                                            S->log_fri, deep.p, deep.p + N, accumulate);
+        choff += ss.size();
+        return r;
+    };
+    if ((rc = deep_call(srcs, vz.data(), z, 0))) return rc;
+    if ((rc = deep_call(zsrc, vzo.data(), zo, 1))) return rc;
+    if (has_lookup) {
+        u64 zero2[2] = {0, 0};
+        if ((rc = deep_call(lsrc, v0.data(), zero2, 1))) return rc;
+    }
+    for (auto &p : pubs) {
+        std::vector<Src> ps;
+        std::vector<u64> pv;
+        for (size_t i = 0; i < p.cols.size(); i++) {
+            ps.push_back({wit_lde.p + (size_t)p.cols[i] * Ln, nullptr});
+            pv.push_back(p.vals[i]);
+            pv.push_back(0);
+        }
+        u64 at2[2] = {p.at, 0};
+        if ((rc = deep_call(ps, pv.data(), at2, 1))) return rc;
+    }
+    proof->stage_ms[4] = timer.lap();
+
+    // ---------------- round 5b: FRI (prover.rs:2075-2105) ----------------
+    uint32_t sched[32], new_pow = 0;
+    size_t sched_len = 0, num_queries = 0, final_degree = 0;
+    if ((rc = bj_fri_schedule(S->security, cap, S->pow_bits, S->log_fri, log_n, &new_pow, &num_queries, sched, &sched_len, &final_degree)))
+        return bj::fail(ctx, rc, "bj_prove: compute_fri_schedule failed");
+    bj_transcript trw;   // bj_fri_prove drives a bj_transcript; hand our state over and take it back
+    trw.t = tr;
+    bj_fri *fri_obj = nullptr;
+    rc = bj_fri_prove(ctx, deep.p, deep.p + N, log_n, S->log_fri, sched, sched_len, cap, &trw, &fri_obj);
+    if (rc) return rc;
+    struct FriGuard {
+        bj_fri *f;
+        ~FriGuard() { bj_fri_destroy(f); }
+    } fri_guard{fri_obj};
+    tr = trw.t;
+    proof->stage_ms[5] = timer.lap();
+
+    // ---------------- round 6: queries (prover.rs:2161-2266) ----------------
+    bj::host::BoolsBuffer bools;
+    bools.max_needed = log_n + S->log_fri;
+    std::vector<u64> idxs(num_queries);
+    for (size_t i = 0; i < num_queries; i++) idxs[i] = bools.query_index(tr, log_n, S->log_fri);
+    const unsigned depth = bj::log2_exact(N / cap);
+    const unsigned widths[4] = {nW, nS2, 2 * q, S->n_cols};
+    const u64 *bases[4] = {wit_lde.p, s2_lde.p, q_lde.p, S->d_lde};
+    const size_t strides[4] = {Ln, Ln, N, Ln};
+    const u64 *trees[4] = {wit_tree.p, s2_tree.p, q_tree.p, S->d_tree};
+    DevBuf d_idx, d_g;
+    size_t per_query = 0;
+    for (int o = 0; o < 4; o++) per_query += widths[o] + (size_t)depth * 4;
+    if ((rc = d_idx.alloc(ctx, num_queries))) return rc;
+    if ((rc = d_g.alloc(ctx, per_query * num_queries))) return rc;
+    if ((rc = bj_memcpy_h2d(ctx, d_idx.p, idxs.data(), num_queries * 8))) return rc;
+    std::vector<u64> gathered(per_query * num_queries);
+    {
+        size_t off = 0;
+        for (int o = 0; o < 4; o++) {
+            bj::launch_gather_rows(bases[o], strides[o], widths[o], d_idx.p, (unsigned)num_queries, d_g.p + off, st);
+            off += (size_t)widths[o] * num_queries;
+            bj::launch_merkle_paths(trees[o], N, depth, d_idx.p, (unsigned)num_queries, d_g.p + off, st);
+            off += (size_t)depth * 4 * num_queries;
+        }
+        BJ_CHECK_LAUNCH(ctx);
+        if ((rc = bj_memcpy_d2h(ctx, gathered.data(), d_g.p, gathered.size() * 8))) return rc;
+    }
+    // ---------------- serialise ----------------
+    std::vector<u64> &D = proof->data;
+    auto put = [&](const u64 *p, size_t k) { D.insert(D.end(), p, p + k); };
+    const u64 header[] = {0x424A5046ULL, 1, S->pub_cols.size(), cap, vz.size() / 2, vzo.size() / 2, v0.size() / 2, sched_len,
+                          final_degree, num_queries, nW, nS2, 2 * q, S->n_cols, depth, log_n, fri};
+    put(header, sizeof(header) / 8);
+    for (size_t i = 0; i < sched_len; i++) D.push_back(sched[i]);
+    for (size_t i = 0; i < S->pub_cols.size(); i++) D.push_back(gl::canon(h_public_values[i]));
+    put(wit_cap.data(), wit_cap.size());
+    put(s2_cap.data(), s2_cap.size());
+    put(q_cap.data(), q_cap.size());
+    put(vz.data(), vz.size());
+    put(vzo.data(), vzo.size());
+    put(v0.data(), v0.size());
+    {
+        std::vector<u64> c(4 * cap);
+        for (size_t i = 0; i < sched_len; i++) {
+            bj_fri_cap(fri_obj, i, c.data());
+            put(c.data(), c.size());
+        }
+        std::vector<u64> f0(final_degree), f1(final_degree);
+        bj_fri_final_monomials(fri_obj, f0.data(), f1.data());
+        put(f0.data(), final_degree);
+        put(f1.data(), final_degree);
+    }
+    for (size_t qi = 0; qi < num_queries; qi++) {
+        D.push_back(idxs[qi]);
+        size_t off = 0;
+        for (int o = 0; o < 4; o++) {
+            put(gathered.data() + off + qi * widths[o], widths[o]);
+            off += (size_t)widths[o] * num_queries;
+            put(gathered.data() + off + qi * (size_t)depth * 4, (size_t)depth * 4);
+            off += (size_t)depth * 4 * num_queries;
+        }
+        size_t f_idx = idxs[qi], ln = N;
+        for (size_t i = 0; i < sched_len; i++) {
+            const unsigned k = sched[i];
+            const size_t E = (size_t)1 << k;
+            const unsigned fdepth = bj::log2_exact((ln >> k) / cap);
+            std::vector<u64> leaf(2 * E), path((size_t)(fdepth ? fdepth : 1) * 4);
+            if ((rc = bj_fri_query(ctx, fri_obj, i, f_idx, leaf.data(), path.data()))) return rc;
+            put(leaf.data(), leaf.size());
+            put(path.data(), (size_t)fdepth * 4);
+            f_idx >>= k;
+            ln >>= k;
+        }
+    }
+    proof->stage_ms[6] = timer.lap();
+    guard.ok = true;
+    *out = proof;
+    return BJ_OK;
+}
+
+int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+             const uint64_t *h_public_values, bj_proof **out) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!S || !h_variables || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
+    const size_t n = (size_t)1 << S->log_n;
+    DevBuf vars, mult;
+    int rc = vars.alloc(ctx, (size_t)S->V * n);
+    if (!rc) rc = bj_memcpy_h2d(ctx, vars.p, h_variables, (size_t)S->V * n * 8);
+    if (!rc && S->lookup_reps) {
+        if (!h_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
+        rc = mult.alloc(ctx, n);
+        if (!rc) rc = bj_memcpy_h2d(ctx, mult.p, h_multiplicities, n * 8);
+    }
+    if (rc) return rc;
+    return bj_prove_dev(ctx, S, vars.p, S->lookup_reps ? mult.p : nullptr, h_public_values, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+// Prover round 3 on the device: the quotient numerator over the first q cosets of the LDE and its division by the
+// vanishing polynomial.
+//
+// Must equal (as canonical residues), point by point (flat index I = coset*n + i, i bit-reversed):
+//   gate evaluation over general purpose columns    src/cs/implementations/prover.rs:1031-1080 with the destination of
+//                                                   buffering_source.rs:133-222, 304-362 and the evaluators of
+//                                                   cs/gates/{constant_allocator,fma_gate_without_constant,reduction_gate}.rs
+//   selectors                                       compute_selector_subpath, prover.rs:2775-2916
+//   (z - 1) * L1~                                   prover.rs:1189-1227 with unnormalized_l1_inverse utils.rs:1585-1672
+//   copy-permutation chain                          compute_quotient_terms_in_extension copy_permutation.rs:1000-1249
+//   lookup terms                                    compute_quotient_terms_for_lookup_specialized lookup_argument_in_ext.rs:949-1319
+//   1 / (x^n - 1) per coset                         divide_by_vanishing_for_bitreversed_coset_enumeration utils.rs:770-817
+// One lane = one LDE point; consecutive lanes read consecutive addresses of every column (coalesced).  Sums of
+// challenge * term products are accumulated unreduced in 160-bit accumulators and reduced once.
+#include "gl.cuh"
+#include "kernels.h"
+
+using gl::u64;
+using gl::u32;
+
+namespace bj {
+
+struct Acc160q {
+    u32 w[5];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = 0;
+    }
+    __device__ __forceinline__ void fma(u64 a, u64 b) {
+        u32 hh, hl;
+        u64 lo;
+        gl::mul_limbs(a, b, hh, hl, lo);
+        u32 c;
+        w[0] = __builtin_addc(w[0], gl::lo32(lo), 0u, &c);
+        w[1] = __builtin_addc(w[1], gl::hi32(lo), c, &c);
+        w[2] = __builtin_addc(w[2], hl, c, &c);
+        w[3] = __builtin_addc(w[3], hh, c, &c);
+        w[4] += c;
+    }
+    __device__ __forceinline__ u64 reduce() const {
+        u64 r = gl::reduce_limbs(w[3], w[2], gl::pack(w[0], w[1]));
+        return gl::sub(r, (u64)w[4] << 32);
+    }
+};
+
+__device__ inline u64 inv_chain3(u64 x) {
+    auto sqn = [](u64 v, int n) { for (int i = 0; i < n; i++) v = gl::sqr(v); return v; };
+    u64 a1 = x, a2 = gl::mul(sqn(a1, 1), a1), a4 = gl::mul(sqn(a2, 2), a2), a8 = gl::mul(sqn(a4, 4), a4);
+    u64 a16 = gl::mul(sqn(a8, 8), a8), a24 = gl::mul(sqn(a16, 8), a8), a28 = gl::mul(sqn(a24, 4), a4);
+    u64 a30 = gl::mul(sqn(a28, 2), a2), a31 = gl::mul(sqn(a30, 1), a1);
+    u64 b = gl::sqr(a31), a32 = gl::mul(b, x);
+    return gl::mul(sqn(b, 32), a32);
+}
+__device__ __forceinline__ u64 mul7q(u64 a) { return gl::sub(gl::mul_pow2(a, 3), a); }
+
+// x_I = 7 * w_{qn}^{bitrev(I)} = 7 * T[I>>1] * (-1)^(I&1)
+__device__ __forceinline__ u64 lde_point(const u64 *tw, size_t I) {
+    u64 wi = tw[I >> 1];
+    if (I & 1) wi = gl::neg(wi);
+    return mul7q(wi);
+}
+
+struct GateDev {
+    int kind, path_len, reps, var_stride, const_stride, num_terms;
+    int path[6];
+};
+struct GateSet {
+    GateDev g[8];
+    int n_gates;
+};
+
+// T = sum_g selector_g * sum_t alpha_t * term_t            (overwrites out)
+__global__ void __launch_bounds__(256)
+quotient_gates_kernel(const u64 *vars, size_t var_stride, const u64 *consts, size_t const_stride, GateSet gs,
+                      const u64 *alphas /* [n_terms][2] */, size_t Q, u64 *out0, u64 *out1) {
+    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= Q) return;
+    gl::e2 acc{0, 0};
+    int aoff = 0;
+    for (int gi = 0; gi < gs.n_gates; gi++) {
+        const GateDev &G = gs.g[gi];
+        if (G.num_terms == 0) continue;
+        u64 sel = 1;
+        for (int b = 0; b < G.path_len; b++) {
+            u64 c = gl::canon(consts[(size_t)b * const_stride + I]);
+            sel = gl::mul(sel, G.path[b] ? c : gl::sub(1, c));
+        }
+        Acc160q s0, s1;
+        s0.clear();
+        s1.clear();
+        const size_t cb0 = (size_t)G.path_len;
+        u64 k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+        if (G.kind == 2) {
+            k0 = gl::canon(consts[cb0 * const_stride + I]);
+            k1 = gl::canon(consts[(cb0 + 1) * const_stride + I]);
+        } else if (G.kind == 3) {
+            k0 = gl::canon(consts[cb0 * const_stride + I]);
+            k1 = gl::canon(consts[(cb0 + 1) * const_stride + I]);
+            k2 = gl::canon(consts[(cb0 + 2) * const_stride + I]);
+            k3 = gl::canon(consts[(cb0 + 3) * const_stride + I]);
+        }
+        for (int r = 0; r < G.reps; r++) {
+            const size_t vb = (size_t)r * G.var_stride;
+#define VARQ(k) gl::canon(vars[(vb + (k)) * var_stride + I])
+            u64 term;
+            if (G.kind == 1) {          // ConstantsAllocator: a - c_r
+                u64 c = gl::canon(consts[(cb0 + (size_t)r * G.const_stride) * const_stride + I]);
+                term = gl::sub(VARQ(0), c);
+            } else if (G.kind == 2) {   // FMA: q*a*b + l*c - d
+                u64 a = VARQ(0), b = VARQ(1), c = VARQ(2), d = VARQ(3);
+                term = gl::sub(gl::add(gl::mul(c, k1), gl::mul(k0, gl::mul(a, b))), d);
+            } else {                    // Reduction<4>: sum c_i v_i - r
+                Acc160q t;
+                t.clear();
+                t.fma(VARQ(0), k0);
+                t.fma(VARQ(1), k1);
+                t.fma(VARQ(2), k2);
+                t.fma(VARQ(3), k3);
+                term = gl::sub(t.reduce(), VARQ(4));
+            }
+#undef VARQ
+            s0.fma(term, alphas[2 * aoff]);
+            s1.fma(term, alphas[2 * aoff + 1]);
+            aoff++;
+        }
+        acc.c0 = gl::add(acc.c0, gl::mul(s0.reduce(), sel));
+        acc.c1 = gl::add(acc.c1, gl::mul(s1.reduce(), sel));
+    }
+    out0[I] = acc.c0;
+    out1[I] = acc.c1;
+}
+
+// T += sum_i alpha_i * (A_i * (lbeta + sum_j lgamma^j col_ij + lgamma^w tid) - 1) + alpha_B * (B * (lbeta + sum_j lgamma^j tab_j) - mult)
+struct LookupQArgs {
+    gl::e2 beta;
+    gl::e2 gpow[9];
+};
+__global__ void __launch_bounds__(256)
+quotient_lookup_kernel(const u64 *lvars, size_t var_stride, const u64 *table_id, const u64 *tables, size_t tab_stride,
+                       const u64 *mult, const u64 *A, const u64 *B, size_t s2_stride, unsigned reps, unsigned w,
+                       LookupQArgs la, const u64 *alphas /* [reps+1][2] */, size_t Q, u64 *out0, u64 *out1) {
+    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= Q) return;
+    Acc160q s0, s1;
+    s0.clear();
+    s1.clear();
+    const u64 tid = gl::canon(table_id[I]);
+    for (unsigned i = 0; i <= reps; i++) {
+        gl::e2 d = la.beta;
+        gl::e2 poly;
+        u64 minus;
+        if (i < reps) {
+            for (unsigned j = 0; j < w; j++) {
+                u64 v = gl::canon(lvars[(size_t)(i * w + j) * var_stride + I]);
+                d = gl::e2_add(d, gl::e2_mul_base(la.gpow[j], v));
+            }
+            d = gl::e2_add(d, gl::e2_mul_base(la.gpow[w], tid));
+            poly = {gl::canon(A[((size_t)2 * i) * s2_stride + I]), gl::canon(A[((size_t)2 * i + 1) * s2_stride + I])};
+            minus = 1;
+        } else {
+            for (unsigned j = 0; j <= w; j++) {
+                u64 v = gl::canon(tables[(size_t)j * tab_stride + I]);
+                d = gl::e2_add(d, gl::e2_mul_base(la.gpow[j], v));
+            }
+            poly = {gl::canon(B[I]), gl::canon(B[s2_stride + I])};
+            minus = gl::canon(mult[I]);
+        }
+        gl::e2 t = gl::e2_mul(poly, d);
+        t.c0 = gl::sub(t.c0, minus);
+        // (t0 + t1 u)(a0 + a1 u) = (t0 a0 + 7 t1 a1) + (t0 a1 + t1 a0) u
+        const u64 a0 = alphas[2 * i], a1 = alphas[2 * i + 1];
+        s0.fma(t.c0, a0);
+        s0.fma(t.c1, mul7q(a1));
+        s1.fma(t.c0, a1);
+        s1.fma(t.c1, a0);
+    }
+    out0[I] = gl::add(gl::canon(out0[I]), s0.reduce());
+    out1[I] = gl::add(gl::canon(out1[I]), s1.reduce());
+}
+
+// T = (T + alpha_L1 * (z - 1) * L1~(x) + copy-permutation chain) / (x^n - 1)
+struct CopyPermQArgs {
+    gl::e2 beta, gamma, alpha_l1;
+    u64 xn_minus_one[64];        // per coset: x^n - 1
+    u64 vanishing_inv[64];       // per coset: 1 / (x^n - 1)
+};
+__global__ void __launch_bounds__(256)
+quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas, size_t sig_stride, const u64 *stage2,
+                          size_t s2_stride, const u64 *non_res, unsigned V, unsigned chunk, unsigned n_chunks,
+                          unsigned log_n, const u64 *tw, CopyPermQArgs ca, const u64 *alphas /* [n_chunks][2] */,
+                          size_t Q, u64 *out0, u64 *out1) {
+    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= Q) return;
+    const size_t n = (size_t)1 << log_n;
+    const unsigned coset = (unsigned)(I >> log_n);
+    const u32 i_br = (u32)(I & (n - 1));
+    const u64 x = lde_point(tw, I);
+    Acc160q s0, s1;
+    s0.clear();
+    s1.clear();
+    const gl::e2 zv{gl::canon(stage2[I]), gl::canon(stage2[s2_stride + I])};
+    {   // (z - 1) * (x^n - 1) / (x - 1) * alpha
+        u64 l1 = gl::mul(ca.xn_minus_one[coset], inv_chain3(gl::sub(x, 1)));
+        gl::e2 t{gl::mul(gl::sub(zv.c0, 1), l1), gl::mul(zv.c1, l1)};
+        s0.fma(t.c0, ca.alpha_l1.c0);
+        s0.fma(t.c1, mul7q(ca.alpha_l1.c1));
+        s1.fma(t.c0, ca.alpha_l1.c1);
+        s1.fma(t.c1, ca.alpha_l1.c0);
+    }
+    // z(omega * x): next natural index inside the coset
+    const u32 i_next = gl::bitrev32((gl::bitrev32(i_br, log_n) + 1) & (u32)(n - 1), log_n);
+    const size_t In = ((size_t)coset << log_n) + i_next;
+    const gl::e2 z_shift{gl::canon(stage2[In]), gl::canon(stage2[s2_stride + In])};
+    for (unsigned j = 0; j < n_chunks; j++) {
+        gl::e2 lhs = (j + 1 < n_chunks)
+                         ? gl::e2{gl::canon(stage2[((size_t)2 + 2 * j) * s2_stride + I]), gl::canon(stage2[((size_t)3 + 2 * j) * s2_stride + I])}
+                         : z_shift;
+        gl::e2 rhs = (j == 0) ? zv
+                              : gl::e2{gl::canon(stage2[((size_t)2 * j) * s2_stride + I]), gl::canon(stage2[((size_t)2 * j + 1) * s2_stride + I])};
+        for (unsigned c = j * chunk; c < (j + 1) * chunk && c < V; c++) {
+            u64 w = gl::canon(vars[(size_t)c * var_stride + I]);
+            u64 sg = gl::canon(sigmas[(size_t)c * sig_stride + I]);
+            gl::e2 d{gl::add(gl::add(gl::mul(sg, ca.beta.c0), w), ca.gamma.c0), gl::add(gl::mul(sg, ca.beta.c1), ca.gamma.c1)};
+            lhs = gl::e2_mul(lhs, d);
+            u64 kx = gl::mul(x, non_res[c]);
+            gl::e2 nm{gl::add(gl::add(gl::mul(kx, ca.beta.c0), w), ca.gamma.c0), gl::add(gl::mul(kx, ca.beta.c1), ca.gamma.c1)};
+            rhs = gl::e2_mul(rhs, nm);
+        }
+        gl::e2 t = gl::e2_sub(lhs, rhs);
+        const u64 a0 = alphas[2 * j], a1 = alphas[2 * j + 1];
+        s0.fma(t.c0, a0);
+        s0.fma(t.c1, mul7q(a1));
+        s1.fma(t.c0, a1);
+        s1.fma(t.c1, a0);
+    }
+    u64 r0 = gl::add(gl::canon(out0[I]), s0.reduce());
+    u64 r1 = gl::add(gl::canon(out1[I]), s1.reduce());
+    const u64 vi = ca.vanishing_inv[coset];
+    out0[I] = gl::mul(r0, vi);
+    out1[I] = gl::mul(r1, vi);
+}
+
+// ----------------------------------------------------------------------------------------------- launchers
+void launch_quotient_gates(const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                           const int *h_gates_flat /* 12 ints per gate */, unsigned n_gates, const u64 *d_alphas,
+                           size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s) {
+    GateSet gs;
+    gs.n_gates = (int)n_gates;
+    for (unsigned g = 0; g < n_gates && g < 8; g++) {
+        const int *f = h_gates_flat + 12 * g;
+        gs.g[g] = GateDev{f[0], f[1], f[2], f[3], f[4], f[5], {f[6], f[7], f[8], f[9], f[10], f[11]}};
+    }
+    hipLaunchKernelGGL(quotient_gates_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_vars, var_stride,
+                       d_consts, const_stride, gs, d_alphas, Q, d_out0, d_out1);
+}
+
+void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_table_id, const u64 *d_tables,
+                            size_t tab_stride, const u64 *d_mult, const u64 *d_A, const u64 *d_B, size_t s2_stride,
+                            unsigned reps, unsigned w, const u64 *lbeta, const u64 *lgamma, const u64 *d_alphas,
+                            size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s) {
+    LookupQArgs la;
+    la.beta = {gl::canon(lbeta[0]), gl::canon(lbeta[1])};
+    gl::e2 g{gl::canon(lgamma[0]), gl::canon(lgamma[1])};
+    la.gpow[0] = {1, 0};
+    for (unsigned j = 1; j <= w && j < 9; j++) la.gpow[j] = gl::e2_mul(la.gpow[j - 1], g);
+    hipLaunchKernelGGL(quotient_lookup_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_lvars, var_stride,
+                       d_table_id, d_tables, tab_stride, d_mult, d_A, d_B, s2_stride, reps, w, la, d_alphas, Q, d_out0,
+                       d_out1);
+}
+
+void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
+                               const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
+                               unsigned log_n, unsigned log_q, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
+                               const u64 *alpha_l1, const u64 *d_alphas_cp, u64 *d_out0, u64 *d_out1, hipStream_t s) {
+    const size_t n = (size_t)1 << log_n, Q = n << log_q;
+    const unsigned q = 1u << log_q;
+    CopyPermQArgs ca;
+    ca.beta = {gl::canon(beta[0]), gl::canon(beta[1])};
+    ca.gamma = {gl::canon(gamma[0]), gl::canon(gamma[1])};
+    ca.alpha_l1 = {gl::canon(alpha_l1[0]), gl::canon(alpha_l1[1])};
+    // x^n on coset c: (7 * w_{qn}^{bitrev_q(c)})^n = 7^n * w_q^{bitrev_q(c)}
+    const u64 g_n = gl::pow(gl::GEN, n);
+    const u64 wq = gl::omega(log_q);
+    for (unsigned c = 0; c < 64; c++) {
+        if (c < q) {
+            u64 xn = gl::mul(g_n, gl::pow(wq, gl::bitrev32(c, log_q)));
+            ca.xn_minus_one[c] = gl::sub(xn, 1);
+            ca.vanishing_inv[c] = gl::inv(ca.xn_minus_one[c]);
+        } else {
+            ca.xn_minus_one[c] = 0;
+            ca.vanishing_inv[c] = 0;
+        }
+    }
+    const unsigned n_chunks = (V + chunk - 1) / chunk;
+    hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_vars, var_stride,
+                       d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
+                       d_alphas_cp, Q, d_out0, d_out1);
+}
+
+// ----------------------------------------------------------------------------------------------- query gathers
+// out[q][c] = base[c * col_stride + idx[q]]   (leaf elements of a base oracle, proof.rs:65-100)
+__global__ void gather_rows_kernel(const u64 *base, size_t col_stride, unsigned n_cols, const u64 *idx, unsigned n_idx,
+                                   u64 *out) {
+    unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned qi = blockIdx.y;
+    if (c >= n_cols || qi >= n_idx) return;
+    out[(size_t)qi * n_cols + c] = gl::canon(base[(size_t)c * col_stride + idx[qi]]);
+}
+void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, const u64 *d_idx, unsigned n_idx,
+                        u64 *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_cols + 63) / 64, n_idx), dim3(64), 0, s, d_base, col_stride, n_cols,
+                       d_idx, n_idx, d_out);
+}
+// Merkle paths for many leaves at once: out[q][d][4] = sibling at depth d  (merkle_tree.rs:462-480)
+__global__ void merkle_paths_kernel(const u64 *tree, size_t num_leaves, unsigned depth, const u64 *idx, unsigned n_idx,
+                                    u64 *out) {
+    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * depth) return;
+    unsigned qi = t / depth, d = t % depth;
+    size_t off = 0, len = num_leaves;
+    for (unsigned k = 0; k < d; k++) {
+        off += len;
+        len >>= 1;
+    }
+    size_t pos = (idx[qi] >> d) ^ 1;
+    const u64 *src = tree + 4 * (off + pos);
+    u64 *dst = out + ((size_t)qi * depth + d) * 4;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+}
+void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, const u64 *d_idx, unsigned n_idx,
+                         u64 *d_out, hipStream_t s) {
+    unsigned total = n_idx * depth;
+    if (!total) return;
+    hipLaunchKernelGGL(merkle_paths_kernel, dim3((total + 63) / 64), dim3(64), 0, s, d_tree, num_leaves, depth, d_idx,
+                       n_idx, d_out);
+}
+
+}  // namespace bj

@@ -219,6 +219,82 @@ int bj_fri_final_monomials(const bj_fri *f, uint64_t *h_c0, uint64_t *h_c1); /* 
 int bj_fri_query(bj_ctx *ctx, const bj_fri *f, size_t oracle, size_t index, uint64_t *h_leaf_elements,
                  uint64_t *h_path);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Whole prover (seam S1).  Replaces CSReferenceAssembly::prove_cpu_basic (src/cs/implementations/prover.rs:153-168)
+ * and the prover-side part of get_full_setup (src/cs/implementations/setup.rs:1273-1300) for the circuit class of the
+ * reference's SHA-256 bench: general-purpose gates selected by a selector tree, specialized lookups with a shared
+ * constant table id, Poseidon2 tree hasher + Poseidon2 transcript, no witness columns, PoW off.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef enum bj_gate_kind {
+    BJ_GATE_CONSTANT_ALLOCATOR = 1, /* a - c                      src/cs/gates/constant_allocator.rs:107-126          */
+    BJ_GATE_FMA_NO_CONSTANT = 2,    /* q*a*b + l*c - d            src/cs/gates/fma_gate_without_constant.rs:96-126    */
+    BJ_GATE_REDUCTION4 = 3,         /* sum_i c_i*v_i - r          src/cs/gates/reduction_gate.rs:103-126              */
+    BJ_GATE_NOP = 4                 /* no terms                   src/cs/gates/nop_gate.rs:41                         */
+} bj_gate_kind;
+
+typedef struct bj_gate_desc {
+    int kind;                 /* bj_gate_kind */
+    unsigned path_len;        /* selector path from TreeNode::output_placement (setup.rs:1455-1483) */
+    unsigned char path[8];    /* 1: multiply by constant column i, 0: by (1 - constant column i)  (prover.rs:2775-2916) */
+    unsigned num_repetitions; /* num_repetitions_in_geometry */
+    unsigned var_stride;      /* per_chunk_offset.variables_offset */
+    unsigned const_stride;    /* per_chunk_offset.constants_offset */
+    unsigned num_terms;       /* quotient terms per repetition (0 for markers) */
+} bj_gate_desc;
+
+typedef struct bj_circuit {
+    unsigned log_n;              /* trace length 2^log_n */
+    unsigned num_vars;           /* all variable columns: general purpose first, then the specialized lookup columns */
+    unsigned num_gp_vars;        /* CSGeometry::num_columns_under_copy_permutation */
+    unsigned num_witness_cols;   /* must be 0 */
+    unsigned num_constant_cols;  /* selector/gate constants + (lookups) the table-id column */
+    unsigned lookup_width;       /* LookupParameters::UseSpecializedColumnsWithTableIdAsConstant { width, .. } */
+    unsigned lookup_reps;        /* num_repetitions; 0 = no lookup argument */
+    unsigned table_id_col;       /* vk.fixed_parameters.table_ids_column_idxes[0] */
+    unsigned quotient_degree;    /* vk.fixed_parameters.quotient_degree (power of two) */
+    unsigned num_gates;          /* evaluators over general purpose columns, in evaluator order (<= 8) */
+    const bj_gate_desc *gates;
+    const uint64_t *non_residues;     /* num_vars entries: non_residues_for_copy_permutation (copy_permutation.rs:512-523) */
+    unsigned num_public_inputs;
+    const unsigned *public_input_cols; /* vk.fixed_parameters.public_inputs_locations */
+    const unsigned *public_input_rows;
+} bj_circuit;
+
+typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */
+    unsigned fri_lde_factor;
+    unsigned cap_size;
+    unsigned security_level;
+    unsigned pow_bits; /* must be 0 */
+} bj_proof_config;
+
+typedef struct bj_setup bj_setup; /* device-resident SetupStorage + setup Merkle tree + VK cap; reusable across proofs */
+typedef struct bj_proof bj_proof;
+
+/* h_sigmas [num_vars][n], h_constants [num_constant_cols][n], h_tables [lookup_width+1][n] (NULL without lookups):
+ * natural-order values over the main domain (SetupBaseStorage, polynomial_storage.rs:48-75). */
+int bj_setup_create(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_sigmas, const uint64_t *h_constants,
+                    const uint64_t *h_tables, const bj_proof_config *config, bj_setup **out);
+void bj_setup_destroy(bj_setup *s);
+int bj_setup_cap(const bj_setup *s, uint64_t *h_cap); /* vk.setup_merkle_tree_cap: cap_size*4 u64 */
+
+/* WitnessSet (witness.rs:21-27) in: variables [num_vars][n] natural order, multiplicities [n] (NULL without lookups),
+ * public input values in location order.  Proof out (bj_proof_serialize).  Returns BJ_ERR_INVALID_ARG with
+ * "constraint system is not satisfied" where the reference panics "unsatisfied" (prover.rs:1425-1438). */
+int bj_prove(bj_ctx *ctx, const bj_setup *setup, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+             const uint64_t *h_public_values, bj_proof **out);
+/* same with the witness already resident in HBM ([num_vars][n] contiguous; not modified) */
+int bj_prove_dev(bj_ctx *ctx, const bj_setup *setup, const uint64_t *d_variables, const uint64_t *d_multiplicities,
+                 const uint64_t *h_public_values, bj_proof **out);
+void bj_proof_destroy(bj_proof *p);
+/* Flat little-endian u64 serialisation of Proof (proof.rs:121-136); layout documented in era_boojum_amd/proof_format.py:
+ * header | schedule | public inputs | witness / stage-2 / quotient caps | values at z, z*omega, 0 | FRI caps |
+ * final monomials | per query: index, 4 base-oracle openings (leaf elements + path), FRI openings. */
+size_t bj_proof_size_u64(const bj_proof *p);
+int bj_proof_serialize(const bj_proof *p, uint64_t *out);
+/* wall-clock per stage in ms, named after the reference's log lines: [0] witness LDE + tree, [1] second stage,
+ * [2] quotient work and LDE + tree, [3] openings at z, [4] batched FRI opening computation (DEEP), [5] FRI, [6] queries */
+int bj_proof_stage_ms(const bj_proof *p, float *out8);
+
 #ifdef __cplusplus
 }
 #endif

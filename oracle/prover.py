@@ -93,7 +93,8 @@ class Setup:
         self.log_L = self.L.bit_length() - 1
         n = c.n
         # leaf order of the setup oracle: sigma || constants || tables   (polynomial_storage.rs:667-676)
-        self.cols_nat = np.concatenate([c.sigmas, c.constants, c.tables], axis=0)
+        parts = [c.sigmas, c.constants] + ([c.tables] if c.lookup_reps else [])
+        self.cols_nat = np.concatenate(parts, axis=0)
         self.mono = O.ifft_batch(self.cols_nat, 1, threads)
         self.lde = O.lde_batch(self.mono, self.log_L, threads)            # [cols][L][n]
         N = n * fri_lde_factor

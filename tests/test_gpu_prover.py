@@ -1,0 +1,69 @@
+"""-m gpu: the whole HIP prover (bj_setup_create + bj_prove through the C ABI) against the CPU oracle prover on the same
+SHA-shaped synthetic circuit: IDENTICAL proof (every cap, opening, FRI layer, query), and the oracle's restatement of
+the reference verifier accepts it."""
+import numpy as np
+import pytest
+
+import era_boojum_amd as E
+from era_boojum_amd import proof_format, synthetic as S
+from gpu_util import ctx
+from oracle import prover as OP
+from oracle import verifier as OV
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(pg, po):
+    for k in ("public_inputs", "witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z",
+              "values_at_z_omega", "values_at_0", "fri_base_oracle_cap", "fri_intermediate_oracles_caps",
+              "final_fri_monomials"):
+        assert pg[k] == po[k], k
+    assert len(pg["queries_per_fri_repetition"]) == len(po["queries_per_fri_repetition"])
+    for qg, qo in zip(pg["queries_per_fri_repetition"], po["queries_per_fri_repetition"]):
+        for name in ("witness_query", "stage_2_query", "quotient_query", "setup_query"):
+            assert qg[name] == qo[name], name
+        assert qg["fri_queries"] == qo["fri_queries"]
+
+
+@pytest.mark.parametrize("log_n,fri_lde,cap,sec,bits", [(9, 8, 16, 30, 2), (8, 2, 4, 20, 2), (12, 8, 16, 40, 2), (14, 4, 16, 50, 4)])
+def test_hip_proof_equals_oracle_proof_and_verifies(log_n, fri_lde, cap, sec, bits):
+    c = S.sha_shaped_circuit(log_n, seed=100 + log_n, table_bits=bits)
+    osetup = OP.Setup(c, fri_lde, cap, threads=8)
+    po = OP.prove(c, osetup, fri_lde, cap, security_level=sec, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, fri_lde, cap, sec)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, stage_ms = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=sec)
+    _compare(pg, po)
+    vk = OV.VerificationKey(c, gsetup.cap(), fri_lde, cap)
+    assert OV.verify(vk, pg, verbose=True)
+    assert set(stage_ms) == set(E.binding.STAGE_NAMES)
+    gsetup.close()
+
+
+def test_hip_prover_reports_unsatisfied_witness():
+    c = S.sha_shaped_circuit(8, seed=5, table_bits=2)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 20)
+    rows = np.nonzero(c.constants[0] == 1)[0]
+    bad = c.variables.copy()
+    bad[3, rows[0]] = (int(bad[3, rows[0]]) + 1) % E.P
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        gsetup.prove(variables=bad)
+    gsetup.close()
+
+
+def test_hip_prover_without_lookups():
+    c = S.sha_shaped_circuit(8, seed=9, table_bits=2)
+    # strip the lookup argument: keep only the general-purpose part of the circuit
+    c.variables = np.ascontiguousarray(c.variables[:c.num_gp_vars]); c.sigmas = np.ascontiguousarray(c.sigmas[:c.num_gp_vars])
+    c.non_residues = c.non_residues[:c.num_gp_vars]
+    c.constants = np.ascontiguousarray(c.constants[:c.num_constants_for_gates]); c.num_constant_cols = c.num_constants_for_gates
+    c.num_lookup_vars = 0; c.lookup_reps = 0
+    osetup = OP.Setup(c, 4, 8, threads=4)
+    po = OP.prove(c, osetup, 4, 8, security_level=20, threads=4)
+    gsetup = E.ProverSetup(ctx(), c, 4, 8, 20)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=20)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 4, 8), pg, verbose=True)
+    gsetup.close()
