@@ -5,32 +5,12 @@
 // All polynomial data stay in HBM; the host only sees caps (cap_size*32 B), the final monomials and the challenges.
 #include "ctx.h"
 #include "host_transcript.hpp"
+#include "fri_types.h"
 
 #include <cstring>
 #include <vector>
 
 using gl::u64;
-
-struct bj_fri {
-    int device = 0;
-    size_t cap_size = 0;
-    unsigned log_full = 0, log_lde = 0;
-    struct Oracle {
-        u64 *d_c0 = nullptr, *d_c1 = nullptr;  // leaf sources (oracle 0: the caller's codeword, not owned)
-        bool owned = false;
-        size_t len = 0;
-        unsigned log_e = 0;
-        u64 *d_tree = nullptr;
-        size_t num_leaves = 0;
-        std::vector<u64> cap;
-        u64 ch0 = 0, ch1 = 0;
-    };
-    std::vector<Oracle> oracles;
-    u64 *d_last0 = nullptr, *d_last1 = nullptr;  // last folded layer
-    size_t last_len = 0;
-    std::vector<u64> final_c0, final_c1;
-    size_t final_degree = 0;
-};
 
 extern "C" {
 

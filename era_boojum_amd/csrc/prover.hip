@@ -9,6 +9,7 @@
 // (src/gadgets/sha256/mod.rs:284-375).
 #include "ctx.h"
 #include "host_transcript.hpp"
+#include "fri_types.h"
 
 #include <chrono>
 #include <cstring>
@@ -40,6 +41,8 @@ void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, c
                         u64 *d_out, hipStream_t s);
 void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, const u64 *d_idx, unsigned n_idx,
                          u64 *d_out, hipStream_t s);
+void launch_gather_fri_leaves(const u64 *d_c0, const u64 *d_c1, unsigned log_e, const u64 *d_leaf_idx, unsigned n_idx,
+                              u64 *d_out, hipStream_t s);
 }  // namespace bj
 
 struct bj_setup {
@@ -524,6 +527,40 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         BJ_CHECK_LAUNCH(ctx);
         if ((rc = bj_memcpy_d2h(ctx, gathered.data(), d_g.p, gathered.size() * 8))) return rc;
     }
+    // FRI openings, batched per oracle: leaf j = (index >> folds so far) >> k  (proof.rs:65-100, fri/mod.rs:829-895)
+    std::vector<std::vector<u64>> fri_leaves(sched_len), fri_paths(sched_len);
+    std::vector<unsigned> fri_depth(sched_len);
+    {
+        DevBuf d_li, d_fo;
+        if ((rc = d_li.alloc(ctx, num_queries))) return rc;
+        size_t max_out = 0;
+        for (size_t i = 0; i < sched_len; i++) {
+            const bj_fri::Oracle &o = fri_obj->oracles[i];
+            fri_depth[i] = bj::log2_exact(o.num_leaves / cap);
+            size_t need = ((size_t)2 << o.log_e) + (size_t)fri_depth[i] * 4;
+            if (need > max_out) max_out = need;
+        }
+        if ((rc = d_fo.alloc(ctx, max_out * num_queries))) return rc;
+        std::vector<u64> li(num_queries);
+        unsigned shift = 0;
+        for (size_t i = 0; i < sched_len; i++) {
+            const bj_fri::Oracle &o = fri_obj->oracles[i];
+            for (size_t qi = 0; qi < num_queries; qi++) li[qi] = (idxs[qi] >> shift) >> o.log_e;
+            shift += o.log_e;
+            if ((rc = bj_memcpy_h2d(ctx, d_li.p, li.data(), num_queries * 8))) return rc;
+            const size_t E2 = (size_t)2 << o.log_e;
+            bj::launch_gather_fri_leaves(o.d_c0, o.d_c1, o.log_e, d_li.p, (unsigned)num_queries, d_fo.p, st);
+            bj::launch_merkle_paths(o.d_tree, o.num_leaves, fri_depth[i], d_li.p, (unsigned)num_queries,
+                                    d_fo.p + E2 * num_queries, st);
+            BJ_CHECK_LAUNCH(ctx);
+            fri_leaves[i].resize(E2 * num_queries);
+            fri_paths[i].resize((size_t)fri_depth[i] * 4 * num_queries + 1);
+            if ((rc = bj_memcpy_d2h(ctx, fri_leaves[i].data(), d_fo.p, E2 * num_queries * 8))) return rc;
+            if (fri_depth[i] &&
+                (rc = bj_memcpy_d2h(ctx, fri_paths[i].data(), d_fo.p + E2 * num_queries, (size_t)fri_depth[i] * 4 * num_queries * 8)))
+                return rc;
+        }
+    }
     // ---------------- serialise ----------------
     std::vector<u64> &D = proof->data;
     auto put = [&](const u64 *p, size_t k) { D.insert(D.end(), p, p + k); };
@@ -558,17 +595,10 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             put(gathered.data() + off + qi * (size_t)depth * 4, (size_t)depth * 4);
             off += (size_t)depth * 4 * num_queries;
         }
-        size_t f_idx = idxs[qi], ln = N;
         for (size_t i = 0; i < sched_len; i++) {
-            const unsigned k = sched[i];
-            const size_t E = (size_t)1 << k;
-            const unsigned fdepth = bj::log2_exact((ln >> k) / cap);
-            std::vector<u64> leaf(2 * E), path((size_t)(fdepth ? fdepth : 1) * 4);
-            if ((rc = bj_fri_query(ctx, fri_obj, i, f_idx, leaf.data(), path.data()))) return rc;
-            put(leaf.data(), leaf.size());
-            put(path.data(), (size_t)fdepth * 4);
-            f_idx >>= k;
-            ln >>= k;
+            const size_t E2 = (size_t)2 << sched[i];
+            put(fri_leaves[i].data() + qi * E2, E2);
+            put(fri_paths[i].data() + qi * (size_t)fri_depth[i] * 4, (size_t)fri_depth[i] * 4);
         }
     }
     proof->stage_ms[6] = timer.lap();

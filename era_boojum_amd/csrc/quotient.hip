@@ -335,4 +335,22 @@ void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, c
                        n_idx, d_out);
 }
 
+// FRI leaf = 2^k values of c0 then 2^k values of c1 at leaf index j (merkle_tree.rs:285-292)
+__global__ void gather_fri_leaves_kernel(const u64 *c0, const u64 *c1, unsigned log_e, const u64 *leaf_idx, unsigned n_idx,
+                                         u64 *out) {
+    const unsigned E = 1u << log_e;
+    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_idx * 2 * E) return;
+    unsigned qi = t / (2 * E), e = t % (2 * E);
+    const u64 *src = e < E ? c0 : c1;
+    out[t] = gl::canon(src[leaf_idx[qi] * E + (e & (E - 1))]);
+}
+void launch_gather_fri_leaves(const u64 *d_c0, const u64 *d_c1, unsigned log_e, const u64 *d_leaf_idx, unsigned n_idx,
+                              u64 *d_out, hipStream_t s) {
+    unsigned total = n_idx * (2u << log_e);
+    if (!total) return;
+    hipLaunchKernelGGL(gather_fri_leaves_kernel, dim3((total + 63) / 64), dim3(64), 0, s, d_c0, d_c1, log_e, d_leaf_idx,
+                       n_idx, d_out);
+}
+
 }  // namespace bj
