@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — headline measurement of the MI355X-native Boojum hot path.
+"""bench.py — headline measurement of the MI355X-native Boojum proving hot path.
 
-Workload at N = 1 (BASELINE.json configs[1], "cfg2"): forward Goldilocks NTT, n = 2^20, 256 columns, natural ->
-bit-reversed, LDE coset shift 7, u64 data resident in HBM when the timed region starts.  One "step" = one pass of the
-batched NTT over the 256 columns.  With N > 1 every rank transforms its own 256 columns (independent polynomial
-columns shard across GPUs with no data-path collective): weak scaling.
+Workload (BASELINE.json configs[2], "cfg3"): FULL PROVE of a SHA-256-shaped circuit with 2^20 rows on one MI355X —
+witness LDE + Poseidon2 Merkle tree, copy-permutation / lookup stage, quotient, openings, DEEP, FRI, queries — with the
+reference bench's parameters (60 + 32 variable columns, 8 x width-4 lookups, LDE 8, cap 16, security 100, PoW off,
+Poseidon2 tree hasher; src/gadgets/sha256/mod.rs:296-375).  The circuit is the SHA-shaped satisfiable synthetic circuit of
+era_boojum_amd/synthetic.py (real SHA-256 synthesis needs the reference's Rust CS); prover cost is
+data-independent.  One "step" = one proof; the witness is resident in HBM when the timed region starts (the span the
+reference times is `prove_cpu_basic` only, sha256/mod.rs:514-527), the serialised proof is on the host when it ends.
+`value` = constraints/sec := trace rows of ALL ranks / wall seconds.  With N > 1 every rank proves its own instance
+(replicas, no data-path collective): weak scaling.  (--log-n 22 runs BASELINE's 2^22-row size on one GPU.)
 
-Printed JSON (one line, rank 0): see the driver contract.  `value` = algorithmic bytes (16 B per element: 8 read +
-8 written) of ALL ranks / wall time of the timed region.  `roofline` prices the NTT kernels against the
-HBM roofline using the per-step GPU time measured with HIP events on the stream the kernels run on.
-`cpu_baseline` = the C oracle (restated reference CPU algorithm, one polynomial per thread like the reference's
-Worker policy) timed on this box's host cores on the same workload.
+Extra objects on the JSON line:
+  roofline      the dominant kernel of a proof, the Poseidon2 leaf hashing of the witness tree: algorithmic bytes
+                (8*W + 32 per leaf) / its duration measured with HIP events on the launch stream inside the
+                timed proofs.  It is integer-VALU-bound by construction (~472 field multiplications per 64 absorbed bytes).
+  ntt           BASELINE configs[1] ("cfg2"): 2^20 x 256-column forward NTT, algorithmic 16 B/element vs the HBM peak.
+  stages_ms     per-round wall time, named after the reference's log lines.
+  cpu_baseline  the C/Python oracle prover (restated reference CPU algorithm) on this box's host cores, on a smaller
+                instance of the same circuit (bounded to ~10-30 s), in rows/s.
 """
 import argparse
 import json
@@ -28,17 +36,21 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=20)
-    ap.add_argument("--cols", type=int, default=256)
-    ap.add_argument("--coset", type=int, default=7)
+    ap.add_argument("--fri-lde", type=int, default=8)
+    ap.add_argument("--cap", type=int, default=16)
+    ap.add_argument("--security", type=int, default=100)
+    ap.add_argument("--cpu-log-n", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import era_boojum_amd as E
+    from era_boojum_amd import synthetic as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -48,102 +60,125 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
-    log_n, n_cols = args.log_n, args.cols
-    n = 1 << log_n
-    dev = torch.device("cuda", local_rank)
-    # synthetic input: uniform u64 below p (seed per rank), resident in HBM
-    g = torch.Generator(device=dev)
-    g.manual_seed(20240807 + rank)
-    hi = torch.randint(0, 0xFFFFFFFF, (n_cols, n), dtype=torch.int64, device=dev, generator=g)
-    lo = torch.randint(0, 1 << 32, (n_cols, n), dtype=torch.int64, device=dev, generator=g)
-    src = (hi << 32) | lo          # hi < 2^32-1  =>  value < p
-    del hi, lo
-    dst = torch.empty_like(src)
-
-    ctx = E.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    def step():
-        ctx.ntt_forward_batch(src.data_ptr(), dst.data_ptr(), log_n, n_cols, coset=args.coset)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    log_n = args.log_n
+    n = 1 << log_n
+    table_bits = 4 if log_n >= 14 else 2
+    circuit = S.sha_shaped_circuit(log_n, seed=42 + rank, table_bits=table_bits)
+    ctx = E.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security)
+    # witness resident in HBM (torch owns the allocations)
+    d_vars = torch.from_numpy(circuit.variables.view(np.int64)).to(dev)
+    d_mult = torch.from_numpy(circuit.multiplicities.view(np.int64)).to(dev)
+
+    def step():
+        return setup.prove_dev(d_vars.data_ptr(), d_mult.data_ptr())
+
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    ctx.timer_start()
+    leaf_ms, stage_acc, proof_buf = [], {}, None
     for _ in range(args.steps):
-        step()
-    gpu_ms = ctx.timer_stop_ms()
+        proof_buf, stages = step()
+        if os.environ.get('BJ_BENCH_DEBUG'):
+            print({k: round(v, 1) for k, v in stages.items()}, file=sys.stderr)
+        leaf_ms.append(stages.pop("witness_tree_leaf_kernel"))
+        for k, v in stages.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed, gpu_ms], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, gpu_ms = float(tt[0]), float(tt[1])
+        elapsed = float(tt[0])
 
-    bytes_per_step_per_gpu = 16.0 * n * n_cols
-    total_bytes = bytes_per_step_per_gpu * world * args.steps
-    value = total_bytes / elapsed / 1e9
-    kern_s = gpu_ms / 1e3 / args.steps
-    achieved = bytes_per_step_per_gpu / kern_s / 1e9
-
+    rows_total = float(n) * world * args.steps
+    value = rows_total / elapsed
+    W = circuit.num_vars + 1                                  # witness leaf width (variables + multiplicities)
+    leaves = n * args.fri_lde
+    leaf_bytes = float(leaves) * (8 * W + 32)
+    leaf_s = float(np.mean(leaf_ms)) / 1e3
+    achieved = leaf_bytes / leaf_s / 1e9
     out = {
-        "metric": "goldilocks_ntt_algorithmic_throughput",
-        "value": round(value, 2),
-        "unit": "GB/s",
+        "metric": "prover_constraints_per_sec",
+        "value": round(value, 1),
+        "unit": "rows/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": "cfg2: forward Goldilocks NTT 2^%d x %d columns per GPU, natural->bit-reversed, coset %d"
-                               % (log_n, n_cols, args.coset),
-                   "log_n": log_n, "columns_per_gpu": n_cols, "sharding": "independent columns per rank, no collective"},
+        "config": {"workload": "cfg3: full prove of a SHA-256-shaped circuit, 2^%d rows per GPU (92 variable + 1 multiplicity "
+                               "columns, 8x4 lookups, LDE %d, cap %d, security %d, Poseidon2 tree + transcript, PoW off)"
+                               % (log_n, args.fri_lde, args.cap, args.security),
+                   "log_n": log_n, "rows_per_gpu": n, "circuit": "SHA-shaped satisfiable synthetic (seed 42+rank)",
+                   "sharding": "one independent proof per rank (replicas), no data-path collective",
+                   "proof_bytes": int(proof_buf.size * 8)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "kernel": "NTT batch = all pass kernels of one step (HIP events on the launch stream)",
-                     "gpu_ms_per_step": round(kern_s * 1e3, 4),
-                     "algorithmic_bytes_per_step": bytes_per_step_per_gpu},
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "kernel": "bj::poseidon2_leaves_kernel (witness tree: 2^%d leaves x %d elements)" % (log_n + args.fri_lde.bit_length() - 1, W),
+                     "kernel_ms": round(leaf_s * 1e3, 3), "algorithmic_bytes_per_launch": leaf_bytes,
+                     "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},
+        "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},
     }
 
+    # ---- secondary leg: cfg2 NTT (2^20 x 256 columns), the "NTT GB/s vs HBM peak" half of the metric
+    if not args.no_ntt:
+        nlog, ncols = 20, 256
+        src = torch.randint(0, 1 << 62, (ncols, 1 << nlog), dtype=torch.int64, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            ctx.ntt_forward_batch(src.data_ptr(), dst.data_ptr(), nlog, ncols, coset=7)
+        reps = 10
+        ctx.timer_start()
+        for _ in range(reps):
+            ctx.ntt_forward_batch(src.data_ptr(), dst.data_ptr(), nlog, ncols, coset=7)
+        ms = ctx.timer_stop_ms() / reps
+        nb = 16.0 * (1 << nlog) * ncols
+        out["ntt"] = {"workload": "cfg2: forward NTT 2^20 x 256 columns, natural->bit-reversed, coset 7", "ms": round(ms, 4),
+                      "achieved": round(nb / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": round(nb / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nb,
+                      "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
+        del src, dst
+
     if rank == 0 and not args.no_cpu_baseline:
-        import oracle as O
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        from era_boojum_amd import proof_format
+        from oracle import prover as OP
+        from oracle import verifier as OV
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         threads = min(threads, 64)
-        host = src[: min(n_cols, 4 * threads)].cpu().numpy().view(np.uint64)
-        # parity spot check of what was just timed (2 columns), then the timed CPU leg
-        got = dst[:2].cpu().numpy().view(np.uint64)
-        want = O.fft_batch(host[:2], args.coset, threads=2)
-        if not np.array_equal(got, want):
-            raise SystemExit("parity failure: HIP NTT differs from the oracle")
-        reps, t_cpu = 0, 0.0
+        # parity spot check of what was just timed: the oracle's verifier restatement must accept the timed proof
+        pg = proof_format.parse(proof_buf, security_level=args.security)
+        if not OV.verify(OV.VerificationKey(circuit, setup.cap(), args.fri_lde, args.cap), pg):
+            raise SystemExit("parity failure: the verifier restatement rejects the HIP proof")
+        csmall = S.sha_shaped_circuit(args.cpu_log_n, seed=42, table_bits=4 if args.cpu_log_n >= 14 else 2)
+        osetup = OP.Setup(csmall, args.fri_lde, args.cap, threads=threads)
         c0 = time.perf_counter()
-        while t_cpu < 10.0 and reps < 50:
-            O.fft_batch(host, args.coset, threads=threads)
-            reps += 1
-            t_cpu = time.perf_counter() - c0
-        cpu_gbps = 16.0 * n * host.shape[0] * reps / t_cpu / 1e9
-        out["cpu_baseline"] = {"value": round(cpu_gbps, 3), "unit": "GB/s", "cores": threads, "kind": "port",
-                               "sample": "%d columns of 2^%d x %d repetitions, one polynomial per thread (C oracle, "
-                                         "-O3 -march=x86-64-v3, OpenMP)" % (host.shape[0], log_n, reps)}
+        OP.prove(csmall, osetup, args.fri_lde, args.cap, security_level=args.security, threads=threads)
+        t_cpu = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": round((1 << args.cpu_log_n) / t_cpu, 1), "unit": "rows/s", "cores": threads, "kind": "port",
+                               "sample": "one proof of the same SHA-shaped circuit at 2^%d rows by the oracle prover (C bulk ops "
+                                         "+ python orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (args.cpu_log_n, t_cpu)}
     if rank == 0:
         print(json.dumps(out))
+    setup.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -471,7 +471,9 @@ class ProverSetup:
         ms = (C.c_float * 8)()
         self._lib.bj_proof_stage_ms(h, ms)
         self._lib.bj_proof_destroy(h)
-        return buf, dict(zip(STAGE_NAMES, [float(x) for x in ms][:7]))
+        stages = dict(zip(STAGE_NAMES, [float(x) for x in ms][:7]))
+        stages["witness_tree_leaf_kernel"] = float(ms[7])
+        return buf, stages
 
     def prove(self, variables=None, multiplicities=None, public_values=None):
         """Host-memory entry point (bj_prove): returns (serialised proof u64 array, per-stage ms)."""

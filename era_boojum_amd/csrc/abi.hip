@@ -62,6 +62,27 @@ int ensure_scratch(bj_ctx *ctx, size_t elems) {
     return BJ_OK;
 }
 
+int arena_reset(bj_ctx *ctx, size_t need_elems) {
+    ctx->arena_off = 0;
+    if (need_elems <= ctx->arena_elems) return BJ_OK;
+    if (ctx->arena) {
+        BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        BJ_HIP(ctx, hipFree(ctx->arena));
+        ctx->arena = nullptr;
+        ctx->arena_elems = 0;
+    }
+    BJ_HIP(ctx, hipMalloc((void **)&ctx->arena, need_elems * sizeof(u64)));
+    ctx->arena_elems = need_elems;
+    return BJ_OK;
+}
+
+u64 *arena_alloc(bj_ctx *ctx, size_t elems) {
+    size_t start = (ctx->arena_off + 63) & ~(size_t)63;   // 512-byte alignment
+    if (start + elems > ctx->arena_elems) return nullptr;
+    ctx->arena_off = start + elems;
+    return ctx->arena + start;
+}
+
 }  // namespace bj
 
 using bj::bind;
@@ -120,6 +141,7 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_ptrs) (void)hipFree((void *)ctx->d_ptrs);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -21,6 +21,10 @@ struct bj_ctx {
     gl::u64 *d_scratch = nullptr;  // big scratch for out-of-place steps
     size_t scratch_elems = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // bump-allocated workspace reused across proofs (hipMalloc/hipFree of multi-GB buffers per proof is slow and
+    // synchronising); grown on demand, reset at the start of every bj_prove_dev
+    gl::u64 *arena = nullptr;
+    size_t arena_elems = 0, arena_off = 0;
 };
 
 namespace bj {
@@ -28,6 +32,8 @@ int fail(bj_ctx *ctx, int code, const char *fmt, ...);
 int bind(bj_ctx *ctx);
 int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
+int arena_reset(bj_ctx *ctx, size_t need_elems);
+gl::u64 *arena_alloc(bj_ctx *ctx, size_t elems);   // nullptr if the reservation was too small
 int lde_cosets_strided(bj_ctx *ctx, const gl::u64 *d_mono, size_t in_col_stride, gl::u64 *d_out, size_t out_col_stride,
                        unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count);
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }

@@ -83,6 +83,16 @@ struct DevBuf {
     }
 };
 
+// workspace buffer carved out of the context's arena (no hipMalloc/hipFree inside a proof)
+struct ArenaBuf {
+    u64 *p = nullptr;
+    int alloc(bj_ctx *ctx, size_t elems) {
+        p = bj::arena_alloc(ctx, elems ? elems : 1);
+        if (!p) return bj::fail(ctx, BJ_ERR_OOM, "workspace reservation too small for %zu MiB", elems * 8 >> 20);
+        return BJ_OK;
+    }
+};
+
 gl::e2 e2c(const u64 *p) { return {gl::canon(p[0]), gl::canon(p[1])}; }
 
 struct StageTimer {
@@ -244,6 +254,15 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             }
         }
     } guard{proof};
+    {   // one reservation for every buffer below (sizes mirror the allocations; +1 MiB slack per buffer for alignment)
+        const size_t tree_elems = bj_merkle_tree_digests(N, cap) * 4, slack = (size_t)1 << 17;
+        size_t need = (size_t)nW * Ln + (size_t)(nW > nS2 ? nW : nS2) * n + tree_elems            // wit_lde, mono, wit_tree
+                    + (size_t)nS2 * n + ((size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16)   // s2_nat, tmp
+                    + (size_t)nS2 * Ln + tree_elems                                                // s2_lde, s2_tree
+                    + 2 * Q + (size_t)2 * q * N + tree_elems + 2 * n + 2 * N                       // T, q_lde, q_tree, w, deep
+                    + (size_t)4096 * 1024 + 24 * slack;                                            // alphas, query gathers
+        if ((rc = bj::arena_reset(ctx, need))) return rc;
+    }
     StageTimer timer(st);
     bj::host::Transcript tr;
     tr.absorb(S->cap.data(), S->cap.size());                               // prover.rs:211
@@ -255,7 +274,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = bj::ensure_twiddles(ctx, log_n + (L > fri ? bj::log2_exact(L) : S->log_fri), false))) return rc;
 
     // ---------------- round 1: witness LDE + tree (prover.rs:270-353) ----------------
-    DevBuf wit_lde, wit_tree, mono;
+    ArenaBuf wit_lde, wit_tree, mono;
     if ((rc = wit_lde.alloc(ctx, (size_t)nW * Ln))) return rc;
     if ((rc = mono.alloc(ctx, (size_t)(nW > nS2 ? nW : nS2) * n))) return rc;
     rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
@@ -263,10 +282,16 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if (!rc) rc = bj_lde_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L);
     if (rc) return rc;
     if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
-    rc = bj_merkle_tree_build(ctx, wit_lde.p, Ln, nW, N, cap, wit_tree.p);
+    // witness tree; the leaf kernel (the dominant kernel of a proof) is bracketed by HIP events on the launch stream
+    BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
+    bj::launch_poseidon2_leaves(wit_lde.p, Ln, nullptr, nW, N, wit_tree.p, st);
+    BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
+    bj::launch_poseidon2_node_layers(wit_tree.p, N, cap, st);
+    BJ_CHECK_LAUNCH(ctx);
     std::vector<u64> wit_cap(4 * cap), s2_cap(4 * cap), q_cap(4 * cap);
-    if (!rc) rc = bj_merkle_tree_cap(ctx, wit_tree.p, N, cap, wit_cap.data());
+    rc = bj_merkle_tree_cap(ctx, wit_tree.p, N, cap, wit_cap.data());
     if (rc) return rc;
+    BJ_HIP(ctx, hipEventElapsedTime(&proof->stage_ms[7], ctx->ev0, ctx->ev1));
     tr.absorb(wit_cap.data(), wit_cap.size());
     proof->stage_ms[0] = timer.lap();
 
@@ -274,7 +299,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     u64 beta[2], gamma[2], lbeta[2] = {0, 0}, lgamma[2] = {0, 0};
     challenge2(beta);
     challenge2(gamma);
-    DevBuf s2_nat, s2_lde, s2_tree, tmp;
+    ArenaBuf s2_nat, s2_lde, s2_tree, tmp;
     if ((rc = s2_nat.alloc(ctx, (size_t)nS2 * n))) return rc;
     if ((rc = tmp.alloc(ctx, (size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16))) return rc;
     const u64 *d_sig_nat = S->d_nat, *d_con_nat = S->d_nat + (size_t)V * n, *d_tab_nat = S->d_nat + (size_t)(V + nC) * n;
@@ -315,7 +340,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             cur = gl::e2_mul(cur, a);
         }
     }
-    DevBuf d_alphas, T;
+    ArenaBuf d_alphas, T;
     if ((rc = d_alphas.alloc(ctx, alphas.size()))) return rc;
     if ((rc = bj_memcpy_h2d(ctx, d_alphas.p, alphas.data(), alphas.size() * 8))) return rc;
     if ((rc = T.alloc(ctx, 2 * Q))) return rc;
@@ -341,7 +366,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if (rc) return rc;
     if (top[0] != 0 || top[1] != 0)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: constraint system is not satisfied (quotient is not a polynomial; prover.rs:1425-1438)");
-    DevBuf q_lde, q_tree;
+    ArenaBuf q_lde, q_tree;
     if ((rc = q_lde.alloc(ctx, (size_t)2 * q * N))) return rc;
     for (unsigned e = 0; e < 2 && !rc; e++)   // chunk j of c_e -> column 2j+e (prover.rs:1445-1467)
         rc = bj::lde_cosets_strided(ctx, T.p + (size_t)e * Q, n, q_lde.p + (size_t)e * N, 2 * N, log_n, q, S->log_fri, 0, fri);
@@ -356,7 +381,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     // ---------------- round 4: openings (prover.rs:1501-1802) ----------------
     u64 z[2];
     challenge2(z);
-    DevBuf w;
+    ArenaBuf w;
     if ((rc = w.alloc(ctx, 2 * n))) return rc;
     // base columns whose coset 0 is evaluated, in the order of prover.rs:1550-1683; F_p^2 polys contribute two columns
     struct Src { const u64 *c0, *c1; };
@@ -449,7 +474,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             cur = gl::e2_mul(cur, c);
         }
     }
-    DevBuf deep;
+    ArenaBuf deep;
     if ((rc = deep.alloc(ctx, 2 * N))) return rc;
     size_t choff = 0;
     auto deep_call = [&](const std::vector<Src> &ss, const u64 *vals, const u64 *at, int accumulate) -> int {
@@ -509,7 +534,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     const u64 *bases[4] = {wit_lde.p, s2_lde.p, q_lde.p, S->d_lde};
     const size_t strides[4] = {Ln, Ln, N, Ln};
     const u64 *trees[4] = {wit_tree.p, s2_tree.p, q_tree.p, S->d_tree};
-    DevBuf d_idx, d_g;
+    ArenaBuf d_idx, d_g;
     size_t per_query = 0;
     for (int o = 0; o < 4; o++) per_query += widths[o] + (size_t)depth * 4;
     if ((rc = d_idx.alloc(ctx, num_queries))) return rc;
@@ -531,7 +556,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     std::vector<std::vector<u64>> fri_leaves(sched_len), fri_paths(sched_len);
     std::vector<unsigned> fri_depth(sched_len);
     {
-        DevBuf d_li, d_fo;
+        ArenaBuf d_li, d_fo;
         if ((rc = d_li.alloc(ctx, num_queries))) return rc;
         size_t max_out = 0;
         for (size_t i = 0; i < sched_len; i++) {

@@ -292,7 +292,8 @@ void bj_proof_destroy(bj_proof *p);
 size_t bj_proof_size_u64(const bj_proof *p);
 int bj_proof_serialize(const bj_proof *p, uint64_t *out);
 /* wall-clock per stage in ms, named after the reference's log lines: [0] witness LDE + tree, [1] second stage,
- * [2] quotient work and LDE + tree, [3] openings at z, [4] batched FRI opening computation (DEEP), [5] FRI, [6] queries */
+ * [2] quotient work and LDE + tree, [3] openings at z, [4] batched FRI opening computation (DEEP), [5] FRI, [6] queries;
+ * [7] = duration of the witness-tree Poseidon2 leaf kernel alone, measured with HIP events on the launch stream */
 int bj_proof_stage_ms(const bj_proof *p, float *out8);
 
 #ifdef __cplusplus
