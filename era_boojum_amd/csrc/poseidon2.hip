@@ -23,58 +23,164 @@ namespace bj {
 
 __constant__ u64 POSEIDON_RC[BJ_POSEIDON_NUM_RC] = BJ_POSEIDON_RC_TABLE;
 
-__device__ __forceinline__ u64 pow7(u64 x) {
-    u64 x2 = gl::sqr(x), x3 = gl::mul(x2, x), x4 = gl::sqr(x2);
-    return gl::mul(x4, x3);
+// ---------------------------------------------------------------------------------------------------------
+// Arithmetic inside the permutation is LAZY: state words are "weak" residues (any u64 congruent to the value, not
+// necessarily < p) and the linear layers accumulate in 96-bit integers (three 32-bit words) that are folded back with
+// 2^64 = 2^32 - 1 only once per output.  Every step is exact mod p, so the canonicalised digest equals the reference's;
+// it removes ~18 % of the VALU instructions of the canonical formulation (the kernel is VALU-bound).
+// Invariants (proved in the comments below): a weak value is < 2^64; a correction "+EPS on carry" never carries twice.
+// ---------------------------------------------------------------------------------------------------------
+struct W3 {
+    u32 w0, w1, w2;
+};
+__device__ __forceinline__ W3 w3_from(u64 a) { return {gl::lo32(a), gl::hi32(a), 0u}; }
+__device__ __forceinline__ W3 w3_add(W3 a, W3 b) {
+    u32 c, d;
+    W3 r;
+    r.w0 = __builtin_addc(a.w0, b.w0, 0u, &c);
+    r.w1 = __builtin_addc(a.w1, b.w1, c, &c);
+    r.w2 = __builtin_addc(a.w2, b.w2, c, &d);
+    return r;
+}
+__device__ __forceinline__ W3 w3_add64(W3 a, u64 b) {
+    u32 c, d;
+    W3 r;
+    r.w0 = __builtin_addc(a.w0, gl::lo32(b), 0u, &c);
+    r.w1 = __builtin_addc(a.w1, gl::hi32(b), c, &c);
+    r.w2 = __builtin_addc(a.w2, 0u, c, &d);
+    return r;
+}
+__device__ __forceinline__ W3 w3_sum64(u64 a, u64 b) {   // a + b as a 65-bit integer
+    u32 c, d;
+    W3 r;
+    r.w0 = __builtin_addc(gl::lo32(a), gl::lo32(b), 0u, &c);
+    r.w1 = __builtin_addc(gl::hi32(a), gl::hi32(b), c, &c);
+    r.w2 = __builtin_addc(0u, 0u, c, &d);
+    return r;
+}
+template <unsigned K>
+__device__ __forceinline__ W3 w3_shl(W3 a) {   // a * 2^K, 0 < K < 32; the caller guarantees no overflow of 96 bits
+    return {a.w0 << K, __builtin_amdgcn_alignbit(a.w1, a.w0, 32 - K), __builtin_amdgcn_alignbit(a.w2, a.w1, 32 - K)};
+}
+template <unsigned K>
+__device__ __forceinline__ W3 w3_shl64(u64 a) {   // a * 2^K as a 96-bit integer, 0 < K < 32
+    const u32 lo = gl::lo32(a), hi = gl::hi32(a);
+    return {lo << K, __builtin_amdgcn_alignbit(hi, lo, 32 - K), hi >> (32 - K)};
+}
+// 96-bit integer with w2 < 2^31 -> weak residue:  (w1:w0) + w2 * (2^32 - 1), "+EPS" once on carry.
+// No second carry: after a wrap the sum is < w2 * 2^32 <= 2^63, far below 2^64 - EPS.
+__device__ __forceinline__ u64 w3_reduce(W3 a) {
+    u32 b5, b6, c1, c2, c3, c4;
+    u32 m0 = __builtin_subc(0u, a.w2, 0u, &b5);          // w2 * (2^32 - 1) = (w2 << 32) - w2
+    u32 m1 = __builtin_subc(a.w2, 0u, b5, &b6);
+    u32 r0 = __builtin_addc(a.w0, m0, 0u, &c1);
+    u32 r1 = __builtin_addc(a.w1, m1, c1, &c2);
+    u32 e = c2 ? 0xFFFFFFFFu : 0u;
+    r0 = __builtin_addc(r0, e, 0u, &c3);
+    r1 = __builtin_addc(r1, 0u, c3, &c4);
+    return gl::pack(r0, r1);
+}
+// weak x weak -> weak (same limbs as gl::mul, reduction without the final canonicalisation)
+//   t0 = lo - hi_hi, "-EPS" on borrow (then t0 >= 2^64 - 2^32 > EPS, no second borrow)
+//   t1 = hi_lo * EPS <= (2^32-1)^2;  r = t0 + t1, "+EPS" on carry (then r < 2^64 - 2^33, no second carry)
+__device__ __forceinline__ u64 mulw(u64 a, u64 b) {
+    u32 hh, hl;
+    u64 lo;
+    gl::mul_limbs(a, b, hh, hl, lo);
+    u32 b1, b2, b3, b4, b5, b6, c1, c2, c3, c4;
+    u32 d0 = __builtin_subc(gl::lo32(lo), hh, 0u, &b1);
+    u32 d1 = __builtin_subc(gl::hi32(lo), 0u, b1, &b2);
+    u32 e = b2 ? 0xFFFFFFFFu : 0u;
+    d0 = __builtin_subc(d0, e, 0u, &b3);
+    d1 = __builtin_subc(d1, 0u, b3, &b4);
+    u32 m0 = __builtin_subc(0u, hl, 0u, &b5);
+    u32 m1 = __builtin_subc(hl, 0u, b5, &b6);
+    u32 r0 = __builtin_addc(d0, m0, 0u, &c1);
+    u32 r1 = __builtin_addc(d1, m1, c1, &c2);
+    u32 f = c2 ? 0xFFFFFFFFu : 0u;
+    r0 = __builtin_addc(r0, f, 0u, &c3);
+    r1 = __builtin_addc(r1, 0u, c3, &c4);
+    return gl::pack(r0, r1);
+}
+// weak + canonical constant -> weak: "+EPS" on carry; the wrapped sum is < rc < p, so adding EPS cannot carry again
+__device__ __forceinline__ u64 addw_rc(u64 x, u64 rc) {
+    u32 c1, c2, c3, c4;
+    u32 s0 = __builtin_addc(gl::lo32(x), gl::lo32(rc), 0u, &c1);
+    u32 s1 = __builtin_addc(gl::hi32(x), gl::hi32(rc), c1, &c2);
+    u32 e = c2 ? 0xFFFFFFFFu : 0u;
+    s0 = __builtin_addc(s0, e, 0u, &c3);
+    s1 = __builtin_addc(s1, 0u, c3, &c4);
+    return gl::pack(s0, s1);
+}
+__device__ __forceinline__ u64 pow7w(u64 x) {
+    u64 x2 = mulw(x, x), x3 = mulw(x2, x), x4 = mulw(x2, x2);
+    return mulw(x4, x3);
 }
 
-// M4 block: [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
-__device__ __forceinline__ void m4(u64 &x0, u64 &x1, u64 &x2, u64 &x3) {
-    u64 t0 = gl::add(x0, x1), t1 = gl::add(x2, x3);
-    u64 t2 = gl::add(gl::dbl(x1), t1), t3 = gl::add(gl::dbl(x3), t0);
-    u64 t4 = gl::add(gl::dbl(gl::dbl(t1)), t3), t5 = gl::add(gl::dbl(gl::dbl(t0)), t2);
-    x0 = gl::add(t3, t5);
-    x1 = t5;
-    x2 = gl::add(t2, t4);
-    x3 = t4;
+// M4 block [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] on 64-bit inputs, 96-bit outputs (row sums <= 16 -> < 2^68)
+__device__ __forceinline__ void m4w(u64 x0, u64 x1, u64 x2, u64 x3, W3 &y0, W3 &y1, W3 &y2, W3 &y3) {
+    W3 t0 = w3_sum64(x0, x1), t1 = w3_sum64(x2, x3);
+    W3 t2 = w3_add(w3_shl64<1>(x1), t1), t3 = w3_add(w3_shl64<1>(x3), t0);
+    W3 t4 = w3_add(w3_shl<2>(t1), t3), t5 = w3_add(w3_shl<2>(t0), t2);
+    y0 = w3_add(t3, t5);
+    y1 = t5;
+    y2 = w3_add(t2, t4);
+    y3 = t4;
 }
-
+// external matrix circ(2*M4, M4, M4): out[4b+j] = y_b[j] + sum_b' y_b'[j]; coefficients sum to <= 64 -> < 2^70
 __device__ __forceinline__ void ext_mds(u64 (&s)[12]) {
-    m4(s[0], s[1], s[2], s[3]);
-    m4(s[4], s[5], s[6], s[7]);
-    m4(s[8], s[9], s[10], s[11]);
+    W3 y[12];
+    m4w(s[0], s[1], s[2], s[3], y[0], y[1], y[2], y[3]);
+    m4w(s[4], s[5], s[6], s[7], y[4], y[5], y[6], y[7]);
+    m4w(s[8], s[9], s[10], s[11], y[8], y[9], y[10], y[11]);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        u64 sum = gl::add(gl::add(s[j], s[4 + j]), s[8 + j]);
-        s[j] = gl::add(s[j], sum);
-        s[4 + j] = gl::add(s[4 + j], sum);
-        s[8 + j] = gl::add(s[8 + j], sum);
+        W3 sum = w3_add(w3_add(y[j], y[4 + j]), y[8 + j]);
+        s[j] = w3_reduce(w3_add(y[j], sum));
+        s[4 + j] = w3_reduce(w3_add(y[4 + j], sum));
+        s[8 + j] = w3_reduce(w3_add(y[8 + j], sum));
     }
 }
 
+template <unsigned K>
+__device__ __forceinline__ u64 shl_plus(u64 a, W3 sum) {   // a * 2^K + sum  (< 2^64 * (2^14 + 12))
+    return w3_reduce(w3_add(w3_shl64<K>(a), sum));
+}
+
+// state in: any u64 words; state out: weak words (canonicalise what leaves the sponge with gl::canon)
 __device__ __forceinline__ void poseidon2_permutation(u64 (&s)[12]) {
-    constexpr unsigned SH[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
     ext_mds(s);
     int r = 0;
 #pragma unroll 1
     for (int i = 0; i < 4; i++, r++) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) s[k] = pow7(gl::add(s[k], POSEIDON_RC[12 * r + k]));
+        for (int k = 0; k < 12; k++) s[k] = pow7w(addw_rc(s[k], POSEIDON_RC[12 * r + k]));
         ext_mds(s);
     }
 #pragma unroll 1
     for (int i = 0; i < 22; i++, r++) {
-        s[0] = pow7(gl::add(s[0], POSEIDON_RC[12 * r]));
-        u64 sum = s[0];
+        s[0] = pow7w(addw_rc(s[0], POSEIDON_RC[12 * r]));
+        W3 sum = w3_sum64(s[0], s[1]);
 #pragma unroll
-        for (int k = 1; k < 12; k++) sum = gl::add(sum, s[k]);
-#pragma unroll
-        for (int k = 0; k < 12; k++) s[k] = gl::add(gl::mul_pow2(s[k], SH[k]), sum);
+        for (int k = 2; k < 12; k++) sum = w3_add64(sum, s[k]);
+        // internal matrix 1 + diag(2^{4,14,11,8,0,5,2,9,13,6,3,12})  (poseidon2/params.rs:38-39)
+        s[0] = shl_plus<4>(s[0], sum);
+        s[1] = shl_plus<14>(s[1], sum);
+        s[2] = shl_plus<11>(s[2], sum);
+        s[3] = shl_plus<8>(s[3], sum);
+        s[4] = w3_reduce(w3_add64(sum, s[4]));
+        s[5] = shl_plus<5>(s[5], sum);
+        s[6] = shl_plus<2>(s[6], sum);
+        s[7] = shl_plus<9>(s[7], sum);
+        s[8] = shl_plus<13>(s[8], sum);
+        s[9] = shl_plus<6>(s[9], sum);
+        s[10] = shl_plus<3>(s[10], sum);
+        s[11] = shl_plus<12>(s[11], sum);
     }
 #pragma unroll 1
     for (int i = 0; i < 4; i++, r++) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) s[k] = pow7(gl::add(s[k], POSEIDON_RC[12 * r + k]));
+        for (int k = 0; k < 12; k++) s[k] = pow7w(addw_rc(s[k], POSEIDON_RC[12 * r + k]));
         ext_mds(s);
     }
 }
@@ -96,7 +202,7 @@ poseidon2_leaves_kernel(const u64 *base, size_t col_stride, const u64 *const *co
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const u64 *p = col_ptrs ? col_ptrs[c + k] : base + (size_t)(c + k) * col_stride;
-            s[k] = gl::canon(p[I]);
+            s[k] = p[I];
         }
         poseidon2_permutation(s);
     }
@@ -106,7 +212,7 @@ poseidon2_leaves_kernel(const u64 *base, size_t col_stride, const u64 *const *co
         for (int k = 0; k < 8; k++) {
             if ((unsigned)k < rem) {
                 const u64 *p = col_ptrs ? col_ptrs[c + k] : base + (size_t)(c + k) * col_stride;
-                s[k] = gl::canon(p[I]);
+                s[k] = p[I];
             } else {
                 s[k] = 0;
             }
@@ -115,8 +221,8 @@ poseidon2_leaves_kernel(const u64 *base, size_t col_stride, const u64 *const *co
     }
     // digest = state[0..4]; 32 B per lane
     ulonglong2 *d = reinterpret_cast<ulonglong2 *>(digests + 4 * I);
-    d[0] = make_ulonglong2(s[0], s[1]);
-    d[1] = make_ulonglong2(s[2], s[3]);
+    d[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+    d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
 // leaf j = sponge( src0[jE..(j+1)E) || src1[jE..(j+1)E) || ... )           (merkle_tree.rs:176-386, FRI oracles)
@@ -134,7 +240,7 @@ poseidon2_leaves_chunked_kernel(const u64 *src0, const u64 *src1, unsigned n_src
     for (unsigned t = 0; t < total; t++) {
         unsigned src = t >> log_e, off = t & (E - 1);
         const u64 *p = src == 0 ? src0 : src1;
-        u64 v = gl::canon(p[j * E + off]);
+        u64 v = p[j * E + off];
         // filled is wave-uniform; write through a switch to keep the state in registers
         switch (filled) {
             case 0: s[0] = v; break;
@@ -164,8 +270,8 @@ poseidon2_leaves_chunked_kernel(const u64 *src0, const u64 *src1, unsigned n_src
         poseidon2_permutation(s);
     }
     ulonglong2 *d = reinterpret_cast<ulonglong2 *>(digests + 4 * j);
-    d[0] = make_ulonglong2(s[0], s[1]);
-    d[1] = make_ulonglong2(s[2], s[3]);
+    d[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+    d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
 // node layer: parent i = perm(left || right || 0000)[0..4]                 (oracle/mod.rs:162-168)
@@ -174,12 +280,11 @@ __global__ void __launch_bounds__(256) poseidon2_nodes_kernel(const u64 *childre
     if (i >= num_parents) return;
     const ulonglong2 *c = reinterpret_cast<const ulonglong2 *>(children + 8 * i);
     ulonglong2 a = c[0], b = c[1], e = c[2], f = c[3];
-    u64 s[12] = {gl::canon(a.x), gl::canon(a.y), gl::canon(b.x), gl::canon(b.y),
-                 gl::canon(e.x), gl::canon(e.y), gl::canon(f.x), gl::canon(f.y), 0, 0, 0, 0};
+    u64 s[12] = {a.x, a.y, b.x, b.y, e.x, e.y, f.x, f.y, 0, 0, 0, 0};
     poseidon2_permutation(s);
     ulonglong2 *d = reinterpret_cast<ulonglong2 *>(parents + 4 * i);
-    d[0] = make_ulonglong2(s[0], s[1]);
-    d[1] = make_ulonglong2(s[2], s[3]);
+    d[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+    d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
 __global__ void poseidon2_permute_states_kernel(u64 *states, size_t n_states) {
@@ -187,10 +292,10 @@ __global__ void poseidon2_permute_states_kernel(u64 *states, size_t n_states) {
     if (i >= n_states) return;
     u64 s[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = gl::canon(states[12 * i + k]);
+    for (int k = 0; k < 12; k++) s[k] = states[12 * i + k];
     poseidon2_permutation(s);
 #pragma unroll
-    for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
+    for (int k = 0; k < 12; k++) states[12 * i + k] = gl::canon(s[k]);
 }
 
 void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,

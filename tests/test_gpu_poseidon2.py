@@ -20,6 +20,27 @@ def test_permutation_matches_oracle():
     d.free()
 
 
+def test_permutation_on_extreme_words():
+    """The device permutation works on non-canonical ("weak") words with single-step carry corrections; drive it with
+    every combination-rich pattern of boundary values so a missed double carry/borrow would show."""
+    P = O.P
+    specials = [0, 1, 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - 2, P - 1, P, P + 1, (1 << 64) - (1 << 32), (1 << 64) - 2,
+                (1 << 64) - 1, (1 << 63), (1 << 63) - 1, 0xFFFFFFFF00000000, 0x00000000FFFFFFFF, 0xFFFFFFFEFFFFFFFF]
+    rng = np.random.default_rng(77)
+    st = np.zeros((4096, 12), dtype=np.uint64)
+    for i in range(st.shape[0]):
+        for k in range(12):
+            st[i, k] = specials[int(rng.integers(0, len(specials)))] if rng.random() < 0.8 else int(rng.integers(0, 1 << 63)) * 2 + 1
+    st[0] = (1 << 64) - 1
+    st[1] = P - 1
+    st[2] = P
+    want = np.stack([O.poseidon2_permutation(s) for s in st])
+    d = DevBuf(st)
+    ctx().poseidon2_permute(d.ptr, st.shape[0])
+    assert np.array_equal(d.get(st.shape), want)
+    d.free()
+
+
 @pytest.mark.parametrize("n_cols", [1, 4, 7, 8, 9, 16, 17, 58, 93])
 def test_tree_matches_oracle(n_cols):
     num_leaves, cap = 1 << 10, 16
