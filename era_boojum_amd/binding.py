@@ -22,6 +22,7 @@ _SIGNATURES = {
     "bj_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bj_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_timer_start": (C.c_int, [C.c_void_p]),
     "bj_timer_stop_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "bj_ntt_forward_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t, C.c_uint64]),
@@ -47,6 +48,8 @@ _SIGNATURES = {
     "bj_deep_quotient_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]),
     "bj_setup_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_setup_create_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_void_p)]),
     "bj_setup_destroy": (None, [C.c_void_p]),
     "bj_setup_cap": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -118,6 +121,7 @@ class Context:
 
     def __init__(self, device=0, stream=None):
         self._lib = load_library()
+        self.device = int(device)
         h = C.c_void_p()
         rc = self._lib.bj_ctx_create(int(device), C.byref(h))
         if rc != 0:
@@ -418,11 +422,74 @@ STAGE_NAMES = ["witness_lde_and_tree", "second_stage", "quotient_work_and_lde", 
                "batched_fri_opening_computation", "fri", "queries"]
 
 
-class ProverSetup:
-    """Device-resident setup for a circuit of era_boojum_amd.synthetic.Circuit shape (bj_setup_create)."""
+_ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
 
-    def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0):
+
+class _Comm(C.Structure):  # bj_comm
+    _fields_ = [("rank", C.c_uint), ("world", C.c_uint), ("all_gather", _ALL_GATHER_FN), ("user", C.c_void_p)]
+
+
+class TorchComm:
+    """bj_comm over torch.distributed: the all-gather the sharded prover asks the host for.
+
+    The library hands over raw device pointers; they are copied (device to device) through torch-owned staging tensors
+    so that the collective itself is torch.distributed's: backend nccl (= RCCL over xGMI) runs on the staging tensors
+    directly, backend gloo (CPU tests, or several ranks sharing one GPU) bounces through host memory."""
+
+    def __init__(self, ctx, group=None):
+        import torch
+        import torch.distributed as dist
+        self._ctx, self._torch, self._dist, self._group = ctx, torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._device = torch.device("cuda", ctx.device)
+        self._on_device = dist.get_backend(group) == "nccl"
+        self._send = self._recv = None
+        self.calls, self.bytes = 0, 0
+        self._fn = _ALL_GATHER_FN(self._all_gather)        # keep the trampoline alive
+        self.struct = _Comm(self.rank, self.world, self._fn, None)
+
+    def _staging(self, nbytes):
+        t = self._torch
+        if self._send is None or self._send.numel() < nbytes:
+            self._send = t.empty(nbytes, dtype=t.uint8, device=self._device)
+            self._recv = t.empty(nbytes * self.world, dtype=t.uint8, device=self._device)
+        return self._send[:nbytes], self._recv[:nbytes * self.world]
+
+    def _all_gather(self, _user, d_send, d_recv, nbytes):
+        try:
+            ctx, lib = self._ctx, self._ctx._lib
+            send, recv = self._staging(nbytes)
+            ctx._check(lib.bj_memcpy_d2d(ctx._h, C.c_void_p(send.data_ptr()), C.c_void_p(d_send), nbytes))
+            if self._on_device:
+                self._dist.all_gather_into_tensor(recv, send, group=self._group)
+                self._torch.cuda.synchronize(self._device)
+            else:
+                h_send = send.cpu()
+                h_recv = self._torch.empty(nbytes * self.world, dtype=self._torch.uint8)
+                self._dist.all_gather_into_tensor(h_recv, h_send, group=self._group)
+                recv.copy_(h_recv)
+                self._torch.cuda.synchronize(self._device)
+            ctx._check(lib.bj_memcpy_d2d(ctx._h, C.c_void_p(d_recv), C.c_void_p(recv.data_ptr()), nbytes * self.world))
+            self.calls += 1
+            self.bytes += nbytes * self.world
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            self.error = e
+            return 1
+
+
+class ProverSetup:
+    """Device-resident setup for a circuit of era_boojum_amd.synthetic.Circuit shape (bj_setup_create).
+
+    With `comm` (a TorchComm) the LDE cosets of every column are split across the ranks of the process group and
+    `prove` / `prove_dev` become collective: every rank passes the same witness and gets the same proof
+    (bj_setup_create_sharded)."""
+
+    def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, comm=None):
         self._ctx, self._lib, self.circuit = ctx, ctx._lib, circuit
+        self._comm = comm
         self.fri_lde_factor, self.cap_size, self.security_level, self.pow_bits = fri_lde_factor, cap_size, security_level, pow_bits
         c = circuit
         gates = (_GateDesc * len(c.gates))()
@@ -444,8 +511,9 @@ class ProverSetup:
         con = np.ascontiguousarray(c.constants, dtype=np.uint64)
         tab = np.ascontiguousarray(c.tables, dtype=np.uint64)
         h = C.c_void_p()
-        ctx._check(self._lib.bj_setup_create(ctx._h, C.byref(cc), _np_ptr(sig), _np_ptr(con),
-                                             _np_ptr(tab) if c.lookup_reps else None, C.byref(cfg), C.byref(h)))
+        ctx._check(self._lib.bj_setup_create_sharded(ctx._h, C.byref(cc), _np_ptr(sig), _np_ptr(con),
+                                                     _np_ptr(tab) if c.lookup_reps else None, C.byref(cfg),
+                                                     C.byref(comm.struct) if comm is not None else None, C.byref(h)))
         self._h = h
 
     def close(self):

@@ -123,7 +123,7 @@ int bj_ctx_create(int device, bj_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return BJ_ERR_NO_DEVICE;
     bj_ctx *ctx = new bj_ctx();
     ctx->device = device;
-    if (hipMalloc((void **)&ctx->d_small, (64 + 64 * 32) * sizeof(u64)) != hipSuccess ||
+    if (hipMalloc((void **)&ctx->d_small, (64 + 64 * 32 + 4096) * sizeof(u64)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return BJ_ERR_HIP;
@@ -188,6 +188,15 @@ int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!bytes) return BJ_OK;
     if (!h_dst || !d_src) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_memcpy_d2h: null pointer");
     BJ_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJ_OK;
+}
+
+int bj_memcpy_d2d(bj_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+    if (int rc = bind(ctx)) return rc;
+    if (!bytes) return BJ_OK;
+    if (!d_dst || !d_src) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_memcpy_d2d: null pointer");
+    BJ_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BJ_OK;
 }

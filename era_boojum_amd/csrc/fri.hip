@@ -36,8 +36,8 @@ fri_fold_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 *roots
 // factors kappa, kappa^2, kappa^4, and writes ONE output.  Intermediate arrays never touch HBM.
 template <int K>
 __global__ void __launch_bounds__(256)
-fri_fold_fused_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 *roots, size_t out_len, u64 coset_inv,
-                      u64 ch0, u64 ch1) {
+fri_fold_fused_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 *roots, size_t out_len, size_t j0,
+                      u64 coset_inv, u64 ch0, u64 ch1) {
     constexpr int E = 1 << K;
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -58,7 +58,7 @@ fri_fold_fused_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 
 #pragma unroll
             for (int m = 0; m < outs; m++) {
                 gl::e2 a = v[2 * m], b = v[2 * m + 1];
-                u64 r = gl::mul(gl::canon(roots[j * outs + m]), kappa);
+                u64 r = gl::mul(gl::canon(roots[(j0 + j) * outs + m]), kappa);   // j0: global output index of local 0
                 gl::e2 diff = gl::e2_sub(a, b);
                 diff = {gl::mul(diff.c0, r), gl::mul(diff.c1, r)};
                 gl::e2 t = gl::e2_mul(diff, alpha);
@@ -74,7 +74,7 @@ fri_fold_fused_kernel(const u64 *c0, const u64 *c1, u64 *o0, u64 *o1, const u64 
 
 // fold by 2^k in one launch (k = 1..3); len = input length
 void launch_fri_fold_step(const u64 *d_c0, const u64 *d_c1, size_t len, unsigned k, u64 *d_o0, u64 *d_o1,
-                          const u64 *d_roots, u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s) {
+                          const u64 *d_roots, u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s, size_t j0) {
     size_t out_len = len >> k;
     if (!out_len) return;
     unsigned tpb = 256;
@@ -82,11 +82,11 @@ void launch_fri_fold_step(const u64 *d_c0, const u64 *d_c1, size_t len, unsigned
     if (blocks > 16384) blocks = 16384;
     coset_inv = gl::canon(coset_inv); ch0 = gl::canon(ch0); ch1 = gl::canon(ch1);
     if (k == 1)
-        hipLaunchKernelGGL(fri_fold_fused_kernel<1>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, coset_inv, ch0, ch1);
+        hipLaunchKernelGGL(fri_fold_fused_kernel<1>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, j0, coset_inv, ch0, ch1);
     else if (k == 2)
-        hipLaunchKernelGGL(fri_fold_fused_kernel<2>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, coset_inv, ch0, ch1);
+        hipLaunchKernelGGL(fri_fold_fused_kernel<2>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, j0, coset_inv, ch0, ch1);
     else
-        hipLaunchKernelGGL(fri_fold_fused_kernel<3>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, coset_inv, ch0, ch1);
+        hipLaunchKernelGGL(fri_fold_fused_kernel<3>, dim3((unsigned)blocks), dim3(tpb), 0, s, d_c0, d_c1, d_o0, d_o1, d_roots, out_len, j0, coset_inv, ch0, ch1);
 }
 
 void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u64 *d_o1, const u64 *d_roots,

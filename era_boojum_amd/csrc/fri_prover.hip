@@ -88,6 +88,18 @@ void bj_fri_destroy(bj_fri *f) {
 
 int bj_fri_prove(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, unsigned log_n, unsigned log_lde,
                  const uint32_t *schedule, size_t schedule_len, size_t cap_size, bj_transcript *tr, bj_fri **out) {
+    return bj::fri_prove_sharded(ctx, bj::Shard{}, d_c0, d_c1, log_n, log_lde, schedule, schedule_len, cap_size, tr, out);
+}
+
+}  // extern "C"
+
+// With sh.world > 1 the codeword arrives split by contiguous index ranges (d_c0/d_c1 address this rank's N/world values).
+// Oracle 0 is committed shard-wise (local subtree, gathered cap) and folded locally — a fold of 2^k adjacent values
+// never crosses a shard boundary — then the folded layer (N/2^k0 values) is all-gathered and the remaining, geometrically
+// smaller oracles are computed by every rank, so all ranks hold the same transcript.
+int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, const u64 *d_c1, unsigned log_n,
+                          unsigned log_lde, const uint32_t *schedule, size_t schedule_len, size_t cap_size,
+                          bj_transcript *tr, bj_fri **out) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_prove: null out pointer");
     *out = nullptr;
@@ -103,6 +115,8 @@ int bj_fri_prove(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, unsign
         total_fold += schedule[i];
     }
     if (total_fold > log_n) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_prove: schedule folds below degree 1");
+    if (sh.world > 1 && (!bj::is_pow2(sh.world) || cap_size % sh.world || ((size_t)1 << log_full) >> schedule[0] < cap_size))
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_prove: world must be a power of two dividing the cap size");
     if (int rc = bj::ensure_twiddles(ctx, log_full, true)) return rc;  // roots of the FULL domain (fri/mod.rs:192)
 
     bj_fri *f = new bj_fri();
@@ -120,35 +134,59 @@ int bj_fri_prove(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, unsign
     };
     for (size_t step = 0; step < schedule_len; step++) {
         const unsigned k = schedule[step];
+        const unsigned parts = step == 0 ? sh.world : 1;   // how many ranks share this oracle
+        const size_t loc_len = cur_len / parts, loc_cap = cap_size / parts;
         bj_fri::Oracle o;
         o.d_c0 = (u64 *)cur0;
         o.d_c1 = (u64 *)cur1;
         o.owned = step > 0;
-        o.len = cur_len;
+        o.len = loc_len;
         o.log_e = k;
-        o.num_leaves = cur_len >> k;
-        if (o.num_leaves < cap_size) return bail(bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_prove: oracle smaller than cap"));
-        size_t nd = 2 * o.num_leaves - cap_size;
+        o.num_leaves = loc_len >> k;
+        o.world = parts;
+        if (o.num_leaves < loc_cap || loc_cap == 0)
+            return bail(bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_prove: oracle smaller than cap"));
+        size_t nd = 2 * o.num_leaves - loc_cap;
         if (hipMalloc((void **)&o.d_tree, nd * 4 * sizeof(u64)) != hipSuccess)
             return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: tree allocation failed"));
         f->oracles.push_back(o);
         bj_fri::Oracle &oo = f->oracles.back();
         // oracle: 2^k values of c0 then of c1 per leaf (merkle_tree.rs:176-386)
-        rc = bj_merkle_tree_build_chunked(ctx, cur0, cur1, cur_len, k, cap_size, oo.d_tree);
+        rc = bj_merkle_tree_build_chunked(ctx, cur0, cur1, loc_len, k, loc_cap, oo.d_tree);
         if (rc) return bail(rc);
         oo.cap.resize(4 * cap_size);
-        rc = bj_merkle_tree_cap(ctx, oo.d_tree, oo.num_leaves, cap_size, oo.cap.data());
+        if (parts == 1)
+            rc = bj_merkle_tree_cap(ctx, oo.d_tree, oo.num_leaves, cap_size, oo.cap.data());
+        else
+            rc = bj::gather_cap(ctx, sh, oo.d_tree, oo.num_leaves, cap_size, oo.cap.data());
         if (rc) return bail(rc);
         tr->t.absorb(oo.cap.data(), oo.cap.size());
         oo.ch0 = tr->t.challenge();
         oo.ch1 = tr->t.challenge();
         // fold by 2^k in one fused launch; alpha and kappa are squared per inner fold inside the kernel
-        size_t out_len = cur_len >> k;
+        const size_t out_len = cur_len >> k, loc_out = loc_len >> k;
         u64 *nxt = nullptr;
         if (hipMalloc((void **)&nxt, 2 * out_len * sizeof(u64)) != hipSuccess)
             return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
-        bj::launch_fri_fold_step(cur0, cur1, cur_len, k, nxt, nxt + out_len, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
-                                 ctx->stream);
+        if (parts == 1) {
+            bj::launch_fri_fold_step(cur0, cur1, cur_len, k, nxt, nxt + out_len, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
+                                     ctx->stream);
+        } else {
+            u64 *part = nullptr;   // [2][loc_out] of this rank, gathered into nxt = [2][out_len]
+            if (hipMalloc((void **)&part, 2 * loc_out * sizeof(u64)) != hipSuccess) {
+                (void)hipFree(nxt);
+                return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
+            }
+            bj::launch_fri_fold_step(cur0, cur1, loc_len, k, part, part + loc_out, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
+                                     ctx->stream, (size_t)sh.rank * loc_out);
+            rc = bj::all_gather_columns(ctx, sh, part, nxt, 2, loc_out);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(part);
+            if (rc) {
+                (void)hipFree(nxt);
+                return bail(rc);
+            }
+        }
         if (hipGetLastError() != hipSuccess) {
             (void)hipFree(nxt);
             return bail(bj::fail(ctx, BJ_ERR_HIP, "bj_fri_prove: fold launch failed"));
@@ -188,6 +226,8 @@ int bj_fri_prove(bj_ctx *ctx, const uint64_t *d_c0, const uint64_t *d_c1, unsign
     return BJ_OK;
 }
 
+extern "C" {
+
 size_t bj_fri_num_oracles(const bj_fri *f) { return f ? f->oracles.size() : 0; }
 size_t bj_fri_final_degree(const bj_fri *f) { return f ? f->final_degree : 0; }
 
@@ -217,6 +257,7 @@ int bj_fri_query(bj_ctx *ctx, const bj_fri *f, size_t oracle, size_t index, uint
     if (!f || oracle >= f->oracles.size() || !h_leaf_elements)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_query: bad oracle index / null pointer");
     const bj_fri::Oracle &o = f->oracles[oracle];
+    if (o.world > 1) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_fri_query: oracle is sharded across GPUs (use bj_prove)");
     if (index >= o.len) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_query: index out of range");
     const size_t E = (size_t)1 << o.log_e, leaf = index >> o.log_e;
     BJ_HIP(ctx, hipMemcpyAsync(h_leaf_elements, o.d_c0 + leaf * E, E * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));

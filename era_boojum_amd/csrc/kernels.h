@@ -40,5 +40,5 @@ void launch_poseidon2_permute_states(u64 *d_states, size_t n_states, hipStream_t
 void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u64 *d_o1, const u64 *d_roots,
                      u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s);
 void launch_fri_fold_step(const u64 *d_c0, const u64 *d_c1, size_t len, unsigned k, u64 *d_o0, u64 *d_o1,
-                          const u64 *d_roots, u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s);
+                          const u64 *d_roots, u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s, size_t j0 = 0);
 }  // namespace bj

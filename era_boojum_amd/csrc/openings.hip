@@ -210,8 +210,8 @@ void launch_barycentric_eval(const u64 *const *d_col_ptrs, unsigned n_cols, size
 static constexpr int DEEP_PTS = 4;
 
 __global__ void __launch_bounds__(256)
-deep_accumulate_kernel(const u64 *const *cols, const u64 *coefs /*[n][2]*/, unsigned n_cols, size_t N, const u64 *tw,
-                       u64 c0, u64 c1, u64 at0, u64 at1, u64 *dst0, u64 *dst1, int accumulate) {
+deep_accumulate_kernel(const u64 *const *cols, const u64 *coefs /*[n][2]*/, unsigned n_cols, size_t N, size_t I0,
+                       const u64 *tw, u64 c0, u64 c1, u64 at0, u64 at1, u64 *dst0, u64 *dst1, int accumulate) {
     const size_t base = (size_t)blockIdx.x * (256 * DEEP_PTS) + threadIdx.x;
     Acc160 s0[DEEP_PTS], s1[DEEP_PTS];
 #pragma unroll
@@ -238,7 +238,7 @@ deep_accumulate_kernel(const u64 *const *cols, const u64 *coefs /*[n][2]*/, unsi
 #pragma unroll
     for (int k = 0; k < DEEP_PTS; k++) {
         size_t I = base + (size_t)k * 256;
-        size_t Ic = I < N ? I : 0;
+        size_t Ic = I0 + (I < N ? I : 0);   // global LDE index of the point
         u64 wi = tw[Ic >> 1];
         if (Ic & 1) wi = gl::neg(wi);
         u64 x = mul7(wi);
@@ -267,12 +267,12 @@ deep_accumulate_kernel(const u64 *const *cols, const u64 *coefs /*[n][2]*/, unsi
     }
 }
 
-void launch_deep_accumulate(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t N,
+void launch_deep_accumulate(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t N, size_t I0,
                             const u64 *d_tw_fwd, u64 c0, u64 c1, u64 at0, u64 at1, u64 *d_dst0, u64 *d_dst1,
                             int accumulate, hipStream_t s) {
     unsigned blocks = (unsigned)((N + 256 * DEEP_PTS - 1) / (256 * DEEP_PTS));
-    hipLaunchKernelGGL(deep_accumulate_kernel, dim3(blocks), dim3(256), 0, s, d_col_ptrs, d_coefs, n_cols, N, d_tw_fwd,
-                       c0, c1, at0, at1, d_dst0, d_dst1, accumulate);
+    hipLaunchKernelGGL(deep_accumulate_kernel, dim3(blocks), dim3(256), 0, s, d_col_ptrs, d_coefs, n_cols, N, I0,
+                       d_tw_fwd, c0, c1, at0, at1, d_dst0, d_dst1, accumulate);
 }
 
 }  // namespace bj

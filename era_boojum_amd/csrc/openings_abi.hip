@@ -11,11 +11,17 @@ void launch_barycentric_weights(u64 *d_w0, u64 *d_w1, const u64 *d_tw_fwd, unsig
 unsigned barycentric_num_blocks(size_t n);
 void launch_barycentric_eval(const u64 *const *d_col_ptrs, unsigned n_cols, size_t n, const u64 *d_w0, const u64 *d_w1,
                              u64 *d_partials, u64 *d_out, hipStream_t s);
-void launch_deep_accumulate(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t N,
+void launch_deep_accumulate(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t N, size_t I0,
                             const u64 *d_tw_fwd, u64 c0, u64 c1, u64 at0, u64 at1, u64 *d_dst0, u64 *d_dst1,
                             int accumulate, hipStream_t s);
 }  // namespace bj
 
+namespace bj {
+int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
+                          const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
+                          unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
+                          int accumulate);
+}
 namespace {
 // device-side argument block: [ptrs (n_cols)] [coefs (2*n_cols)] in one temporary allocation
 struct DevArgs {
@@ -70,6 +76,19 @@ int bj_deep_quotient_accumulate(bj_ctx *ctx, const uint64_t *const *h_src_c0, co
                                 size_t n_src, const uint64_t *h_values, const uint64_t *h_challenges,
                                 const uint64_t *at2, unsigned log_n, unsigned log_lde, uint64_t *d_dst_c0,
                                 uint64_t *d_dst_c1, int accumulate) {
+    return bj::deep_accumulate_range(ctx, h_src_c0, h_src_c1, n_src, h_values, h_challenges, at2, log_n, log_lde,
+                                     (size_t)1 << (log_n + log_lde), 0, d_dst_c0, d_dst_c1, accumulate);
+}
+
+}  // extern "C"
+
+namespace bj {
+// the same over the LOCAL index range [I0, I0 + N_local) of the LDE domain (a contiguous range of cosets owned by one GPU);
+// source and destination pointers address the local range
+int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
+                          const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
+                          unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
+                          int accumulate) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!h_src_c0 || !h_values || !h_challenges || !at2 || !d_dst_c0 || !d_dst_c1)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_deep_quotient_accumulate: null pointer");
@@ -103,11 +122,10 @@ int bj_deep_quotient_accumulate(bj_ctx *ctx, const uint64_t *const *h_src_c0, co
     BJ_HIP(ctx, hipMemcpyAsync((void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
     BJ_HIP(ctx, hipMemcpyAsync(d_coefs, coefs.data(), coefs.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    bj::launch_deep_accumulate(d_ptrs, d_coefs, n_cols, (size_t)1 << log_full, ctx->tw_fwd, C.c0, C.c1,
+    bj::launch_deep_accumulate(d_ptrs, d_coefs, n_cols, N_local, I0, ctx->tw_fwd, C.c0, C.c1,
                                gl::canon(at2[0]), gl::canon(at2[1]), d_dst_c0, d_dst_c1, accumulate, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the argument block is freed on return
     return BJ_OK;
 }
-
-}  // extern "C"
+}  // namespace bj

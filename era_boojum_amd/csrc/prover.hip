@@ -1,4 +1,5 @@
-// Whole-prover orchestration on one GPU: bj_setup_create / bj_prove_dev / bj_prove (seam S1 of SURVEY.md §8b).
+// Whole-prover orchestration: bj_setup_create[_sharded] / bj_prove_dev / bj_prove (seam S1 of SURVEY.md §8b), on one GPU
+// or with the LDE cosets of one proof split across several (bj_comm, include/boojum_hip.h).
 // Follows prove_cpu_basic (src/cs/implementations/prover.rs:153-2266) round by round; the host only runs the
 // Fiat–Shamir transcript and O(#columns) scalar arithmetic, every polynomial stays in HBM.
 //
@@ -35,14 +36,19 @@ void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_
                             size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s);
 void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
-                               unsigned log_n, unsigned log_q, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
-                               const u64 *alpha_l1, const u64 *d_alphas_cp, u64 *d_out0, u64 *d_out1, hipStream_t s);
+                               unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
+                               const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, u64 *d_out0,
+                               u64 *d_out1, hipStream_t s);
 void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, const u64 *d_idx, unsigned n_idx,
                         u64 *d_out, hipStream_t s);
 void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, const u64 *d_idx, unsigned n_idx,
                          u64 *d_out, hipStream_t s);
 void launch_gather_fri_leaves(const u64 *d_c0, const u64 *d_c1, unsigned log_e, const u64 *d_leaf_idx, unsigned n_idx,
                               u64 *d_out, hipStream_t s);
+int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
+                          const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
+                          unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
+                          int accumulate);
 }  // namespace bj
 
 struct bj_setup {
@@ -57,9 +63,15 @@ struct bj_setup {
     unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0;
     unsigned L = 0, log_L = 0, log_fri = 0, log_q = 0;
     unsigned n_cols = 0;           // V sigmas + nC constants + (w+1) tables
-    u64 *d_nat = nullptr;          // [n_cols][n] natural-order values
-    u64 *d_lde = nullptr;          // [n_cols][L][n]
-    u64 *d_tree = nullptr;
+    // shard of the LDE domain held by this GPU: cosets [c0, c0 + cl), i.e. flat indices [c0*n, (c0+cl)*n)
+    bj::Shard sh;
+    unsigned c0 = 0, cl = 0;
+    size_t Ls = 0;                 // column stride of every LDE array = cl * n
+    size_t Nl = 0;                 // Merkle leaves held here (n * fri_lde / world)
+    size_t cap_l = 0;              // cap nodes of the local subtree (cap_size / world)
+    u64 *d_nat = nullptr;          // [n_cols][n] natural-order values (replicated)
+    u64 *d_lde = nullptr;          // [n_cols][cl][n]
+    u64 *d_tree = nullptr;         // local subtree
     u64 *d_non_res = nullptr;
     std::vector<u64> cap;
 };
@@ -113,6 +125,51 @@ struct StageTimer {
 
 }  // namespace
 
+namespace bj {
+int all_gather(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_recv, size_t elems) {
+    if (!elems) return BJ_OK;
+    if (sh.world == 1) {
+        if (d_send != d_recv)
+            BJ_HIP(ctx, hipMemcpyAsync(d_recv, d_send, elems * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        return BJ_OK;
+    }
+    if (!sh.comm.all_gather) return fail(ctx, BJ_ERR_INVALID_ARG, "sharded prover: no all_gather callback");
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = sh.comm.all_gather(sh.comm.user, d_send, d_recv, elems * 8))
+        return fail(ctx, BJ_ERR_HIP, "sharded prover: the host's all_gather callback failed (%d)", rc);
+    return BJ_OK;
+}
+
+int all_gather_columns(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_dst, unsigned parts, size_t part_len) {
+    if (sh.world == 1) return all_gather(ctx, sh, d_send, d_dst, (size_t)parts * part_len);
+    u64 *tmp = nullptr;
+    const size_t per = (size_t)parts * part_len;
+    if (hipMalloc((void **)&tmp, per * sh.world * 8) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "all_gather_columns: staging allocation failed");
+    int rc = all_gather(ctx, sh, d_send, tmp, per);
+    if (!rc) {
+        // tmp[r][p][part_len] -> dst[p][r][part_len]: for each rank one strided 2-D copy
+        for (unsigned r = 0; r < sh.world && !rc; r++)
+            if (hipMemcpy2DAsync(d_dst + (size_t)r * part_len, (size_t)sh.world * part_len * 8, tmp + (size_t)r * per,
+                                 part_len * 8, part_len * 8, parts, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                rc = fail(ctx, BJ_ERR_HIP, "all_gather_columns: device copy failed");
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int gather_cap(bj_ctx *ctx, const Shard &sh, const u64 *d_tree_local, size_t leaves_local, size_t cap_size, u64 *h_cap) {
+    const size_t cap_l = cap_size / sh.world;
+    if (sh.world == 1) return bj_merkle_tree_cap(ctx, d_tree_local, leaves_local, cap_size, h_cap);
+    // the local cap fragment is the last layer of the local subtree
+    const u64 *frag = d_tree_local + (2 * leaves_local - 2 * cap_l) * 4;
+    u64 *d_all = ctx->d_small + 64 + 64 * 32;   // 4096 u64 reserved for this (ctx.h)
+    if (cap_size * 4 > 4096) return fail(ctx, BJ_ERR_INVALID_ARG, "gather_cap: cap too large");
+    if (int rc = all_gather(ctx, sh, frag, d_all, cap_l * 4)) return rc;
+    return bj_memcpy_d2h(ctx, h_cap, d_all, cap_size * 32);
+}
+}  // namespace bj
+
 extern "C" {
 
 void bj_setup_destroy(bj_setup *s) {
@@ -127,6 +184,11 @@ void bj_setup_destroy(bj_setup *s) {
 
 int bj_setup_create(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_sigmas, const uint64_t *h_constants,
                     const uint64_t *h_tables, const bj_proof_config *cfg, bj_setup **out) {
+    return bj_setup_create_sharded(ctx, c, h_sigmas, h_constants, h_tables, cfg, nullptr, out);
+}
+
+int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_sigmas, const uint64_t *h_constants,
+                            const uint64_t *h_tables, const bj_proof_config *cfg, const bj_comm *comm, bj_setup **out) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: null out pointer");
     *out = nullptr;
@@ -144,8 +206,26 @@ int bj_setup_create(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_sigmas, 
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad column counts");
     unsigned n_chunks = (c->num_vars + c->quotient_degree - 1) / c->quotient_degree;
     if (n_chunks < 2) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: a single copy-permutation chunk is not supported");
+    if (comm && comm->world > 1) {
+        const unsigned W = comm->world;
+        if (!bj::is_pow2(W) || comm->rank >= W || !comm->all_gather)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must be a power of two, rank < world, callback set");
+        if (cfg->fri_lde_factor % W || cfg->cap_size % W || c->quotient_degree > cfg->fri_lde_factor)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must divide fri_lde_factor and cap_size, and "
+                                                     "quotient_degree must not exceed fri_lde_factor");
+        const unsigned cl = cfg->fri_lde_factor / W;
+        if (cl < c->quotient_degree && c->quotient_degree % cl)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: cosets per rank must divide the quotient degree");
+        if ((((size_t)1 << c->log_n) * cl) < cfg->cap_size / W)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: shard smaller than its cap fragment");
+    }
     bj_setup *s = new bj_setup();
     s->device = ctx->device;
+    if (comm && comm->world > 1) {
+        s->sh.rank = comm->rank;
+        s->sh.world = comm->world;
+        s->sh.comm = *comm;
+    }
     s->log_n = c->log_n; s->V = c->num_vars; s->num_gp_vars = c->num_gp_vars; s->nC = c->num_constant_cols;
     s->lookup_w = c->lookup_width; s->lookup_reps = c->lookup_reps; s->table_id_col = c->table_id_col;
     s->q = c->quotient_degree;
@@ -172,13 +252,18 @@ int bj_setup_create(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_sigmas, 
     const size_t n = (size_t)1 << s->log_n;
     const unsigned nT = s->lookup_reps ? s->lookup_w + 1 : 0;
     s->n_cols = s->V + s->nC + nT;
+    s->cl = s->L / s->sh.world;
+    s->c0 = s->sh.rank * s->cl;
+    s->Ls = (size_t)s->cl * n;
+    s->Nl = n * s->fri_lde / s->sh.world;
+    s->cap_l = s->cap_size / s->sh.world;
     int rc = BJ_OK;
     auto bail = [&](int code) {
         bj_setup_destroy(s);
         return code;
     };
     if (hipMalloc((void **)&s->d_nat, (size_t)s->n_cols * n * 8) != hipSuccess ||
-        hipMalloc((void **)&s->d_lde, (size_t)s->n_cols * s->L * n * 8) != hipSuccess ||
+        hipMalloc((void **)&s->d_lde, (size_t)s->n_cols * s->Ls * 8) != hipSuccess ||
         hipMalloc((void **)&s->d_non_res, s->V * 8) != hipSuccess)
         return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: device allocation failed"));
     // leaf order of the setup oracle: sigma || constants || tables (polynomial_storage.rs:667-676)
@@ -191,16 +276,15 @@ int bj_setup_create(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_sigmas, 
         DevBuf mono;
         if ((rc = mono.alloc(ctx, (size_t)s->n_cols * n))) return bail(rc);
         rc = bj_intt_batch(ctx, s->d_nat, mono.p, s->log_n, s->n_cols, n, 1);
-        if (!rc) rc = bj_lde_batch(ctx, mono.p, n, s->d_lde, s->log_n, s->n_cols, s->log_L);
+        if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, s->d_lde, s->log_n, s->n_cols, s->log_L, s->c0, s->cl);
         if (!rc) rc = bj_sync(ctx);
         if (rc) return bail(rc);
     }
-    const size_t leaves = n * s->fri_lde;
-    if (hipMalloc((void **)&s->d_tree, bj_merkle_tree_digests(leaves, s->cap_size) * 32) != hipSuccess)
+    if (hipMalloc((void **)&s->d_tree, bj_merkle_tree_digests(s->Nl, s->cap_l) * 32) != hipSuccess)
         return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: tree allocation failed"));
-    rc = bj_merkle_tree_build(ctx, s->d_lde, (size_t)s->L * n, s->n_cols, leaves, s->cap_size, s->d_tree);
+    rc = bj_merkle_tree_build(ctx, s->d_lde, s->Ls, s->n_cols, s->Nl, s->cap_l, s->d_tree);
     s->cap.resize(4 * s->cap_size);
-    if (!rc) rc = bj_merkle_tree_cap(ctx, s->d_tree, leaves, s->cap_size, s->cap.data());
+    if (!rc) rc = bj::gather_cap(ctx, s->sh, s->d_tree, s->Nl, s->cap_size, s->cap.data());
     if (rc) return bail(rc);
     *out = s;
     return BJ_OK;
@@ -236,7 +320,15 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if (!S->pub_cols.empty() && !h_public_values) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_dev: public input values required");
     hipStream_t st = ctx->stream;
     const unsigned log_n = S->log_n, V = S->V, q = S->q, L = S->L, fri = S->fri_lde, cap = S->cap_size;
-    const size_t n = (size_t)1 << log_n, N = n * fri, Q = n * q, Ln = n * L;
+    const bj::Shard &sh = S->sh;
+    // N / Ln: leaves / column stride HELD BY THIS GPU (the whole domain on one GPU); Q: points of the quotient domain
+    const size_t n = (size_t)1 << log_n, N = S->Nl, Q = n * q, Ln = S->Ls, I0 = (size_t)S->c0 * n;
+    const size_t capl = S->cap_l;
+    // quotient evaluation: a rank holding >= q cosets evaluates on its own first q cosets (they form the coset
+    // 7*w^bitrev(c0) of the size-qn subgroup, same monomials); otherwise the ranks holding cosets < q each evaluate
+    // theirs and the pieces are all-gathered
+    const bool q_local = S->cl >= q;
+    const size_t Qe = q_local ? Q : (S->c0 < q ? Ln : 0);   // points this rank evaluates
     const unsigned nW = V + (has_lookup ? 1 : 0);
     const unsigned n_chunks = (V + q - 1) / q, n_part = n_chunks - 1;
     const unsigned nS2 = 2 * (1 + n_part) + (has_lookup ? 2 * (S->lookup_reps + 1) : 0);
@@ -255,12 +347,12 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         }
     } guard{proof};
     {   // one reservation for every buffer below (sizes mirror the allocations; +1 MiB slack per buffer for alignment)
-        const size_t tree_elems = bj_merkle_tree_digests(N, cap) * 4, slack = (size_t)1 << 17;
+        const size_t tree_elems = bj_merkle_tree_digests(N, capl) * 4, slack = (size_t)1 << 17;
         size_t need = (size_t)nW * Ln + (size_t)(nW > nS2 ? nW : nS2) * n + tree_elems            // wit_lde, mono, wit_tree
                     + (size_t)nS2 * n + ((size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16)   // s2_nat, tmp
                     + (size_t)nS2 * Ln + tree_elems                                                // s2_lde, s2_tree
-                    + 2 * Q + (size_t)2 * q * N + tree_elems + 2 * n + 2 * N                       // T, q_lde, q_tree, w, deep
-                    + (size_t)4096 * 1024 + 24 * slack;                                            // alphas, query gathers
+                    + 2 * Q + (sh.world > 1 ? 2 * Ln * (sh.world + 1) : 0) + (size_t)2 * q * N + tree_elems + 2 * n + 2 * N                       // T (+ gather staging), q_lde, q_tree, w, deep
+                    + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 24 * slack;       // alphas, query gathers
         if ((rc = bj::arena_reset(ctx, need))) return rc;
     }
     StageTimer timer(st);
@@ -279,17 +371,17 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = mono.alloc(ctx, (size_t)(nW > nS2 ? nW : nS2) * n))) return rc;
     rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
     if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
-    if (!rc) rc = bj_lde_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L);
+    if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L, S->c0, S->cl);
     if (rc) return rc;
-    if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
+    if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
     // witness tree; the leaf kernel (the dominant kernel of a proof) is bracketed by HIP events on the launch stream
     BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
     bj::launch_poseidon2_leaves(wit_lde.p, Ln, nullptr, nW, N, wit_tree.p, st);
     BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
-    bj::launch_poseidon2_node_layers(wit_tree.p, N, cap, st);
+    bj::launch_poseidon2_node_layers(wit_tree.p, N, capl, st);
     BJ_CHECK_LAUNCH(ctx);
     std::vector<u64> wit_cap(4 * cap), s2_cap(4 * cap), q_cap(4 * cap);
-    rc = bj_merkle_tree_cap(ctx, wit_tree.p, N, cap, wit_cap.data());
+    rc = bj::gather_cap(ctx, sh, wit_tree.p, N, cap, wit_cap.data());
     if (rc) return rc;
     BJ_HIP(ctx, hipEventElapsedTime(&proof->stage_ms[7], ctx->ev0, ctx->ev1));
     tr.absorb(wit_cap.data(), wit_cap.size());
@@ -315,11 +407,11 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     BJ_CHECK_LAUNCH(ctx);
     if ((rc = s2_lde.alloc(ctx, (size_t)nS2 * Ln))) return rc;
     rc = bj_intt_batch(ctx, s2_nat.p, mono.p, log_n, nS2, n, 1);
-    if (!rc) rc = bj_lde_batch(ctx, mono.p, n, s2_lde.p, log_n, nS2, S->log_L);
+    if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, s2_lde.p, log_n, nS2, S->log_L, S->c0, S->cl);
     if (rc) return rc;
-    if ((rc = s2_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
-    rc = bj_merkle_tree_build(ctx, s2_lde.p, Ln, nS2, N, cap, s2_tree.p);
-    if (!rc) rc = bj_merkle_tree_cap(ctx, s2_tree.p, N, cap, s2_cap.data());
+    if ((rc = s2_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
+    rc = bj_merkle_tree_build(ctx, s2_lde.p, Ln, nS2, N, capl, s2_tree.p);
+    if (!rc) rc = bj::gather_cap(ctx, sh, s2_tree.p, N, cap, s2_cap.data());
     if (rc) return rc;
     tr.absorb(s2_cap.data(), s2_cap.size());
     proof->stage_ms[1] = timer.lap();
@@ -344,22 +436,40 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = d_alphas.alloc(ctx, alphas.size()))) return rc;
     if ((rc = bj_memcpy_h2d(ctx, d_alphas.p, alphas.data(), alphas.size() * 8))) return rc;
     if ((rc = T.alloc(ctx, 2 * Q))) return rc;
+    ArenaBuf Tl;   // this rank's evaluations [2][Qe] (T itself when nothing has to be gathered)
+    if (q_local)
+        Tl.p = T.p;
+    else if ((rc = Tl.alloc(ctx, 2 * Ln))) return rc;
+    u64 *t0 = Tl.p, *t1 = Tl.p + (q_local ? Q : Ln);
     const u64 *a_lookup = d_alphas.p, *a_gates = d_alphas.p + 2 * n_lookup_terms, *a_l1 = a_gates + 2 * n_gate_terms;
     const u64 *d_sig_lde = S->d_lde, *d_con_lde = S->d_lde + (size_t)V * Ln, *d_tab_lde = S->d_lde + (size_t)(V + nC) * Ln;
-    bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Q, T.p, T.p + Q, st);
-    if (has_lookup) {
+    if (Qe) bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Qe, t0, t1, st);
+    if (has_lookup && Qe) {
         const u64 *dA = s2_lde.p + (size_t)(2 + 2 * n_part) * Ln, *dB = dA + (size_t)2 * S->lookup_reps * Ln;
         bj::launch_quotient_lookup(wit_lde.p + (size_t)S->num_gp_vars * Ln, Ln, d_con_lde + (size_t)S->table_id_col * Ln, d_tab_lde,
                                    Ln, wit_lde.p + (size_t)V * Ln, dA, dB, Ln, S->lookup_reps, S->lookup_w, lbeta, lgamma,
-                                   a_lookup, Q, T.p, T.p + Q, st);
+                                   a_lookup, Qe, t0, t1, st);
     }
-    bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_q, ctx->tw_fwd,
-                                  beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_gate_terms), a_l1 + 2, T.p, T.p + Q, st);
+    if (Qe)
+        bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_L, ctx->tw_fwd,
+                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_gate_terms), a_l1 + 2, Qe, I0, t0, t1, st);
     BJ_CHECK_LAUNCH(ctx);
+    u64 q_shift = gl::GEN;   // coset the gathered evaluations live on
+    if (q_local) {
+        q_shift = gl::mul(gl::GEN, gl::pow(gl::omega(log_n + S->log_L), gl::bitrev32(S->c0, S->log_L)));
+    } else {
+        // ranks [0, q/cl) hold cosets [0, q); everybody receives everything and keeps those pieces
+        ArenaBuf all;
+        if ((rc = all.alloc(ctx, (size_t)2 * Ln * sh.world))) return rc;
+        if ((rc = bj::all_gather(ctx, sh, Tl.p, all.p, 2 * Ln))) return rc;
+        for (unsigned r = 0; r < q / S->cl; r++)
+            BJ_HIP(ctx, hipMemcpy2DAsync(T.p + (size_t)r * Ln, Q * 8, all.p + (size_t)r * 2 * Ln, Ln * 8, Ln * 8, 2,
+                                         hipMemcpyDeviceToDevice, st));
+    }
     // flatten (= bit-reversal of the size-qn array), iNTT on coset g, chunk, LDE to fri_lde_factor (prover.rs:1386-1482)
     const unsigned log_Q = log_n + S->log_q;
     rc = bj_bitreverse_batch(ctx, T.p, T.p, log_Q, 2, Q);
-    if (!rc) rc = bj_intt_batch(ctx, T.p, T.p, log_Q, 2, Q, gl::GEN);
+    if (!rc) rc = bj_intt_batch(ctx, T.p, T.p, log_Q, 2, Q, q_shift);
     u64 top[2] = {1, 1};
     if (!rc) rc = bj_memcpy_d2h(ctx, &top[0], T.p + Q - 1, 8);
     if (!rc) rc = bj_memcpy_d2h(ctx, &top[1], T.p + 2 * Q - 1, 8);
@@ -369,11 +479,12 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     ArenaBuf q_lde, q_tree;
     if ((rc = q_lde.alloc(ctx, (size_t)2 * q * N))) return rc;
     for (unsigned e = 0; e < 2 && !rc; e++)   // chunk j of c_e -> column 2j+e (prover.rs:1445-1467)
-        rc = bj::lde_cosets_strided(ctx, T.p + (size_t)e * Q, n, q_lde.p + (size_t)e * N, 2 * N, log_n, q, S->log_fri, 0, fri);
+        rc = bj::lde_cosets_strided(ctx, T.p + (size_t)e * Q, n, q_lde.p + (size_t)e * N, 2 * N, log_n, q, S->log_fri,
+                                    sh.world > 1 ? S->c0 : 0, sh.world > 1 ? S->cl : fri);
     if (rc) return rc;
-    if ((rc = q_tree.alloc(ctx, bj_merkle_tree_digests(N, cap) * 4))) return rc;
-    rc = bj_merkle_tree_build(ctx, q_lde.p, N, 2 * q, N, cap, q_tree.p);
-    if (!rc) rc = bj_merkle_tree_cap(ctx, q_tree.p, N, cap, q_cap.data());
+    if ((rc = q_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
+    rc = bj_merkle_tree_build(ctx, q_lde.p, N, 2 * q, N, capl, q_tree.p);
+    if (!rc) rc = bj::gather_cap(ctx, sh, q_tree.p, N, cap, q_cap.data());
     if (rc) return rc;
     tr.absorb(q_cap.data(), q_cap.size());
     proof->stage_ms[2] = timer.lap();
@@ -399,8 +510,11 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         for (unsigned i = 0; i < nT; i++) srcs.push_back({d_tab_lde + (size_t)i * Ln, nullptr});
     }
     for (unsigned j = 0; j < q; j++) srcs.push_back({q_lde.p + (size_t)(2 * j) * N, q_lde.p + (size_t)(2 * j + 1) * N});
+    // every rank evaluates from ITS first coset (shift 7*w^bitrev(c0)): the polynomials have degree < n, so the value
+    // is the same field element whichever coset it is interpolated from — no exchange, identical transcripts
+    const u64 open_shift = gl::mul(gl::GEN, gl::pow(gl::omega(log_n + S->log_L), gl::bitrev32(S->c0, S->log_L)));
     auto evaluate = [&](const std::vector<Src> &ss, const u64 *at, std::vector<u64> &vals) -> int {
-        int r = bj_barycentric_weights(ctx, log_n, gl::GEN, at, w.p, w.p + n);
+        int r = bj_barycentric_weights(ctx, log_n, open_shift, at, w.p, w.p + n);
         if (r) return r;
         std::vector<const u64 *> ptrs;
         for (auto &s : ss) {
@@ -483,8 +597,8 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             p0.push_back(s.c0);
             p1.push_back(s.c1);
         }
-        int r = bj_deep_quotient_accumulate(ctx, p0.data(), p1.data(), ss.size(), vals, chs.data() + 2 * choff, at, log_n,
-                                            S->log_fri, deep.p, deep.p + N, accumulate);
+        int r = bj::deep_accumulate_range(ctx, p0.data(), p1.data(), ss.size(), vals, chs.data() + 2 * choff, at, log_n,
+                                          S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p, deep.p + N, accumulate);
         choff += ss.size();
         return r;
     };
@@ -515,7 +629,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     bj_transcript trw;   // bj_fri_prove drives a bj_transcript; hand our state over and take it back
     trw.t = tr;
     bj_fri *fri_obj = nullptr;
-    rc = bj_fri_prove(ctx, deep.p, deep.p + N, log_n, S->log_fri, sched, sched_len, cap, &trw, &fri_obj);
+    rc = bj::fri_prove_sharded(ctx, sh, deep.p, deep.p + N, log_n, S->log_fri, sched, sched_len, cap, &trw, &fri_obj);
     if (rc) return rc;
     struct FriGuard {
         bj_fri *f;
@@ -529,7 +643,9 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     bools.max_needed = log_n + S->log_fri;
     std::vector<u64> idxs(num_queries);
     for (size_t i = 0; i < num_queries; i++) idxs[i] = bools.query_index(tr, log_n, S->log_fri);
-    const unsigned depth = bj::log2_exact(N / cap);
+    const unsigned depth = bj::log2_exact(N / capl);
+    const unsigned W = sh.world;
+    // a leaf lives on rank index / N; every rank gathers at (index mod N) and the owner's answer is kept
     const unsigned widths[4] = {nW, nS2, 2 * q, S->n_cols};
     const u64 *bases[4] = {wit_lde.p, s2_lde.p, q_lde.p, S->d_lde};
     const size_t strides[4] = {Ln, Ln, N, Ln};
@@ -539,8 +655,13 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     for (int o = 0; o < 4; o++) per_query += widths[o] + (size_t)depth * 4;
     if ((rc = d_idx.alloc(ctx, num_queries))) return rc;
     if ((rc = d_g.alloc(ctx, per_query * num_queries))) return rc;
-    if ((rc = bj_memcpy_h2d(ctx, d_idx.p, idxs.data(), num_queries * 8))) return rc;
-    std::vector<u64> gathered(per_query * num_queries);
+    {
+        std::vector<u64> loc(num_queries);
+        for (size_t i = 0; i < num_queries; i++) loc[i] = idxs[i] % N;
+        if ((rc = bj_memcpy_h2d(ctx, d_idx.p, loc.data(), num_queries * 8))) return rc;
+    }
+    const size_t G = per_query * num_queries;
+    std::vector<u64> gathered(G * W);   // [rank][...]; query qi reads the block of rank idxs[qi] / N
     {
         size_t off = 0;
         for (int o = 0; o < 4; o++) {
@@ -550,7 +671,14 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             off += (size_t)depth * 4 * num_queries;
         }
         BJ_CHECK_LAUNCH(ctx);
-        if ((rc = bj_memcpy_d2h(ctx, gathered.data(), d_g.p, gathered.size() * 8))) return rc;
+        const u64 *src = d_g.p;
+        ArenaBuf all;
+        if (W > 1) {
+            if ((rc = all.alloc(ctx, G * W))) return rc;
+            if ((rc = bj::all_gather(ctx, sh, d_g.p, all.p, G))) return rc;
+            src = all.p;
+        }
+        if ((rc = bj_memcpy_d2h(ctx, gathered.data(), src, gathered.size() * 8))) return rc;
     }
     // FRI openings, batched per oracle: leaf j = (index >> folds so far) >> k  (proof.rs:65-100, fri/mod.rs:829-895)
     std::vector<std::vector<u64>> fri_leaves(sched_len), fri_paths(sched_len);
@@ -561,16 +689,17 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         size_t max_out = 0;
         for (size_t i = 0; i < sched_len; i++) {
             const bj_fri::Oracle &o = fri_obj->oracles[i];
-            fri_depth[i] = bj::log2_exact(o.num_leaves / cap);
+            fri_depth[i] = bj::log2_exact(o.num_leaves / (cap / o.world));
             size_t need = ((size_t)2 << o.log_e) + (size_t)fri_depth[i] * 4;
             if (need > max_out) max_out = need;
         }
-        if ((rc = d_fo.alloc(ctx, max_out * num_queries))) return rc;
-        std::vector<u64> li(num_queries);
+        if ((rc = d_fo.alloc(ctx, max_out * num_queries * (W + 1)))) return rc;
+        std::vector<u64> li(num_queries), host_all;
         unsigned shift = 0;
         for (size_t i = 0; i < sched_len; i++) {
             const bj_fri::Oracle &o = fri_obj->oracles[i];
-            for (size_t qi = 0; qi < num_queries; qi++) li[qi] = (idxs[qi] >> shift) >> o.log_e;
+            for (size_t qi = 0; qi < num_queries; qi++) li[qi] = ((idxs[qi] >> shift) >> o.log_e) % o.num_leaves;
+            const unsigned shift0 = shift;
             shift += o.log_e;
             if ((rc = bj_memcpy_h2d(ctx, d_li.p, li.data(), num_queries * 8))) return rc;
             const size_t E2 = (size_t)2 << o.log_e;
@@ -580,6 +709,20 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             BJ_CHECK_LAUNCH(ctx);
             fri_leaves[i].resize(E2 * num_queries);
             fri_paths[i].resize((size_t)fri_depth[i] * 4 * num_queries + 1);
+            const size_t PD = (size_t)fri_depth[i] * 4, blk = (E2 + PD) * num_queries;
+            if (o.world > 1) {   // oracle 0 of a sharded proof: keep the owner's leaf and path
+                u64 *d_all = d_fo.p + max_out * num_queries;
+                if ((rc = bj::all_gather(ctx, sh, d_fo.p, d_all, blk))) return rc;
+                host_all.resize(blk * W);
+                if ((rc = bj_memcpy_d2h(ctx, host_all.data(), d_all, blk * W * 8))) return rc;
+                for (size_t qi = 0; qi < num_queries; qi++) {
+                    const size_t owner = ((idxs[qi] >> shift0) >> o.log_e) / o.num_leaves;
+                    const u64 *b = host_all.data() + owner * blk;
+                    std::memcpy(fri_leaves[i].data() + qi * E2, b + qi * E2, E2 * 8);
+                    std::memcpy(fri_paths[i].data() + qi * PD, b + E2 * num_queries + qi * PD, PD * 8);
+                }
+                continue;
+            }
             if ((rc = bj_memcpy_d2h(ctx, fri_leaves[i].data(), d_fo.p, E2 * num_queries * 8))) return rc;
             if (fri_depth[i] &&
                 (rc = bj_memcpy_d2h(ctx, fri_paths[i].data(), d_fo.p + E2 * num_queries, (size_t)fri_depth[i] * 4 * num_queries * 8)))
@@ -613,7 +756,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     }
     for (size_t qi = 0; qi < num_queries; qi++) {
         D.push_back(idxs[qi]);
-        size_t off = 0;
+        size_t off = (idxs[qi] / N) * G;
         for (int o = 0; o < 4; o++) {
             put(gathered.data() + off + qi * widths[o], widths[o]);
             off += (size_t)widths[o] * num_queries;

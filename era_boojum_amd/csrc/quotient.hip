@@ -188,13 +188,14 @@ __global__ void __launch_bounds__(256)
 quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas, size_t sig_stride, const u64 *stage2,
                           size_t s2_stride, const u64 *non_res, unsigned V, unsigned chunk, unsigned n_chunks,
                           unsigned log_n, const u64 *tw, CopyPermQArgs ca, const u64 *alphas /* [n_chunks][2] */,
-                          size_t Q, u64 *out0, u64 *out1) {
+                          size_t Q, size_t I0 /* global index of local point 0 (multi-GPU coset shards) */, u64 *out0,
+                          u64 *out1) {
     const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= Q) return;
     const size_t n = (size_t)1 << log_n;
-    const unsigned coset = (unsigned)(I >> log_n);
+    const unsigned coset = (unsigned)((I0 + I) >> log_n);   // global coset: selects x^n and the vanishing inverse
     const u32 i_br = (u32)(I & (n - 1));
-    const u64 x = lde_point(tw, I);
+    const u64 x = lde_point(tw, I0 + I);
     Acc160q s0, s1;
     s0.clear();
     s1.clear();
@@ -209,7 +210,7 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     }
     // z(omega * x): next natural index inside the coset
     const u32 i_next = gl::bitrev32((gl::bitrev32(i_br, log_n) + 1) & (u32)(n - 1), log_n);
-    const size_t In = ((size_t)coset << log_n) + i_next;
+    const size_t In = (I - i_br) + i_next;
     const gl::e2 z_shift{gl::canon(stage2[In]), gl::canon(stage2[s2_stride + In])};
     for (unsigned j = 0; j < n_chunks; j++) {
         gl::e2 lhs = (j + 1 < n_chunks)
@@ -270,20 +271,21 @@ void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_
 
 void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
-                               unsigned log_n, unsigned log_q, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
-                               const u64 *alpha_l1, const u64 *d_alphas_cp, u64 *d_out0, u64 *d_out1, hipStream_t s) {
-    const size_t n = (size_t)1 << log_n, Q = n << log_q;
-    const unsigned q = 1u << log_q;
+                               unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
+                               const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, u64 *d_out0,
+                               u64 *d_out1, hipStream_t s) {
+    const size_t n = (size_t)1 << log_n, Q = Q_local;
+    const unsigned L = 1u << log_L;   // cosets of the whole LDE domain; a GPU may hold any contiguous range of them
     CopyPermQArgs ca;
     ca.beta = {gl::canon(beta[0]), gl::canon(beta[1])};
     ca.gamma = {gl::canon(gamma[0]), gl::canon(gamma[1])};
     ca.alpha_l1 = {gl::canon(alpha_l1[0]), gl::canon(alpha_l1[1])};
-    // x^n on coset c: (7 * w_{qn}^{bitrev_q(c)})^n = 7^n * w_q^{bitrev_q(c)}
+    // x^n on coset c: (7 * w_{Ln}^{bitrev_L(c)})^n = 7^n * w_L^{bitrev_L(c)}   (for c < q this is w_q^{bitrev_q(c)})
     const u64 g_n = gl::pow(gl::GEN, n);
-    const u64 wq = gl::omega(log_q);
+    const u64 wq = gl::omega(log_L);
     for (unsigned c = 0; c < 64; c++) {
-        if (c < q) {
-            u64 xn = gl::mul(g_n, gl::pow(wq, gl::bitrev32(c, log_q)));
+        if (c < L) {
+            u64 xn = gl::mul(g_n, gl::pow(wq, gl::bitrev32(c, log_L)));
             ca.xn_minus_one[c] = gl::sub(xn, 1);
             ca.vanishing_inv[c] = gl::inv(ca.xn_minus_one[c]);
         } else {
@@ -294,7 +296,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
     const unsigned n_chunks = (V + chunk - 1) / chunk;
     hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_vars, var_stride,
                        d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
-                       d_alphas_cp, Q, d_out0, d_out1);
+                       d_alphas_cp, Q, I0, d_out0, d_out1);
 }
 
 // ----------------------------------------------------------------------------------------------- query gathers

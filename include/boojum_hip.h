@@ -60,6 +60,7 @@ int bj_malloc(bj_ctx *ctx, size_t bytes, void **d_ptr);
 int bj_free(bj_ctx *ctx, void *d_ptr);
 int bj_memcpy_h2d(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int bj_memcpy_d2d(bj_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); /* stream-ordered, then synchronised */
 
 /* HIP-event stopwatch on the context's stream (used by bench.py to time the kernels where they are launched). */
 int bj_timer_start(bj_ctx *ctx);
@@ -274,6 +275,26 @@ typedef struct bj_proof bj_proof;
  * natural-order values over the main domain (SetupBaseStorage, polynomial_storage.rs:48-75). */
 int bj_setup_create(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_sigmas, const uint64_t *h_constants,
                     const uint64_t *h_tables, const bj_proof_config *config, bj_setup **out);
+/* ---- one proof across several GPUs ----------------------------------------------------------------
+ * One process per GPU.  GPU `rank` of `world` owns the cosets [rank*L/world, (rank+1)*L/world) of every LDE'd column
+ * (L = fri_lde_factor), which is the contiguous range [rank*N/world, (rank+1)*N/world) of Merkle leaves of every oracle
+ * (leaf index = coset*n + i, proof.rs:89-91), hashes its own subtree down to cap_size/world cap nodes, and the ranks
+ * exchange only: cap fragments, the quotient evaluations (when a rank owns fewer than quotient_degree cosets), the first
+ * folded FRI layer and the query openings.  Main-domain work (iNTTs, copy-permutation and lookup polynomials, openings at
+ * z from the rank's own first coset) is replicated, so every rank ends with the same transcript state and the SAME proof,
+ * bit for bit the one a single GPU produces.  The library does not link a communication library: the host hands in an
+ * all-gather over device buffers (era_boojum_amd/binding.py wraps torch.distributed: nccl = RCCL over xGMI in production,
+ * gloo in the tests).  Requirements: world | fri_lde_factor, world | cap_size, quotient_degree <= fri_lde_factor. */
+typedef struct bj_comm {
+    unsigned rank, world;
+    /* every rank contributes `bytes` at d_send; on return d_recv holds world*bytes, rank-major.  Called with the
+     * context's stream idle; the data must be visible to that stream when it returns.  Non-zero return = failure. */
+    int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes);
+    void *user;
+} bj_comm;
+int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_sigmas, const uint64_t *h_constants,
+                            const uint64_t *h_tables, const bj_proof_config *config, const bj_comm *comm, bj_setup **out);
+/* bj_prove / bj_prove_dev on a sharded setup are collective: every rank calls them with the same witness. */
 void bj_setup_destroy(bj_setup *s);
 int bj_setup_cap(const bj_setup *s, uint64_t *h_cap); /* vk.setup_merkle_tree_cap: cap_size*4 u64 */
 
