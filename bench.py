@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — headline measurement of the MI355X-native Boojum proving hot path.
 
-Workload (BASELINE.json configs[2], "cfg3"): FULL PROVE of a SHA-256-shaped circuit with 2^20 rows on one MI355X —
-witness LDE + Poseidon2 Merkle tree, copy-permutation / lookup stage, quotient, openings, DEEP, FRI, queries — with the
-reference bench's parameters (60 + 32 variable columns, 8 x width-4 lookups, LDE 8, cap 16, security 100, PoW off,
+Workload (the one BASELINE.json's metric is quoted on, configs[3] "cfg4"): FULL PROVE of a SHA-256-shaped circuit with
+2^22 rows — witness LDE + Poseidon2 Merkle tree, copy-permutation / lookup stage, quotient, openings, DEEP, FRI, queries —
+with the reference bench's parameters (60 + 32 variable columns, 8 x width-4 lookups, LDE 8, cap 16, security 100, PoW off,
 Poseidon2 tree hasher; src/gadgets/sha256/mod.rs:296-375).  The circuit is the SHA-shaped satisfiable synthetic circuit of
 era_boojum_amd/synthetic.py (real SHA-256 synthesis needs the reference's Rust CS); prover cost is
 data-independent.  One "step" = one proof; the witness is resident in HBM when the timed region starts (the span the
 reference times is `prove_cpu_basic` only, sha256/mod.rs:514-527), the serialised proof is on the host when it ends.
-`value` = constraints/sec := trace rows of ALL ranks / wall seconds.  With N > 1 every rank proves its own instance
-(replicas, no data-path collective): weak scaling.  (--log-n 22 runs BASELINE's 2^22-row size on one GPU.)
+`value` = constraints/sec := trace rows proved / wall seconds.  It fits one GPU, so N = 1 proves it on one MI355X; with
+N > 1 the SAME proof is sharded over the N GPUs by LDE cosets (bj_setup_create_sharded: GPU g owns cosets
+[g*8/N, (g+1)*8/N) = a contiguous range of Merkle leaves; cap fragments, the quotient evaluations, the first folded FRI
+layer and the query openings are all-gathered over RCCL) and every rank ends with the identical proof: STRONG scaling
+(total work fixed).  `--mode replicas` instead lets every rank prove its own instance (weak scaling, no collective);
+`--log-n 20` is BASELINE's cfg3.
 
 Extra objects on the JSON line:
   roofline      the dominant kernel of a proof, the Poseidon2 leaf hashing of the witness tree: algorithmic bytes
@@ -38,7 +42,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--log-n", type=int, default=22)
+    ap.add_argument("--mode", choices=["auto", "sharded", "replicas"], default="auto")
     ap.add_argument("--fri-lde", type=int, default=8)
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
@@ -59,15 +64,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    backend = os.environ.get("BJ_BENCH_BACKEND", "nccl")     # "gloo": several ranks sharing one GPU (functional check only)
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -75,10 +87,12 @@ def main():
     log_n = args.log_n
     n = 1 << log_n
     table_bits = 4 if log_n >= 14 else 2
-    circuit = S.sha_shaped_circuit(log_n, seed=42 + rank, table_bits=table_bits)
+    sharded = world > 1 and args.mode != "replicas"
+    circuit = S.sha_shaped_circuit(log_n, seed=42 if sharded else 42 + rank, table_bits=table_bits)
     ctx = E.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security)
+    comm = E.TorchComm(ctx) if sharded else None
+    setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security, comm=comm)
     # witness resident in HBM (torch owns the allocations)
     d_vars = torch.from_numpy(circuit.variables.view(np.int64)).to(dev)
     d_mult = torch.from_numpy(circuit.multiplicities.view(np.int64)).to(dev)
@@ -89,6 +103,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    comm0 = (comm.calls, comm.bytes) if sharded else (0, 0)
     t0 = time.perf_counter()
     leaf_ms, stage_acc, proof_buf = [], {}, None
     for _ in range(args.steps):
@@ -101,14 +116,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
+    comm_calls = (comm.calls - comm0[0]) // args.steps if sharded else 0
+    comm_mb = (comm.bytes - comm0[1]) / 1e6 / args.steps if sharded else 0.0
 
-    rows_total = float(n) * world * args.steps
+    rows_total = float(n) * (1 if sharded else world) * args.steps
     value = rows_total / elapsed
     W = circuit.num_vars + 1                                  # witness leaf width (variables + multiplicities)
-    leaves = n * args.fri_lde
+    leaves = n * args.fri_lde // (world if sharded else 1)    # leaves hashed by ONE launch of the leaf kernel on this rank
     leaf_bytes = float(leaves) * (8 * W + 32)
     leaf_s = float(np.mean(leaf_ms)) / 1e3
     achieved = leaf_bytes / leaf_s / 1e9
@@ -121,19 +138,22 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if sharded else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": "cfg3: full prove of a SHA-256-shaped circuit, 2^%d rows per GPU (92 variable + 1 multiplicity "
+        "config": {"workload": "%s: full prove of a SHA-256-shaped circuit, 2^%d rows (92 variable + 1 multiplicity "
                                "columns, 8x4 lookups, LDE %d, cap %d, security %d, Poseidon2 tree + transcript, PoW off)"
-                               % (log_n, args.fri_lde, args.cap, args.security),
-                   "log_n": log_n, "rows_per_gpu": n, "circuit": "SHA-shaped satisfiable synthetic (seed 42+rank)",
-                   "sharding": "one independent proof per rank (replicas), no data-path collective",
+                               % ({22: "cfg4", 20: "cfg3"}.get(log_n, "custom"), log_n, args.fri_lde, args.cap, args.security),
+                   "log_n": log_n, "rows": n, "circuit": "SHA-shaped satisfiable synthetic (seed 42)",
+                   "sharding": ("one proof sharded by LDE cosets over %d GPUs (%d cosets = %d Merkle leaves each), all-gather of "
+                                "caps / quotient / first FRI layer / query openings, %d collectives and %.1f MB received per "
+                                "rank per proof" % (world, args.fri_lde // world, leaves, comm_calls, comm_mb))
+                               if sharded else ("one GPU" if world == 1 else "one independent proof per rank (replicas), no data-path collective"),
                    "proof_bytes": int(proof_buf.size * 8)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                     "kernel": "bj::poseidon2_leaves_kernel (witness tree: 2^%d leaves x %d elements)" % (log_n + args.fri_lde.bit_length() - 1, W),
+                     "kernel": "bj::poseidon2_leaves_kernel (witness tree: %d leaves x %d elements per launch)" % (leaves, W),
                      "kernel_ms": round(leaf_s * 1e3, 3), "algorithmic_bytes_per_launch": leaf_bytes,
                      "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},
         "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},

@@ -15,6 +15,19 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+SYNTH_SRC = os.path.join(HERE, "host", "synth_host.c")
+SYNTH_LIB = os.path.join(HERE, "libsynth_host.so")
+
+
+def build_synth(force=False):
+    """gcc build of the host-side input-synthesis helper (not on the proving path; field_np.py falls back to numpy)."""
+    if not force and os.path.exists(SYNTH_LIB) and os.path.getmtime(SYNTH_LIB) >= os.path.getmtime(SYNTH_SRC):
+        return SYNTH_LIB
+    subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=x86-64-v2", "-fopenmp", "-shared", "-fPIC", "-o", SYNTH_LIB,
+                           SYNTH_SRC])
+    return SYNTH_LIB
+
+
 def _deps():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     out.append(os.path.join(os.path.dirname(HERE), "include", "boojum_hip.h"))
@@ -23,6 +36,7 @@ def _deps():
 
 
 def build(force=False, verbose=False):
+    build_synth(force)
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(p) for p in _deps()):
         return LIB
     objs = []

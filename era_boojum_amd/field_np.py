@@ -10,6 +10,34 @@ _M32 = np.uint64(0xFFFFFFFF)
 _S32 = np.uint64(32)
 
 
+def _load_native():
+    """libsynth_host.so (era_boojum_amd/host/synth_host.c): same arithmetic in C + OpenMP; optional."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsynth_host.so")
+    if os.environ.get("BJ_SYNTH_NUMPY") or not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError:
+        return None
+    vp, sz, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64
+    lib.synth_mul.argtypes = [vp, vp, vp, sz]
+    lib.synth_mul_scalar.argtypes = [vp, u64, vp, sz]
+    lib.synth_fma2.argtypes = [vp, vp, vp, vp, vp, sz]
+    lib.synth_powers.argtypes = [u64, vp, sz]
+    for f in (lib.synth_mul, lib.synth_mul_scalar, lib.synth_fma2, lib.synth_powers):
+        f.restype = None
+    return lib
+
+
+_NATIVE = _load_native()
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
 def canon(a):
     a = np.asarray(a, dtype=np.uint64)
     return np.where(a >= _P, a - _P, a)
@@ -32,6 +60,17 @@ def sub(a, b):
 
 def mul(a, b):
     a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
+    if _NATIVE is not None and a.ndim == 1 and a.size >= 1024:
+        if b.shape == a.shape:
+            a, b = _c(a), _c(b)
+            out = np.empty_like(a)
+            _NATIVE.synth_mul(a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+            return out
+        if b.ndim == 0:
+            a = _c(a)
+            out = np.empty_like(a)
+            _NATIVE.synth_mul_scalar(a.ctypes.data, int(b), out.ctypes.data, a.size)
+            return out
     with np.errstate(over="ignore"):
         a0, a1, b0, b1 = a & _M32, a >> _S32, b & _M32, b >> _S32
         p00 = a0 * b0
@@ -54,6 +93,9 @@ def powers(base, count):
     if count <= 1:
         return out
     base = int(base) % P
+    if _NATIVE is not None:
+        _NATIVE.synth_powers(base, out.ctypes.data, count)
+        return out
     filled = 1
     step = base
     while filled < count:
@@ -69,3 +111,13 @@ def omega(log_n):
     for _ in range(32 - log_n):
         w = w * w % P
     return w
+
+
+def fma2(a, b, c, d):
+    """a*b + c*d"""
+    if _NATIVE is not None and all(np.ndim(x) == 1 for x in (a, b, c, d)) and len(a) >= 1024:
+        a, b, c, d = _c(a), _c(b), _c(c), _c(d)
+        out = np.empty_like(a)
+        _NATIVE.synth_fma2(a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, out.ctypes.data, a.size)
+        return out
+    return add(mul(a, b), mul(c, d))

@@ -198,52 +198,48 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     V = num_gp_vars + lookup_width * lookup_reps
     variables = np.zeros((V, n), dtype=np.uint64)
     constants = np.zeros((Kc, n), dtype=np.uint64)
-    # link[c, r] = flat index (col * n + row) of the cell whose identity sigma takes at (c, r); default: itself
-    link = np.arange(V * n, dtype=np.int64).reshape(V, n)
+    swaps = []   # copy cycles of length 2: (col_a, col_b, row slice) — sigma exchanges the two cells' identities
 
-    # --- rows -> gate kinds
-    u = rng.random(n)
-    kind = np.full(n, 3, dtype=np.int64)                      # index into `gates`: default Nop
-    kind[u < mix[0]] = 0
-    kind[(u >= mix[0]) & (u < mix[0] + mix[1])] = 1
-    kind[(u >= mix[0] + mix[1]) & (u < sum(mix))] = 2
+    # --- rows -> gate kinds, in contiguous blocks (prover cost does not depend on the arrangement; slices keep the
+    #     generation of a 2^22-row circuit to seconds)
+    cuts = [0, int(n * mix[0]), int(n * (mix[0] + mix[1])), int(n * sum(mix)), n]
     for gi, g in enumerate(gates):
-        rows = np.nonzero(kind == gi)[0]
+        lo, hi = cuts[gi], cuts[gi + 1]
+        rows, m = slice(lo, hi), hi - lo
+        if m == 0:
+            continue
         d = len(g.path)
         for i, bit in enumerate(g.path):
             constants[i, rows] = 1 if bit else 0
         if g.kind == GATE_CONSTANT_ALLOCATOR:
             for r in range(g.reps):
-                c = rand_f(rows.size)
+                c = rand_f(m)
                 constants[d + r * g.const_stride, rows] = c
                 variables[r * g.var_stride, rows] = c
         elif g.kind == GATE_FMA:
-            qc, lc = rand_f(rows.size), rand_f(rows.size)
+            qc, lc = rand_f(m), rand_f(m)
             constants[d, rows], constants[d + 1, rows] = qc, lc
             prev_d = None
             for r in range(g.reps):
-                a, b = rand_f(rows.size), rand_f(rows.size)
-                c = rand_f(rows.size) if prev_d is None else prev_d      # c_k is a copy of d_{k-1}
-                dd = F.add(F.mul(qc, F.mul(a, b)), F.mul(lc, c))
+                a, b = rand_f(m), rand_f(m)
+                c = rand_f(m) if prev_d is None else prev_d      # c_k is a copy of d_{k-1}
+                dd = F.fma2(qc, F.mul(a, b), lc, c)
                 base = r * g.var_stride
                 variables[base, rows], variables[base + 1, rows] = a, b
                 variables[base + 2, rows], variables[base + 3, rows] = c, dd
-                if prev_d is not None:   # copy cycle of length 2: (row, base+2) <-> (row, base-1)
-                    link[base + 2, rows] = (base - 1) * n + rows
-                    link[base - 1, rows] = (base + 2) * n + rows
+                if prev_d is not None:
+                    swaps.append((base + 2, base - 1, rows))
                 prev_d = dd
         elif g.kind == GATE_REDUCTION4:
-            cs = [rand_f(rows.size) for _ in range(4)]
+            cs = [rand_f(m) for _ in range(4)]
             for i in range(4):
                 constants[d + i, rows] = cs[i]
             for r in range(g.reps):
                 base = r * g.var_stride
-                acc = np.zeros(rows.size, dtype=np.uint64)
+                v = [rand_f(m) for _ in range(4)]
                 for i in range(4):
-                    v = rand_f(rows.size)
-                    variables[base + i, rows] = v
-                    acc = F.add(acc, F.mul(v, cs[i]))
-                variables[base + 4, rows] = acc
+                    variables[base + i, rows] = v[i]
+                variables[base + 4, rows] = F.add(F.fma2(v[0], cs[0], v[1], cs[1]), F.fma2(v[2], cs[2], v[3], cs[3]))
     # --- lookups: every row looks 8 tuples up in ONE table (shared table id in a constant column)
     tabs = make_tables(table_bits)
     total_len = sum(t.shape[0] for t in tabs)
@@ -261,19 +257,21 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     sizes = np.array([t.shape[0] for t in tabs])
     offs = np.array(offs)
     mult = np.zeros(n, dtype=np.uint64)
+    small = np.ascontiguousarray(tables[:lookup_width, :total_len])
     for rep in range(lookup_reps):
         pick = offs[tid] + (rng.integers(0, 1 << 62, size=n) % sizes[tid])
         for j in range(lookup_width):
-            variables[num_gp_vars + rep * lookup_width + j] = tables[j, pick]
-        np.add.at(mult, pick, np.uint64(1))
-    # --- sigma = id o link,  id(c, r) = k_c * omega^r
+            variables[num_gp_vars + rep * lookup_width + j] = small[j][pick]
+        mult += np.bincount(pick, minlength=n).astype(np.uint64)
+    # --- sigma = id o link,  id(c, r) = k_c * omega^r; linked cells (the FMA chains) exchange identities
     ks = non_residues(V, n)
     om = F.powers(F.omega(log_n), n)
     sigmas = np.empty((V, n), dtype=np.uint64)
-    link_col, link_row = link // n, link % n
-    ks_arr = np.array(ks, dtype=np.uint64)
     for c in range(V):
-        sigmas[c] = F.mul(ks_arr[link_col[c]], om[link_row[c]])
+        sigmas[c] = F.mul(om, np.uint64(ks[c]))
+    for ca, cb, rows in swaps:
+        ia, ib = sigmas[ca, rows].copy(), sigmas[cb, rows].copy()
+        sigmas[ca, rows], sigmas[cb, rows] = ib, ia
     pubs = []
     for i in range(num_public_inputs):
         col, row = (7 * i + 3) % num_gp_vars, (11 * i + 5) % n
