@@ -67,40 +67,40 @@ __device__ __forceinline__ W3 w3_shl64(u64 a) {   // a * 2^K as a 96-bit integer
     const u32 lo = gl::lo32(a), hi = gl::hi32(a);
     return {lo << K, __builtin_amdgcn_alignbit(hi, lo, 32 - K), hi >> (32 - K)};
 }
+// lo + m * (2^32 - 1) as ONE v_mad_u64_u32; e = EPS where the 64-bit sum wrapped, else 0.  Carry-writing VALU ops
+// (v_add_co/v_addc_co/v_sub_co/...) cost ~2x a plain op on gfx950 and each carry link needs 2 wait states, so one
+// multiply-add replaces the (m << 32) - m construction and its 64-bit add (4 carry ops).  The s_nop covers the
+// VALU-SGPR-write -> VALU-read wait states for the mask (the compiler cannot see inside the string).
+__device__ __forceinline__ u64 mad_eps(u32 m, u64 lo, u32 &e) {
+    u64 r, cm;
+    asm("v_mad_u64_u32 %[r], %[cm], %[m], -1, %[lo]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %[e], 0, -1, %[cm]"
+        : [r] "=&v"(r), [cm] "=&s"(cm), [e] "=v"(e)
+        : [m] "v"(m), [lo] "v"(lo));
+    return r;
+}
 // 96-bit integer with w2 < 2^31 -> weak residue:  (w1:w0) + w2 * (2^32 - 1), "+EPS" once on carry.
 // No second carry: after a wrap the sum is < w2 * 2^32 <= 2^63, far below 2^64 - EPS.
 __device__ __forceinline__ u64 w3_reduce(W3 a) {
-    u32 b5, b6, c1, c2, c3, c4;
-    u32 m0 = __builtin_subc(0u, a.w2, 0u, &b5);          // w2 * (2^32 - 1) = (w2 << 32) - w2
-    u32 m1 = __builtin_subc(a.w2, 0u, b5, &b6);
-    u32 r0 = __builtin_addc(a.w0, m0, 0u, &c1);
-    u32 r1 = __builtin_addc(a.w1, m1, c1, &c2);
-    u32 e = c2 ? 0xFFFFFFFFu : 0u;
-    r0 = __builtin_addc(r0, e, 0u, &c3);
-    r1 = __builtin_addc(r1, 0u, c3, &c4);
-    return gl::pack(r0, r1);
+    u32 e;
+    u64 r = mad_eps(a.w2, gl::pack(a.w0, a.w1), e);
+    return r + (u64)e;
 }
-// weak x weak -> weak (same limbs as gl::mul, reduction without the final canonicalisation)
-//   t0 = lo - hi_hi, "-EPS" on borrow (then t0 >= 2^64 - 2^32 > EPS, no second borrow)
-//   t1 = hi_lo * EPS <= (2^32-1)^2;  r = t0 + t1, "+EPS" on carry (then r < 2^64 - 2^33, no second carry)
+// weak x weak -> weak (same limbs as gl::mul, reduction without the final canonicalisation):
+//   V = lo + hl*EPS - hh  in (-2^32, 2^65 - 2^33);   R = lo + hl*EPS mod 2^64 (carry c), then R - hh mod 2^64 (borrow b)
+//   c only: true value = R + 2^64 = R + EPS (R < 2^64 - 2^33, no second carry);  b only: R - EPS (R > 2^64 - 2^32);
+//   both: the wrap and the borrow cancel.  So W = R + (c ? EPS : 0) - (b ? EPS : 0) mod 2^64 in every case.
 __device__ __forceinline__ u64 mulw(u64 a, u64 b) {
-    u32 hh, hl;
+    u32 hh, hl, e;
     u64 lo;
     gl::mul_limbs(a, b, hh, hl, lo);
-    u32 b1, b2, b3, b4, b5, b6, c1, c2, c3, c4;
-    u32 d0 = __builtin_subc(gl::lo32(lo), hh, 0u, &b1);
-    u32 d1 = __builtin_subc(gl::hi32(lo), 0u, b1, &b2);
-    u32 e = b2 ? 0xFFFFFFFFu : 0u;
-    d0 = __builtin_subc(d0, e, 0u, &b3);
-    d1 = __builtin_subc(d1, 0u, b3, &b4);
-    u32 m0 = __builtin_subc(0u, hl, 0u, &b5);
-    u32 m1 = __builtin_subc(hl, 0u, b5, &b6);
-    u32 r0 = __builtin_addc(d0, m0, 0u, &c1);
-    u32 r1 = __builtin_addc(d1, m1, c1, &c2);
-    u32 f = c2 ? 0xFFFFFFFFu : 0u;
-    r0 = __builtin_addc(r0, f, 0u, &c3);
-    r1 = __builtin_addc(r1, 0u, c3, &c4);
-    return gl::pack(r0, r1);
+    u64 r = mad_eps(hl, lo, e);
+    u32 b1, b2;
+    u32 d0 = __builtin_subc(gl::lo32(r), hh, 0u, &b1);
+    u32 d1 = __builtin_subc(gl::hi32(r), 0u, b1, &b2);
+    u32 f = b2 ? 0xFFFFFFFFu : 0u;
+    return gl::pack(d0, d1) + (u64)e - (u64)f;
 }
 // weak + canonical constant -> weak: "+EPS" on carry; the wrapped sum is < rc < p, so adding EPS cannot carry again
 __device__ __forceinline__ u64 addw_rc(u64 x, u64 rc) {
