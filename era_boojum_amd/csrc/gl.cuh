@@ -56,13 +56,33 @@ __host__ __device__ __forceinline__ u64 dbl(u64 a) { return add(a, a); }
 
 // (hi_hi : hi_lo : lo) = 128-bit value -> canonical residue, using 2^64 = 2^32 - 1 and 2^96 = -1 (mod p)
 __host__ __device__ __forceinline__ u64 reduce_limbs(u32 hi_hi, u32 hi_lo, u64 lo) {
-    u32 b1, b2, b3, b4, b5, b6, c1, c2, c3, c4;
-    // t0 = lo - hi_hi  (+p on borrow)
+    u32 b1, b2, b3, b4;
+    // t0 = lo - hi_hi  (+p on borrow), in [0, 2^64)
     u32 d0 = __builtin_subc(lo32(lo), hi_hi, 0u, &b1);
     u32 d1 = __builtin_subc(hi32(lo), 0u, b1, &b2);
     u32 e = b2 ? 0xFFFFFFFFu : 0u;
     d0 = __builtin_subc(d0, e, 0u, &b3);
     d1 = __builtin_subc(d1, 0u, b3, &b4);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BJ_GL_REDUCE_CHAINS)
+    // r = t0 + hi_lo * EPS in ONE multiply-add; "+EPS" when the sum wrapped (then r < 2^64 - 2^33: no second wrap, result
+    // < p) or when r >= p (r - p = r + EPS mod 2^64).  Carry-writing VALU ops are the scarce resource on gfx950 (one per
+    // ~4.4 cycles per SIMD), this form needs 2 instead of 6 of them.  gfx950 needs 2 wait states between a VALU write of
+    // an SGPR/VCC and a VALU read of it as a mask; the compiler cannot see inside the string, so they are placed by
+    // hand (v_cmp + s_nop 0 after the mad, s_nop 0 + v_cndmask after the v_cmp).  No SALU combination of the masks:
+    // an s_or_b64 right after the VALU writes read stale values on a lone wave.
+    u64 r, cm;
+    u32 fix;
+    asm("v_mad_u64_u32 %[r], %[cm], %[m], -1, %[t0]\n\t"
+        "v_cmp_ge_u64 vcc, %[r], %[p]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 %[fix], 0, -1, %[cm]\n\t"
+        "v_cndmask_b32 %[fix], %[fix], -1, vcc"
+        : [r] "=&v"(r), [cm] "=&s"(cm), [fix] "=&v"(fix)
+        : [m] "v"(hi_lo), [t0] "v"(pack(d0, d1)), [p] "s"(P)
+        : "vcc");
+    return r + (u64)fix;
+#else
+    u32 b5, b6, c1, c2, c3, c4;
     // t1 = hi_lo * (2^32 - 1) = (hi_lo << 32) - hi_lo
     u32 m0 = __builtin_subc(0u, hi_lo, 0u, &b5);
     u32 m1 = __builtin_subc(hi_lo, 0u, b5, &b6);
@@ -72,6 +92,7 @@ __host__ __device__ __forceinline__ u64 reduce_limbs(u32 hi_hi, u32 hi_lo, u64 l
     u32 q0 = __builtin_addc(r0, 0xFFFFFFFFu, 0u, &c3);
     u32 q1 = __builtin_addc(r1, 0u, c3, &c4);
     return (c2 | c4) ? pack(q0, q1) : pack(r0, r1);
+#endif
 }
 __host__ __device__ __forceinline__ u64 reduce128(u64 hi, u64 lo) { return reduce_limbs(hi32(hi), lo32(hi), lo); }
 
