@@ -28,6 +28,8 @@ def _load_native():
     lib.synth_powers.argtypes = [u64, vp, sz]
     for f in (lib.synth_mul, lib.synth_mul_scalar, lib.synth_fma2, lib.synth_powers):
         f.restype = None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    lib.synth_set_threads(max(1, min(16, cores)))
     return lib
 
 

@@ -2,8 +2,13 @@
  * SHA-shaped circuits the benches and tests prove).  Not on the proving path and not part of libboojum_hip.so: the
  * numpy implementation in field_np.py computes the same thing, this one is ~50x faster so that a 2^22-row circuit is
  * generated in seconds.  Built by era_boojum_amd/build.py with gcc -O3 -fopenmp. */
+#include <omp.h>
 #include <stddef.h>
 #include <stdint.h>
+
+/* cap the OpenMP team: the default (one thread per host core, 256 on the GPU boxes) costs more in fork/join than the
+ * loops below take */
+void synth_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
 
 #define GL_P 0xFFFFFFFF00000001ULL
 
