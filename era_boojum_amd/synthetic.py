@@ -248,7 +248,7 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     tables = np.zeros((lookup_width + 1, n), dtype=np.uint64)
     offs, o = [], 0
     for ti, t in enumerate(tabs):
-        tables[:lookup_width, o:o + t.shape[0]] = t.T
+        tables[:lookup_width, o:o + t.shape[0]] = t.T[:lookup_width]      # narrower lookups use the projection
         tables[lookup_width, o:o + t.shape[0]] = ti + 1         # table ids start at 1 (reference_cs.rs:24)
         offs.append(o)
         o += t.shape[0]

@@ -67,3 +67,24 @@ def test_hip_prover_without_lookups():
     _compare(pg, po)
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 4, 8), pg, verbose=True)
     gsetup.close()
+
+
+@pytest.mark.parametrize("log_n,kw,fri_lde,cap,sec", [
+    (10, dict(num_gp_vars=24, lookup_width=3, lookup_reps=4, num_public_inputs=0), 8, 16, 30),   # fixture-like width-3 lookups, no public inputs
+    (11, dict(num_gp_vars=40, lookup_width=4, lookup_reps=2, num_public_inputs=3), 16, 32, 40),  # LDE 16, cap 32
+    (9, dict(num_gp_vars=60, lookup_width=3, lookup_reps=8, num_public_inputs=1), 4, 4, 20),     # LDE 4 = quotient degree, cap 4
+    (13, dict(num_gp_vars=20, lookup_width=4, lookup_reps=1, num_public_inputs=2, mix=(0.2, 0.2, 0.2)), 8, 8, 60),
+])
+def test_hip_proof_equals_oracle_proof_other_geometries(log_n, kw, fri_lde, cap, sec):
+    """Column counts, lookup width / repetitions, public inputs, LDE factor and cap size away from the bench's."""
+    c = S.sha_shaped_circuit(log_n, seed=7 * log_n, table_bits=2, **kw)
+    S.check_satisfied(c)
+    osetup = OP.Setup(c, fri_lde, cap, threads=8)
+    po = OP.prove(c, osetup, fri_lde, cap, security_level=sec, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, fri_lde, cap, sec)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=sec)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), fri_lde, cap), pg, verbose=True)
+    gsetup.close()
