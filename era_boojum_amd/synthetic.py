@@ -114,6 +114,7 @@ def place_selectors(gates, num_constant_cols_geometry):
                 _paths(tree, [], paths)
                 for g in order:
                     g.path = paths[id(g)]
+                place_selectors.last_tree = tree       # kept for the VerificationKey wire format (wire_format.py)
                 return _stats(tree, 0)
         target *= 2
     raise ValueError("no selector placement found")
@@ -171,6 +172,8 @@ class Circuit:
     non_residues: list
     public_inputs: list             # [(col, row, value)]
     total_tables_len: int
+    selector_tree: object = None    # ('gate', GateDesc) | ('fork', left, right); left = constant, right = 1 - constant
+    max_allowed_constraint_degree: int = 4
 
     @property
     def n(self):
@@ -277,7 +280,8 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         col, row = (7 * i + 3) % num_gp_vars, (11 * i + 5) % n
         pubs.append((col, row, int(variables[col, row])))
     return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
-                   table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len)
+                   table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len,
+                   selector_tree=getattr(place_selectors, "last_tree", None))
 
 
 def check_satisfied(c: Circuit):
