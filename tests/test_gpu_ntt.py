@@ -9,7 +9,7 @@ from gpu_util import DevBuf, ctx, rand_gl, P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("log_n", list(range(0, 15)) + [16, 17])
+@pytest.mark.parametrize("log_n", list(range(0, 20)) + [22])
 @pytest.mark.parametrize("coset", [1, 7])
 def test_forward_matches_oracle(log_n, coset):
     rng = np.random.default_rng(1000 + log_n)
@@ -40,7 +40,7 @@ def test_forward_random_coset_and_strided_columns():
     d.free()
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 12, 13, 16])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 12, 13, 14, 15, 16, 18])
 @pytest.mark.parametrize("coset", [1, 7])
 def test_inverse_matches_oracle_and_roundtrips(log_n, coset):
     rng = np.random.default_rng(2000 + log_n)
@@ -57,7 +57,7 @@ def test_inverse_matches_oracle_and_roundtrips(log_n, coset):
     d.free(); out.free()
 
 
-@pytest.mark.parametrize("log_n,log_lde", [(0, 1), (3, 1), (6, 3), (10, 2), (13, 3), (14, 1)])
+@pytest.mark.parametrize("log_n,log_lde", [(0, 1), (3, 1), (6, 3), (10, 2), (13, 3), (14, 1), (15, 2), (17, 3), (18, 3), (19, 1)])
 def test_lde_matches_oracle(log_n, log_lde):
     rng = np.random.default_rng(3000 + log_n)
     n_cols = 3
