@@ -96,10 +96,17 @@ __device__ __forceinline__ u64 mulw(u64 a, u64 b) {
     u64 lo;
     gl::mul_limbs(a, b, hh, hl, lo);
     u64 r = mad_eps(hl, lo, e);
-    u32 b1, b2;
-    u32 d0 = __builtin_subc(gl::lo32(r), hh, 0u, &b1);
-    u32 d1 = __builtin_subc(gl::hi32(r), 0u, b1, &b2);
-    u32 f = b2 ? 0xFFFFFFFFu : 0u;
+    // r - hh with the borrow chain written out: the compiler lowers the C borrow idiom to cndmask + sub pairs (8
+    // instructions for what is sub, subb, cndmask); the s_nops are the wait states between carry producer and consumer
+    u32 d0, d1, f;
+    asm("v_sub_co_u32 %[d0], vcc, %[r0], %[hh]\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 %[d1], vcc, 0, %[r1], vcc\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 %[f], 0, -1, vcc"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [f] "=v"(f)
+        : [r0] "v"(gl::lo32(r)), [r1] "v"(gl::hi32(r)), [hh] "v"(hh)
+        : "vcc");
     return gl::pack(d0, d1) + (u64)e - (u64)f;
 }
 // weak + canonical constant -> weak: "+EPS" on carry; the wrapped sum is < rc < p, so adding EPS cannot carry again
@@ -142,9 +149,34 @@ __device__ __forceinline__ void ext_mds(u64 (&s)[12]) {
     }
 }
 
+// a * 2^K + sum with multiply-adds instead of shift / 96-bit add / fold (9 -> 6 instructions, 4 -> 1 carry op):
+//   a = a0 + a1*2^32,  sum = sl + sh*2^32 with sl, sh < 2^36 (sums of the low / high words of the state)
+//   A = a0*2^K + sl                < 2^47          (no carry)
+//   B = a1*2^K + sh                < 2^47
+//   a*2^K + sum = A + B*2^32 = A + B_hi*2^64 + B_lo*2^32  ==  A + B_hi*EPS + B_lo*2^32      (B_hi < 2^15)
+//   T = A + B_hi*EPS < 2^48 (no carry);  result = T + (B_lo << 32): one add on the high word, "+EPS" on its carry
+//   (after a wrap the value is < 2^48, so the correction cannot carry again).
+// The power of two travels in an SGPR (VOP3 has no literal operand on gfx950).
+__device__ __forceinline__ u64 mad64(u32 x, u32 y, u64 c) {   // x*y + c, carry-out discarded (callers prove there is none)
+    u64 r;
+    asm("v_mad_u64_u32 %[r], vcc, %[x], %[y], %[c]" : [r] "=v"(r) : [x] "v"(x), [y] "s"(y), [c] "v"(c) : "vcc");
+    return r;
+}
+__device__ __forceinline__ u64 acc32(u32 x, u64 c) {   // c + x (zero-extended), c < 2^63
+    u64 r;
+    asm("v_mad_u64_u32 %[r], vcc, %[x], 1, %[c]" : [r] "=v"(r) : [x] "v"(x), [c] "v"(c) : "vcc");
+    return r;
+}
 template <unsigned K>
-__device__ __forceinline__ u64 shl_plus(u64 a, W3 sum) {   // a * 2^K + sum  (< 2^64 * (2^14 + 12))
-    return w3_reduce(w3_add(w3_shl64<K>(a), sum));
+__device__ __forceinline__ u64 shl_plus(u64 a, u64 sum_lo, u64 sum_hi) {
+    const u64 A = K ? mad64(gl::lo32(a), 1u << K, sum_lo) : acc32(gl::lo32(a), sum_lo);
+    const u64 B = K ? mad64(gl::hi32(a), 1u << K, sum_hi) : acc32(gl::hi32(a), sum_hi);
+    u64 T;
+    asm("v_mad_u64_u32 %[t], vcc, %[b], -1, %[a]" : [t] "=v"(T) : [b] "v"(gl::hi32(B)), [a] "v"(A) : "vcc");
+    u32 c, hi, e;
+    hi = __builtin_addc(gl::hi32(T), gl::lo32(B), 0u, &c);
+    e = c ? 0xFFFFFFFFu : 0u;
+    return gl::pack(gl::lo32(T), hi) + (u64)e;
 }
 
 // state in: any u64 words; state out: weak words (canonicalise what leaves the sponge with gl::canon)
@@ -160,22 +192,27 @@ __device__ __forceinline__ void poseidon2_permutation(u64 (&s)[12]) {
 #pragma unroll 1
     for (int i = 0; i < 22; i++, r++) {
         s[0] = pow7w(addw_rc(s[0], POSEIDON_RC[12 * r]));
-        W3 sum = w3_sum64(s[0], s[1]);
+        // sum of the state as two carry-free accumulators: sl = sum of the low words, sh = sum of the high words (< 2^36
+        // each), one multiply-add per word instead of a 96-bit carry chain;  sum = sl + sh * 2^32
+        u64 sl = (u64)gl::lo32(s[0]), sh = (u64)gl::hi32(s[0]);
 #pragma unroll
-        for (int k = 2; k < 12; k++) sum = w3_add64(sum, s[k]);
+        for (int k = 1; k < 12; k++) {
+            sl = acc32(gl::lo32(s[k]), sl);
+            sh = acc32(gl::hi32(s[k]), sh);
+        }
         // internal matrix 1 + diag(2^{4,14,11,8,0,5,2,9,13,6,3,12})  (poseidon2/params.rs:38-39)
-        s[0] = shl_plus<4>(s[0], sum);
-        s[1] = shl_plus<14>(s[1], sum);
-        s[2] = shl_plus<11>(s[2], sum);
-        s[3] = shl_plus<8>(s[3], sum);
-        s[4] = w3_reduce(w3_add64(sum, s[4]));
-        s[5] = shl_plus<5>(s[5], sum);
-        s[6] = shl_plus<2>(s[6], sum);
-        s[7] = shl_plus<9>(s[7], sum);
-        s[8] = shl_plus<13>(s[8], sum);
-        s[9] = shl_plus<6>(s[9], sum);
-        s[10] = shl_plus<3>(s[10], sum);
-        s[11] = shl_plus<12>(s[11], sum);
+        s[0] = shl_plus<4>(s[0], sl, sh);
+        s[1] = shl_plus<14>(s[1], sl, sh);
+        s[2] = shl_plus<11>(s[2], sl, sh);
+        s[3] = shl_plus<8>(s[3], sl, sh);
+        s[4] = shl_plus<0>(s[4], sl, sh);
+        s[5] = shl_plus<5>(s[5], sl, sh);
+        s[6] = shl_plus<2>(s[6], sl, sh);
+        s[7] = shl_plus<9>(s[7], sl, sh);
+        s[8] = shl_plus<13>(s[8], sl, sh);
+        s[9] = shl_plus<6>(s[9], sl, sh);
+        s[10] = shl_plus<3>(s[10], sl, sh);
+        s[11] = shl_plus<12>(s[11], sl, sh);
     }
 #pragma unroll 1
     for (int i = 0; i < 4; i++, r++) {
