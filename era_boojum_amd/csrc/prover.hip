@@ -522,8 +522,26 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             if (s.c1) ptrs.push_back(s.c1);
         }
         std::vector<u64> raw(2 * ptrs.size());
-        r = bj_barycentric_eval_batch(ctx, ptrs.data(), (unsigned)ptrs.size(), log_n, w.p, w.p + n, raw.data());
-        if (r) return r;
+        const size_t P = ptrs.size(), per = (P + sh.world - 1) / sh.world;
+        if (sh.world > 1 && P >= 8 * (size_t)sh.world && 2 * per * sh.world <= 2048) {
+            // many columns: rank r evaluates the slice [r*per, (r+1)*per) on its own coset, the values are all-gathered
+            // (the value of a polynomial does not depend on the coset it was interpolated from)
+            const size_t lo = (size_t)sh.rank * per, hi = lo + per < P ? lo + per : P;
+            std::vector<u64> mine(2 * per, 0);
+            if (hi > lo) {
+                r = bj_barycentric_eval_batch(ctx, ptrs.data() + lo, (unsigned)(hi - lo), log_n, w.p, w.p + n, mine.data());
+                if (r) return r;
+            }
+            u64 *d_part = ctx->d_small + 64 + 64 * 32, *d_all = d_part + 2048;   // the 4096-u64 gather area of the context
+            if ((r = bj_memcpy_h2d(ctx, d_part, mine.data(), 2 * per * 8))) return r;
+            if ((r = bj::all_gather(ctx, sh, d_part, d_all, 2 * per))) return r;
+            std::vector<u64> all(2 * per * sh.world);
+            if ((r = bj_memcpy_d2h(ctx, all.data(), d_all, all.size() * 8))) return r;
+            std::memcpy(raw.data(), all.data(), raw.size() * 8);
+        } else {
+            r = bj_barycentric_eval_batch(ctx, ptrs.data(), (unsigned)P, log_n, w.p, w.p + n, raw.data());
+            if (r) return r;
+        }
         vals.clear();
         size_t k = 0;
         for (auto &s : ss) {
