@@ -148,7 +148,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "strong" if sharded else "weak",
+        "scaling": "weak" if (args.mode == "replicas") else "strong",   # --gpus N shards the SAME 2^22-row proof: total work fixed
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",

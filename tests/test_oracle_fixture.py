@@ -216,3 +216,14 @@ def test_last_fri_layer_leaves_in_cap(fixture_json):
         fq = q["fri_queries"][5]
         assert fq["proof"] == []
         assert tuple(int(x) for x in O.hash_leaf(fq["leaf_elements"])) in cap
+
+
+def test_lookup_sum_relation_at_zero(fixture_json):
+    """Log-derivative lookup argument (verifier.rs:1139-1260): sum_i A_i(0) == B(0) over the multiplicity polys — pins
+    the number and order of the lookup polynomials in `values_at_0` (8 sub-arguments A_i, then B) on the golden proof."""
+    fx = fixture_json
+    v0 = fx["values_at_0"]
+    reps = fx["geometry"]["lookup"]["UseSpecializedColumnsWithTableIdAsConstant"]["num_repetitions"]
+    assert len(v0) == reps + 1
+    for comp in (0, 1):
+        assert sum(e[comp] for e in v0[:reps]) % P == v0[reps][comp]
