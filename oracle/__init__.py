@@ -373,3 +373,12 @@ def deep_quotient_point(f, values, challenges, at, x):
                                   _p(_arr(values).reshape(-1)), _p(_arr(challenges).reshape(-1)), _p(_arr(at)),
                                   C.c_uint64(x), _p(out))
     return (int(out[0]), int(out[1]))
+
+
+def poseidon_round_constants():
+    """The 30 x 12 round-constant table of oracle/poseidon_rc.h (ALL_ROUND_CONSTANTS, shared by Poseidon and Poseidon2)."""
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "poseidon_rc.h")).read()
+    vals = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]{16})ULL", txt)]
+    assert len(vals) == 360
+    return [vals[12 * r:12 * r + 12] for r in range(30)]

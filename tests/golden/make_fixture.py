@@ -29,6 +29,9 @@ out = {
         'quotient_degree': fp['quotient_degree'],
         'public_inputs_locations': fp['public_inputs_locations'],
         'table_ids_column_idxes': fp['table_ids_column_idxes'],
+        'total_tables_len': fp['total_tables_len'],
+        'selectors_placement': fp['selectors_placement'],
+        'max_allowed_constraint_degree': fp['parameters']['max_allowed_constraint_degree'],
     },
     'setup_merkle_tree_cap': vk['setup_merkle_tree_cap'],
     'public_inputs': p['public_inputs'],

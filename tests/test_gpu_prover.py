@@ -88,3 +88,31 @@ def test_hip_proof_equals_oracle_proof_other_geometries(log_n, kw, fri_lde, cap,
     _compare(pg, po)
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), fri_lde, cap), pg, verbose=True)
     gsetup.close()
+
+
+def test_golden_pinned_quotient_identity_accepts_hip_proof():
+    """The quotient identity code that holds on the reference's golden proof (oracle/golden_quotient.py), fed with the
+    VerificationKey JSON emitted for our circuit, accepts the HIP prover's openings."""
+    import json
+    import oracle as O
+    from oracle import golden_quotient as GQ
+    from era_boojum_amd import wire_format as W
+    c = S.sha_shaped_circuit(10, seed=21, table_bits=2)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    buf, _ = gsetup.prove()
+    proof = proof_format.parse(buf, security_level=30)
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, gsetup.cap(), 8, 16)))
+    t = O.Transcript()
+    t.absorb_cap(gsetup.cap())
+    t.absorb(proof["public_inputs"])
+    t.absorb_cap(np.array(proof["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(proof["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(proof["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), [g.name for g in c.gates], [], c.non_residues,
+                                    dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    proof["values_at_z"], proof["values_at_z_omega"][0])
+    assert lhs == rhs
+    gsetup.close()

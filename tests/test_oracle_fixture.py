@@ -227,3 +227,63 @@ def test_lookup_sum_relation_at_zero(fixture_json):
     assert len(v0) == reps + 1
     for comp in (0, 1):
         assert sum(e[comp] for e in v0[:reps]) % P == v0[reps][comp]
+
+
+GOLDEN_GENERAL_GATES = ["ConstantsAllocatorGate", "U8x4FMAGate", "Poseidon2FlattenedGate", "DotProductGate<4>", "ZeroCheckGate",
+                        "FmaGateInBaseFieldWithoutConstant", "UIntXAddGate", "SelectionGate", "ParallelSelectionGate<4>", "NopGate",
+                        "ReductionGate<4>"]   # evaluator order of the inner circuit, recursive_verifier.rs:2302-2362
+
+
+def test_quotient_identity_of_the_golden_proof(fixture_json, replay):
+    """verifier.rs:1090-1810 on the reference's own proof: sum_i alpha^i term_i(z) == t(z) * (z^n - 1) with the lookup terms,
+    the BooleanConstraintGate over its specialized column, the eleven evaluators over general-purpose columns behind their
+    selector paths (incl. the 118-relation Poseidon2 flattened gate), (z(x)-1)*L_1 and the 20 copy-permutation chunks.
+    Pins the alpha order, the selector-path convention and the copy-permutation / lookup / gate formulas that
+    oracle/prover.py, oracle/verifier.py and the HIP prover share."""
+    from oracle import golden_quotient as GQ
+    from era_boojum_amd.synthetic import non_residues
+    fx = fixture_json
+    t = O.Transcript()
+    t.absorb_cap(fx["setup_merkle_tree_cap"])
+    t.absorb(fx["public_inputs"])
+    t.absorb_cap(fx["witness_oracle_cap"])
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    ch = dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=replay["alpha"], z=replay["z"])
+    assert (beta, gamma) == (replay["beta"], replay["gamma"])
+    nr = non_residues(155, fx["geometry"]["domain_size"])                     # make_non_residues, utils.rs:636-688
+    lhs, rhs = GQ.quotient_identity(fx["geometry"], GOLDEN_GENERAL_GATES, [("BooleanConstraintGate", 1)], nr, ch,
+                                    fx["values_at_z"], fx["values_at_z_omega"][0])
+    assert lhs == rhs
+    # and it is a real check: any single opening changed breaks it
+    bad = [list(v) for v in fx["values_at_z"]]
+    bad[17][0] = (bad[17][0] + 1) % P
+    lhs2, rhs2 = GQ.quotient_identity(fx["geometry"], GOLDEN_GENERAL_GATES, [("BooleanConstraintGate", 1)], nr, ch,
+                                      bad, fx["values_at_z_omega"][0])
+    assert lhs2 != rhs2
+
+
+def test_golden_pinned_identity_accepts_our_proofs():
+    """The same (golden-pinned) identity code, fed with the VerificationKey JSON this repository emits for its own circuit
+    class, accepts a proof of the oracle prover — ties the conventions pinned above to the provers under test."""
+    import json
+    from oracle import golden_quotient as GQ
+    from oracle import prover as OP
+    from era_boojum_amd import synthetic as S, wire_format as W
+    c = S.sha_shaped_circuit(9, seed=11, table_bits=2)
+    setup = OP.Setup(c, 4, 8, threads=2)
+    proof = OP.prove(c, setup, 4, 8, security_level=20, threads=2)
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, np.asarray(setup.cap), 4, 8)))
+    t = O.Transcript()
+    t.absorb_cap(np.asarray(setup.cap))
+    t.absorb(proof["public_inputs"])
+    t.absorb_cap(np.array(proof["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(proof["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(proof["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    gates = [g.name for g in c.gates]
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), gates, [], c.non_residues,
+                                    dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    proof["values_at_z"], proof["values_at_z_omega"][0])
+    assert lhs == rhs
