@@ -76,6 +76,23 @@ int arena_reset(bj_ctx *ctx, size_t need_elems) {
     return BJ_OK;
 }
 
+void *tmp_alloc(bj_ctx *ctx, size_t bytes, bool *from_arena) {
+    *from_arena = false;
+    if (ctx->in_proof) {
+        if (u64 *p = arena_alloc(ctx, (bytes + 7) / 8)) {
+            *from_arena = true;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
+    return p;
+}
+void tmp_free(bj_ctx *ctx, void *p, bool from_arena) {
+    (void)ctx;
+    if (p && !from_arena) (void)hipFree(p);
+}
+
 u64 *arena_alloc(bj_ctx *ctx, size_t elems) {
     size_t start = (ctx->arena_off + 63) & ~(size_t)63;   // 512-byte alignment
     if (start + elems > ctx->arena_elems) return nullptr;

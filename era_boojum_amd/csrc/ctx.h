@@ -25,6 +25,7 @@ struct bj_ctx {
     // synchronising); grown on demand, reset at the start of every bj_prove_dev
     gl::u64 *arena = nullptr;
     size_t arena_elems = 0, arena_off = 0;
+    bool in_proof = false;       // bj_prove_dev is running: temporaries come out of the arena instead of hipMalloc
 };
 
 namespace bj {
@@ -34,6 +35,9 @@ int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
 int arena_reset(bj_ctx *ctx, size_t need_elems);
 gl::u64 *arena_alloc(bj_ctx *ctx, size_t elems);   // nullptr if the reservation was too small
+// short-lived device memory: from the arena inside a proof (no hipMalloc/hipFree, no implicit syncs), hipMalloc otherwise
+void *tmp_alloc(bj_ctx *ctx, size_t bytes, bool *from_arena);
+void tmp_free(bj_ctx *ctx, void *p, bool from_arena);
 int lde_cosets_strided(bj_ctx *ctx, const gl::u64 *d_mono, size_t in_col_stride, gl::u64 *d_out, size_t out_col_stride,
                        unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count);
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }

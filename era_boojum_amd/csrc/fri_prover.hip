@@ -76,13 +76,7 @@ int bj_fri_schedule(uint32_t security_bits, size_t cap_size, uint32_t pow_bits, 
 void bj_fri_destroy(bj_fri *f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    for (auto &o : f->oracles) {
-        if (o.owned) {
-            if (o.d_c0) (void)hipFree(o.d_c0);
-        }
-        if (o.d_tree) (void)hipFree(o.d_tree);
-    }
-    if (f->d_last0) (void)hipFree(f->d_last0);
+    for (void *p : f->owned) (void)hipFree(p);
     delete f;
 }
 
@@ -132,6 +126,14 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
         bj_fri_destroy(f);
         return code;
     };
+    // layers and trees live as long as the bj_fri object: arena blocks inside a proof (released with the arena), hipMalloc
+    // blocks (listed in f->owned) for the stand-alone bj_fri_prove
+    auto alloc = [&](size_t elems) -> u64 * {
+        bool from_arena = false;
+        u64 *p = (u64 *)bj::tmp_alloc(ctx, elems * sizeof(u64), &from_arena);
+        if (p && !from_arena) f->owned.push_back(p);
+        return p;
+    };
     for (size_t step = 0; step < schedule_len; step++) {
         const unsigned k = schedule[step];
         const unsigned parts = step == 0 ? sh.world : 1;   // how many ranks share this oracle
@@ -139,7 +141,6 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
         bj_fri::Oracle o;
         o.d_c0 = (u64 *)cur0;
         o.d_c1 = (u64 *)cur1;
-        o.owned = step > 0;
         o.len = loc_len;
         o.log_e = k;
         o.num_leaves = loc_len >> k;
@@ -147,8 +148,7 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
         if (o.num_leaves < loc_cap || loc_cap == 0)
             return bail(bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_fri_prove: oracle smaller than cap"));
         size_t nd = 2 * o.num_leaves - loc_cap;
-        if (hipMalloc((void **)&o.d_tree, nd * 4 * sizeof(u64)) != hipSuccess)
-            return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: tree allocation failed"));
+        if (!(o.d_tree = alloc(nd * 4))) return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: tree allocation failed"));
         f->oracles.push_back(o);
         bj_fri::Oracle &oo = f->oracles.back();
         // oracle: 2^k values of c0 then of c1 per leaf (merkle_tree.rs:176-386)
@@ -165,32 +165,20 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
         oo.ch1 = tr->t.challenge();
         // fold by 2^k in one fused launch; alpha and kappa are squared per inner fold inside the kernel
         const size_t out_len = cur_len >> k, loc_out = loc_len >> k;
-        u64 *nxt = nullptr;
-        if (hipMalloc((void **)&nxt, 2 * out_len * sizeof(u64)) != hipSuccess)
-            return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
+        u64 *nxt = alloc(2 * out_len);
+        if (!nxt) return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
         if (parts == 1) {
             bj::launch_fri_fold_step(cur0, cur1, cur_len, k, nxt, nxt + out_len, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
                                      ctx->stream);
         } else {
-            u64 *part = nullptr;   // [2][loc_out] of this rank, gathered into nxt = [2][out_len]
-            if (hipMalloc((void **)&part, 2 * loc_out * sizeof(u64)) != hipSuccess) {
-                (void)hipFree(nxt);
-                return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
-            }
+            u64 *part = alloc(2 * loc_out);   // [2][loc_out] of this rank, gathered into nxt = [2][out_len]
+            if (!part) return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
             bj::launch_fri_fold_step(cur0, cur1, loc_len, k, part, part + loc_out, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
                                      ctx->stream, (size_t)sh.rank * loc_out);
             rc = bj::all_gather_columns(ctx, sh, part, nxt, 2, loc_out);
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipFree(part);
-            if (rc) {
-                (void)hipFree(nxt);
-                return bail(rc);
-            }
+            if (rc) return bail(rc);
         }
-        if (hipGetLastError() != hipSuccess) {
-            (void)hipFree(nxt);
-            return bail(bj::fail(ctx, BJ_ERR_HIP, "bj_fri_prove: fold launch failed"));
-        }
+        if (hipGetLastError() != hipSuccess) return bail(bj::fail(ctx, BJ_ERR_HIP, "bj_fri_prove: fold launch failed"));
         for (unsigned i = 0; i < k; i++) kappa = gl::sqr(kappa);
         cur0 = nxt;
         cur1 = nxt + out_len;
@@ -203,16 +191,14 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
     }
     // final interpolation: bit-reverse, iNTT on coset kappa^-1, keep len/lde coefficients (fri/mod.rs:312-343)
     const unsigned log_m = bj::log2_exact(cur_len);
-    u64 *fin = nullptr;
-    if (hipMalloc((void **)&fin, 2 * cur_len * sizeof(u64)) != hipSuccess)
-        return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: final buffer allocation failed"));
+    u64 *fin = alloc(2 * cur_len);
+    if (!fin) return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: final buffer allocation failed"));
     rc = bj_bitreverse_batch(ctx, cur0, fin, log_m, 2, cur_len);
     if (!rc) rc = bj_intt_batch(ctx, fin, fin, log_m, 2, cur_len, gl::inv(kappa));
     f->final_c0.resize(cur_len);
     f->final_c1.resize(cur_len);
     if (!rc) rc = bj_memcpy_d2h(ctx, f->final_c0.data(), fin, cur_len * sizeof(u64));
     if (!rc) rc = bj_memcpy_d2h(ctx, f->final_c1.data(), fin + cur_len, cur_len * sizeof(u64));
-    (void)hipFree(fin);
     if (rc) return bail(rc);
     f->final_degree = cur_len >> log_lde;
     // the reference asserts the high coefficients vanish (fri/mod.rs:327-336): report instead of panicking

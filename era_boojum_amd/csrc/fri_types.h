@@ -32,7 +32,6 @@ struct bj_fri {
     unsigned log_full = 0, log_lde = 0;
     struct Oracle {
         u64 *d_c0 = nullptr, *d_c1 = nullptr;  // leaf sources (oracle 0: the caller's codeword, not owned)
-        bool owned = false;
         size_t len = 0;
         unsigned log_e = 0;
         u64 *d_tree = nullptr;
@@ -42,6 +41,7 @@ struct bj_fri {
         u64 ch0 = 0, ch1 = 0;
     };
     std::vector<Oracle> oracles;
+    std::vector<void *> owned;                   // hipMalloc'ed blocks to release (blocks from the proof arena are not listed)
     u64 *d_last0 = nullptr, *d_last1 = nullptr;  // last folded layer
     size_t last_len = 0;
     std::vector<u64> final_c0, final_c1;

@@ -25,9 +25,16 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
 namespace {
 // device-side argument block: [ptrs (n_cols)] [coefs (2*n_cols)] in one temporary allocation
 struct DevArgs {
+    bj_ctx *ctx = nullptr;
     void *d = nullptr;
+    bool from_arena = false;
+    int alloc(bj_ctx *c, size_t bytes) {
+        ctx = c;
+        d = bj::tmp_alloc(c, bytes, &from_arena);
+        return d ? BJ_OK : bj::fail(c, BJ_ERR_OOM, "argument block allocation failed");
+    }
     ~DevArgs() {
-        if (d) (void)hipFree(d);
+        if (d) bj::tmp_free(ctx, d, from_arena);
     }
 };
 }  // namespace
@@ -59,7 +66,7 @@ int bj_barycentric_eval_batch(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, un
     const unsigned nb = bj::barycentric_num_blocks(n);
     DevArgs args;
     size_t bytes = (size_t)n_cols * sizeof(u64 *) + ((size_t)n_cols * nb * 2 + (size_t)n_cols * 2) * sizeof(u64);
-    BJ_HIP(ctx, hipMalloc(&args.d, bytes));
+    if (int rc = args.alloc(ctx, bytes)) return rc;
     const u64 **d_ptrs = (const u64 **)args.d;
     u64 *d_partials = (u64 *)(d_ptrs + n_cols);
     u64 *d_out = d_partials + (size_t)n_cols * nb * 2;
@@ -116,7 +123,7 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
     }
     const unsigned n_cols = (unsigned)ptrs.size();
     DevArgs args;
-    BJ_HIP(ctx, hipMalloc(&args.d, n_cols * sizeof(u64 *) + coefs.size() * sizeof(u64)));
+    if (int rc = args.alloc(ctx, n_cols * sizeof(u64 *) + coefs.size() * sizeof(u64))) return rc;
     const u64 **d_ptrs = (const u64 **)args.d;
     u64 *d_coefs = (u64 *)(d_ptrs + n_cols);
     BJ_HIP(ctx, hipMemcpyAsync((void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
@@ -125,7 +132,7 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
     bj::launch_deep_accumulate(d_ptrs, d_coefs, n_cols, N_local, I0, ctx->tw_fwd, C.c0, C.c1,
                                gl::canon(at2[0]), gl::canon(at2[1]), d_dst_c0, d_dst_c1, accumulate, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
-    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the argument block is freed on return
+    if (!args.from_arena) BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a hipMalloc'ed argument block is freed on return
     return BJ_OK;
 }
 }  // namespace bj

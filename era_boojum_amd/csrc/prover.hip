@@ -142,9 +142,10 @@ int all_gather(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_recv, siz
 
 int all_gather_columns(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_dst, unsigned parts, size_t part_len) {
     if (sh.world == 1) return all_gather(ctx, sh, d_send, d_dst, (size_t)parts * part_len);
-    u64 *tmp = nullptr;
     const size_t per = (size_t)parts * part_len;
-    if (hipMalloc((void **)&tmp, per * sh.world * 8) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "all_gather_columns: staging allocation failed");
+    bool from_arena = false;
+    u64 *tmp = (u64 *)tmp_alloc(ctx, per * sh.world * 8, &from_arena);
+    if (!tmp) return fail(ctx, BJ_ERR_OOM, "all_gather_columns: staging allocation failed");
     int rc = all_gather(ctx, sh, d_send, tmp, per);
     if (!rc) {
         // tmp[r][p][part_len] -> dst[p][r][part_len]: for each rank one strided 2-D copy
@@ -154,7 +155,7 @@ int all_gather_columns(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_d
                 rc = fail(ctx, BJ_ERR_HIP, "all_gather_columns: device copy failed");
         (void)hipStreamSynchronize(ctx->stream);
     }
-    (void)hipFree(tmp);
+    tmp_free(ctx, tmp, from_arena);
     return rc;
 }
 
@@ -352,9 +353,15 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
                     + (size_t)nS2 * n + ((size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16)   // s2_nat, tmp
                     + (size_t)nS2 * Ln + tree_elems                                                // s2_lde, s2_tree
                     + 2 * Q + (sh.world > 1 ? 2 * Ln * (sh.world + 1) : 0) + (size_t)2 * q * N + tree_elems + 2 * n + 2 * N                       // T (+ gather staging), q_lde, q_tree, w, deep
-                    + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 24 * slack;       // alphas, query gathers
+                    + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
+                    + 4 * N + (N * sh.world) / 2;                                                  // FRI layers + trees, DEEP argument blocks
         if ((rc = bj::arena_reset(ctx, need))) return rc;
     }
+    struct InProof {   // temporaries of the ABI calls below come out of the arena while this is alive
+        bj_ctx *c;
+        explicit InProof(bj_ctx *x) : c(x) { c->in_proof = true; }
+        ~InProof() { c->in_proof = false; }
+    } in_proof(ctx);
     StageTimer timer(st);
     bj::host::Transcript tr;
     tr.absorb(S->cap.data(), S->cap.size());                               // prover.rs:211
