@@ -188,16 +188,18 @@ def main():
                       "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
         del src, dst
 
-    if rank == 0 and not args.no_cpu_baseline:
-        from era_boojum_amd import proof_format
-        from oracle import prover as OP
-        from oracle import verifier as OV
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = min(threads, 64)
+    if rank == 0:
         # parity spot check of what was just timed: the oracle's verifier restatement must accept the timed proof
+        from era_boojum_amd import proof_format
+        from oracle import verifier as OV
         pg = proof_format.parse(proof_buf, security_level=args.security)
         if not OV.verify(OV.VerificationKey(circuit, setup.cap(), args.fri_lde, args.cap), pg):
             raise SystemExit("parity failure: the verifier restatement rejects the HIP proof")
+        out["config"]["verified"] = "oracle/verifier.py accepts the last timed proof"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import prover as OP
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = min(threads, 64)
         csmall = S.sha_shaped_circuit(args.cpu_log_n, seed=42, table_bits=4 if args.cpu_log_n >= 14 else 2)
         osetup = OP.Setup(csmall, args.fri_lde, args.cap, threads=threads)
         c0 = time.perf_counter()
