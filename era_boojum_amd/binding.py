@@ -47,6 +47,8 @@ _SIGNATURES = {
     "bj_barycentric_eval_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_deep_quotient_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]),
+    "bj_gate_program_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint,
+                                       C.c_uint, C.c_size_t, C.c_void_p]),
     "bj_setup_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_setup_create_sharded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_void_p)]),
@@ -129,6 +131,13 @@ class Context:
         self._h = h
         if stream is not None:
             self.set_stream(stream)
+
+    def gate_program_eval(self, program, d_vars, var_stride, d_consts, const_stride, reps, rep_var_stride, rep_const_stride,
+                          n_points, d_terms):
+        """bj_gate_program_eval: raw terms of a seam-S3 gate program at n_points points."""
+        self._check(self._lib.bj_gate_program_eval(self._h, C.byref(program.struct), C.c_void_p(d_vars), var_stride,
+                                                   C.c_void_p(d_consts) if d_consts else None, const_stride, reps, rep_var_stride,
+                                                   rep_const_stride, n_points, C.c_void_p(d_terms)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -403,7 +412,7 @@ class FriProof:
 
 class _GateDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("path_len", C.c_uint), ("path", C.c_ubyte * 8), ("num_repetitions", C.c_uint),
-                ("var_stride", C.c_uint), ("const_stride", C.c_uint), ("num_terms", C.c_uint)]
+                ("var_stride", C.c_uint), ("const_stride", C.c_uint), ("num_terms", C.c_uint), ("program", C.c_void_p)]
 
 
 class _Circuit(C.Structure):
@@ -500,6 +509,10 @@ class ProverSetup:
                 gates[i].path[b] = 1 if bit else 0
             gates[i].num_repetitions, gates[i].var_stride, gates[i].const_stride, gates[i].num_terms = \
                 g.reps, g.var_stride, g.const_stride, g.num_terms
+            prog = getattr(g, "program", None)       # seam S3: evaluate this gate from its op list (gate_program.py)
+            if prog is not None:
+                gates[i].kind = 5
+                gates[i].program = C.cast(C.pointer(prog.struct), C.c_void_p)
         nr = np.array(c.non_residues, dtype=np.uint64)
         cols = (C.c_uint * max(1, len(c.public_inputs)))(*[p[0] for p in c.public_inputs])
         rows = (C.c_uint * max(1, len(c.public_inputs)))(*[p[1] for p in c.public_inputs])

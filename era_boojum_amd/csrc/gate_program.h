@@ -1,0 +1,25 @@
+// Internal: device-side form of a bj_gate_program (seam S3), shared by gate_program.hip and prover.hip.
+#pragma once
+#include "ctx.h"
+
+#define BJ_GATE_PROGRAM_MAX_TEMPORARIES 96
+
+namespace bj {
+struct DevRelation {
+    uint32_t op, dst, a, b;   // a, b: kind << 28 | index
+};
+struct DevProgram {
+    void *block = nullptr;    // one allocation: values | relations | writes
+    gl::u64 *d_values = nullptr;
+    DevRelation *d_rel = nullptr;
+    uint32_t *d_writes = nullptr;
+    unsigned n_rel = 0, n_writes = 0;
+    int upload(bj_ctx *ctx, const bj_gate_program *p);   // validates, packs and copies the program
+    void release();
+};
+// quotient mode (d_alphas != nullptr): out += selector * sum alpha * term; stand-alone mode (d_terms != nullptr): raw terms
+void launch_gate_program(const DevProgram &P, const gl::u64 *d_vars, size_t var_stride, const gl::u64 *d_consts,
+                         size_t const_stride, unsigned path_len, const unsigned char *path, unsigned reps,
+                         unsigned rep_var_stride, unsigned rep_const_stride, const gl::u64 *d_alphas, size_t Q,
+                         gl::u64 *d_out0, gl::u64 *d_out1, gl::u64 *d_terms, hipStream_t s);
+}  // namespace bj

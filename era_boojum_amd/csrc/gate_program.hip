@@ -1,0 +1,205 @@
+// Seam S3: gates given as op lists (include/boojum_hip.h, bj_gate_program) — what the reference's gpu_synthesizer
+// captures from any GateConstraintEvaluator (src/gpu_synthesizer/mod.rs:113-133, 354-444) — evaluated by an interpreter
+// kernel.  The four gates of the SHA bench have hand-written evaluators in quotient.hip; everything else goes through
+// here: lane = LDE point, the program (relations, constants, writes) is wave-uniform and comes through the scalar cache,
+// temporaries live in a per-lane array.  Contribution to the quotient:  T += selector * sum_rep sum_t alpha * term.
+#include "ctx.h"
+#include "gate_program.h"
+
+using gl::u64;
+using gl::u32;
+
+namespace bj {
+
+namespace {
+constexpr int MAX_TMP = BJ_GATE_PROGRAM_MAX_TEMPORARIES;
+
+struct Acc160g {   // same lazy accumulator as quotient.hip
+    u32 w[5];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 5; i++) w[i] = 0;
+    }
+    __device__ __forceinline__ void fma(u64 a, u64 b) {
+        u32 hh, hl;
+        u64 lo;
+        gl::mul_limbs(a, b, hh, hl, lo);
+        u32 c;
+        w[0] = __builtin_addc(w[0], gl::lo32(lo), 0u, &c);
+        w[1] = __builtin_addc(w[1], gl::hi32(lo), c, &c);
+        w[2] = __builtin_addc(w[2], hl, c, &c);
+        w[3] = __builtin_addc(w[3], hh, c, &c);
+        w[4] += c;
+    }
+    __device__ __forceinline__ u64 reduce() const {
+        u64 r = gl::reduce_limbs(w[3], w[2], gl::pack(w[0], w[1]));
+        return gl::sub(r, (u64)w[4] << 32);
+    }
+};
+
+__device__ inline u64 inv_pow(u64 x) {   // x^(p-2); inverse of 0 is 0 like the reference's batch inversion never sees
+    u64 r = 1, b = x;
+    u64 e = gl::P - 2;
+    for (int i = 0; i < 64; i++) {
+        if ((e >> i) & 1) r = gl::mul(r, b);
+        b = gl::sqr(b);
+    }
+    return r;
+}
+
+struct ProgArgs {
+    const u64 *vars;
+    size_t var_stride;
+    const u64 *consts;
+    size_t const_stride;
+    const DevRelation *rel;
+    const u64 *values;
+    const u32 *writes;   // kind << 28 | index
+    unsigned n_rel, n_writes;
+    unsigned path_len;
+    unsigned char path[8];
+    unsigned reps, rep_var_stride, rep_const_stride;
+    const u64 *alphas;   // [reps * n_writes][2] for this gate, or nullptr
+    size_t Q;
+    u64 *out0, *out1;    // accumulated into (quotient mode)
+    u64 *terms;          // raw terms (stand-alone mode)
+};
+
+__global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
+    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= a.Q) return;
+    u64 tmp[MAX_TMP];
+    auto fetch = [&](u32 packed, size_t vb, size_t cb) -> u64 {
+        const u32 kind = packed >> 28, idx = packed & 0x0FFFFFFFu;
+        switch (kind) {
+            case BJ_IDX_VARIABLE_POLY: return gl::canon(a.vars[(vb + idx) * a.var_stride + I]);
+            case BJ_IDX_CONSTANT_POLY: return gl::canon(a.consts[(cb + idx) * a.const_stride + I]);
+            case BJ_IDX_TEMPORARY: return tmp[idx];
+            default: return a.values[idx];
+        }
+    };
+    u64 sel = 1;
+    for (unsigned b = 0; b < a.path_len; b++) {
+        u64 c = gl::canon(a.consts[(size_t)b * a.const_stride + I]);
+        sel = gl::mul(sel, a.path[b] ? c : gl::sub(1, c));
+    }
+    Acc160g s0, s1;
+    s0.clear();
+    s1.clear();
+    for (unsigned r = 0; r < a.reps; r++) {
+        const size_t vb = (size_t)r * a.rep_var_stride, cb = (size_t)a.path_len + (size_t)r * a.rep_const_stride;
+        for (unsigned i = 0; i < a.n_rel; i++) {
+            const DevRelation R = a.rel[i];
+            const u64 x = fetch(R.a, vb, cb);
+            u64 res;
+            switch (R.op) {
+                case BJ_OP_ADD: res = gl::add(x, fetch(R.b, vb, cb)); break;
+                case BJ_OP_DOUBLE: res = gl::add(x, x); break;
+                case BJ_OP_SUB: res = gl::sub(x, fetch(R.b, vb, cb)); break;
+                case BJ_OP_NEGATE: res = gl::neg(x); break;
+                case BJ_OP_MUL: res = gl::mul(x, fetch(R.b, vb, cb)); break;
+                case BJ_OP_SQUARE: res = gl::sqr(x); break;
+                default: res = inv_pow(x); break;
+            }
+            tmp[R.dst] = res;
+        }
+        for (unsigned t = 0; t < a.n_writes; t++) {
+            const u64 term = fetch(a.writes[t], vb, cb);
+            if (a.terms) a.terms[((size_t)r * a.n_writes + t) * a.Q + I] = term;
+            if (a.alphas) {
+                const size_t k = (size_t)r * a.n_writes + t;
+                s0.fma(term, a.alphas[2 * k]);
+                s1.fma(term, a.alphas[2 * k + 1]);
+            }
+        }
+    }
+    if (a.alphas) {
+        a.out0[I] = gl::add(gl::canon(a.out0[I]), gl::mul(s0.reduce(), sel));
+        a.out1[I] = gl::add(gl::canon(a.out1[I]), gl::mul(s1.reduce(), sel));
+    }
+}
+}  // namespace
+
+int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
+    if (!p || !p->relations || !p->writes || p->num_writes == 0)
+        return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: null / empty program");
+    if (p->num_temporaries > (unsigned)MAX_TMP)
+        return fail(ctx, BJ_ERR_UNSUPPORTED, "gate program: %u temporaries (at most %d)", p->num_temporaries, MAX_TMP);
+    auto check = [&](const bj_gate_index &ix) -> bool {
+        switch (ix.kind) {
+            case BJ_IDX_VARIABLE_POLY:
+            case BJ_IDX_CONSTANT_POLY: return ix.index < (1u << 20);
+            case BJ_IDX_TEMPORARY: return ix.index < p->num_temporaries;
+            case BJ_IDX_CONSTANT_VALUE: return ix.index < p->num_values && p->values;
+            default: return false;   // witness columns are not supported
+        }
+    };
+    std::vector<DevRelation> rel(p->num_relations);
+    for (uint32_t i = 0; i < p->num_relations; i++) {
+        const bj_gate_relation &R = p->relations[i];
+        if (R.op < BJ_OP_ADD || R.op > BJ_OP_INVERSE || R.dst >= p->num_temporaries || !check(R.a))
+            return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: bad relation %u", i);
+        const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
+        if (binary && !check(R.b)) return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: bad second operand in relation %u", i);
+        rel[i] = DevRelation{R.op, R.dst, (R.a.kind << 28) | R.a.index, binary ? (R.b.kind << 28) | R.b.index : 0u};
+    }
+    std::vector<u32> wr(p->num_writes);
+    for (uint32_t t = 0; t < p->num_writes; t++) {
+        if (!check(p->writes[t])) return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: bad write %u", t);
+        wr[t] = (p->writes[t].kind << 28) | p->writes[t].index;
+    }
+    std::vector<u64> vals(p->num_values ? p->num_values : 1, 0);
+    for (uint32_t i = 0; i < p->num_values; i++) vals[i] = gl::canon(p->values[i]);
+    n_rel = p->num_relations;
+    n_writes = p->num_writes;
+    const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + wr.size() * 4 + 64;
+    if (hipMalloc(&block, bytes) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "gate program: allocation failed");
+    char *base = (char *)block;
+    d_values = (u64 *)base;
+    d_rel = (DevRelation *)(base + vals.size() * 8);
+    d_writes = (u32 *)(base + vals.size() * 8 + (rel.size() ? rel.size() : 1) * sizeof(DevRelation));
+    int rc = bj_memcpy_h2d(ctx, d_values, vals.data(), vals.size() * 8);
+    if (!rc && !rel.empty()) rc = bj_memcpy_h2d(ctx, d_rel, rel.data(), rel.size() * sizeof(DevRelation));
+    if (!rc) rc = bj_memcpy_h2d(ctx, d_writes, wr.data(), wr.size() * 4);
+    return rc;
+}
+void DevProgram::release() {
+    if (block) (void)hipFree(block);
+    block = nullptr;
+}
+
+void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                         unsigned path_len, const unsigned char *path, unsigned reps, unsigned rep_var_stride,
+                         unsigned rep_const_stride, const u64 *d_alphas, size_t Q, u64 *d_out0, u64 *d_out1, u64 *d_terms,
+                         hipStream_t s) {
+    ProgArgs a{};
+    a.vars = d_vars; a.var_stride = var_stride; a.consts = d_consts; a.const_stride = const_stride;
+    a.rel = P.d_rel; a.values = P.d_values; a.writes = P.d_writes; a.n_rel = P.n_rel; a.n_writes = P.n_writes;
+    a.path_len = path_len;
+    for (unsigned b = 0; b < 8; b++) a.path[b] = b < path_len ? path[b] : 0;
+    a.reps = reps; a.rep_var_stride = rep_var_stride; a.rep_const_stride = rep_const_stride;
+    a.alphas = d_alphas; a.Q = Q; a.out0 = d_out0; a.out1 = d_out1; a.terms = d_terms;
+    if (!Q) return;
+    hipLaunchKernelGGL(gate_program_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, a);
+}
+
+}  // namespace bj
+
+extern "C" int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint64_t *d_vars, size_t var_stride,
+                                    const uint64_t *d_consts, size_t const_stride, unsigned num_repetitions,
+                                    unsigned rep_var_stride, unsigned rep_const_stride, size_t n_points, uint64_t *d_terms) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!d_vars || !d_terms || num_repetitions == 0) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_gate_program_eval: null argument");
+    bj::DevProgram P;
+    if (int rc = P.upload(ctx, program)) {
+        P.release();
+        return rc;
+    }
+    bj::launch_gate_program(P, d_vars, var_stride, d_consts ? d_consts : d_vars, const_stride, 0, nullptr, num_repetitions,
+                            rep_var_stride, rep_const_stride, nullptr, n_points, nullptr, nullptr, d_terms, ctx->stream);
+    int rc = BJ_OK;
+    if (hipGetLastError() != hipSuccess) rc = bj::fail(ctx, BJ_ERR_HIP, "bj_gate_program_eval: launch failed");
+    (void)hipStreamSynchronize(ctx->stream);
+    P.release();
+    return rc;
+}

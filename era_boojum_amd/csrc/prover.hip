@@ -11,6 +11,7 @@
 #include "ctx.h"
 #include "host_transcript.hpp"
 #include "fri_types.h"
+#include "gate_program.h"
 
 #include <chrono>
 #include <cstring>
@@ -56,6 +57,7 @@ struct bj_setup {
     // circuit
     unsigned log_n = 0, V = 0, num_gp_vars = 0, nC = 0, lookup_w = 0, lookup_reps = 0, table_id_col = 0, q = 0;
     std::vector<int> gates_flat;   // 12 ints per gate
+    std::vector<bj::DevProgram> programs;   // per gate; empty (block == nullptr) unless kind == BJ_GATE_PROGRAM
     unsigned n_gates = 0;
     std::vector<u64> non_residues;
     std::vector<unsigned> pub_cols, pub_rows;
@@ -180,6 +182,7 @@ void bj_setup_destroy(bj_setup *s) {
     if (s->d_lde) (void)hipFree(s->d_lde);
     if (s->d_tree) (void)hipFree(s->d_tree);
     if (s->d_non_res) (void)hipFree(s->d_non_res);
+    for (auto &p : s->programs) p.release();
     delete s;
 }
 
@@ -233,9 +236,22 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     s->n_gates = c->num_gates;
     for (unsigned g = 0; g < c->num_gates; g++) {
         const bj_gate_desc &G = c->gates[g];
-        if (G.kind < 1 || G.kind > 4 || G.path_len > 6) {
-            delete s;
+        if (G.kind < 1 || G.kind > BJ_GATE_PROGRAM || G.path_len > 6 || (G.kind == BJ_GATE_PROGRAM && !G.program) ||
+            (G.kind != BJ_GATE_PROGRAM && G.kind != BJ_GATE_NOP && G.num_terms != 1)) {
+            bj_setup_destroy(s);
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad gate descriptor %u", g);
+        }
+        s->programs.emplace_back();
+        if (G.kind == BJ_GATE_PROGRAM) {
+            if (G.program->num_writes != G.num_terms) {
+                bj_setup_destroy(s);
+                return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: gate %u: program writes %u terms, descriptor says %u", g,
+                                G.program->num_writes, G.num_terms);
+            }
+            if (int prc = s->programs.back().upload(ctx, G.program)) {
+                bj_setup_destroy(s);
+                return prc;
+            }
         }
         int f[12] = {G.kind, (int)G.path_len, (int)G.num_repetitions, (int)G.var_stride, (int)G.const_stride,
                      (int)G.num_terms, 0, 0, 0, 0, 0, 0};
@@ -450,7 +466,20 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     u64 *t0 = Tl.p, *t1 = Tl.p + (q_local ? Q : Ln);
     const u64 *a_lookup = d_alphas.p, *a_gates = d_alphas.p + 2 * n_lookup_terms, *a_l1 = a_gates + 2 * n_gate_terms;
     const u64 *d_sig_lde = S->d_lde, *d_con_lde = S->d_lde + (size_t)V * Ln, *d_tab_lde = S->d_lde + (size_t)(V + nC) * Ln;
-    if (Qe) bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Qe, t0, t1, st);
+    if (Qe) {
+        bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Qe, t0, t1, st);
+        unsigned aoff = 0;   // op-list gates (seam S3) add their contribution on top, with their own slice of alpha powers
+        for (unsigned g = 0; g < S->n_gates; g++) {
+            const int *f = S->gates_flat.data() + 12 * g;
+            if (f[0] == BJ_GATE_PROGRAM) {
+                unsigned char path[8] = {0};
+                for (int b = 0; b < f[1]; b++) path[b] = (unsigned char)f[6 + b];
+                bj::launch_gate_program(S->programs[g], wit_lde.p, Ln, d_con_lde, Ln, (unsigned)f[1], path, (unsigned)f[2],
+                                        (unsigned)f[3], (unsigned)f[4], a_gates + 2 * (size_t)aoff, Qe, t0, t1, nullptr, st);
+            }
+            aoff += (unsigned)(f[2] * f[5]);
+        }
+    }
     if (has_lookup && Qe) {
         const u64 *dA = s2_lde.p + (size_t)(2 + 2 * n_part) * Ln, *dB = dA + (size_t)2 * S->lookup_reps * Ln;
         bj::launch_quotient_lookup(wit_lde.p + (size_t)S->num_gp_vars * Ln, Ln, d_con_lde + (size_t)S->table_id_col * Ln, d_tab_lde,

@@ -1,0 +1,209 @@
+"""Gate op lists for seam S3 (include/boojum_hip.h, bj_gate_program): a small tracing builder that records the relations
+of a gate formula the way the reference's gpu_synthesizer does (GpuSynthesizerFieldLike + GPUVariablesContext,
+src/gpu_synthesizer/mod.rs:136-352): write the evaluator once with `+ - *`, get the op list.
+
+    b = GateProgramBuilder()
+    a, bb, c, d = (b.var(i) for i in range(4))
+    q, l = b.const_poly(0), b.const_poly(1)
+    b.push(q * a * bb + l * c - d)          # FmaGateInBaseFieldWithoutConstant
+    program = b.build()
+"""
+import ctypes as C
+
+OP_ADD, OP_DOUBLE, OP_SUB, OP_NEGATE, OP_MUL, OP_SQUARE, OP_INVERSE = 1, 2, 3, 4, 5, 6, 7
+IDX_VARIABLE, IDX_WITNESS, IDX_CONSTANT_POLY, IDX_TEMPORARY, IDX_VALUE = 0, 1, 2, 3, 4
+P = (1 << 64) - (1 << 32) + 1
+
+
+class _GateIndex(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32)]
+
+
+class _GateRelation(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("dst", C.c_uint32), ("a", _GateIndex), ("b", _GateIndex)]
+
+
+class _GateProgram(C.Structure):
+    _fields_ = [("relations", C.POINTER(_GateRelation)), ("num_relations", C.c_uint32), ("values", C.POINTER(C.c_uint64)),
+                ("num_values", C.c_uint32), ("writes", C.POINTER(_GateIndex)), ("num_writes", C.c_uint32),
+                ("num_temporaries", C.c_uint32)]
+
+
+class _Val:
+    """A traced field element: a column, a constant, or a temporary produced by a recorded relation."""
+
+    def __init__(self, builder, kind, index):
+        self.b, self.kind, self.index = builder, kind, index
+
+    def _coerce(self, other):
+        return other if isinstance(other, _Val) else self.b.value(other)
+
+    def __add__(self, o): return self.b._emit(OP_ADD, self, self._coerce(o))
+    def __radd__(self, o): return self._coerce(o) + self
+    def __sub__(self, o): return self.b._emit(OP_SUB, self, self._coerce(o))
+    def __rsub__(self, o): return self._coerce(o) - self
+    def __mul__(self, o): return self.b._emit(OP_MUL, self, self._coerce(o))
+    def __rmul__(self, o): return self._coerce(o) * self
+    def __neg__(self): return self.b._emit(OP_NEGATE, self)
+    def double(self): return self.b._emit(OP_DOUBLE, self)
+    def square(self): return self.b._emit(OP_SQUARE, self)
+    def inverse(self): return self.b._emit(OP_INVERSE, self)
+
+
+class GateProgramBuilder:
+    def __init__(self):
+        self.relations, self.values, self.writes, self.n_tmp = [], [], [], 0
+
+    def var(self, i): return _Val(self, IDX_VARIABLE, i)
+    def const_poly(self, i): return _Val(self, IDX_CONSTANT_POLY, i)
+
+    def value(self, x):
+        x = int(x) % P
+        if x not in self.values:
+            self.values.append(x)
+        return _Val(self, IDX_VALUE, self.values.index(x))
+
+    def _emit(self, op, a, b=None):
+        dst = self.n_tmp
+        self.n_tmp += 1
+        self.relations.append((op, dst, (a.kind, a.index), (b.kind, b.index) if b is not None else (0, 0)))
+        return _Val(self, IDX_TEMPORARY, dst)
+
+    def push(self, v):
+        """push_evaluation_result: `v` is a quotient term of one repetition."""
+        self.writes.append((v.kind, v.index))
+
+    def build(self):
+        return GateProgram(self.relations, self.values, self.writes, self.n_tmp)
+
+
+class GateProgram:
+    def __init__(self, relations, values, writes, num_temporaries):
+        self.relations, self.values, self.writes, self.num_temporaries = list(relations), list(values), list(writes), num_temporaries
+        self._rel = (_GateRelation * max(1, len(relations)))()
+        for i, (op, dst, a, b) in enumerate(relations):
+            self._rel[i] = _GateRelation(op, dst, _GateIndex(*a), _GateIndex(*b))
+        self._val = (C.c_uint64 * max(1, len(values)))(*values)
+        self._wr = (_GateIndex * max(1, len(writes)))(*[_GateIndex(k, i) for k, i in writes])
+        self.struct = _GateProgram(self._rel, len(relations), self._val, len(values), self._wr, len(writes), num_temporaries)
+
+    @property
+    def num_terms(self):
+        return len(self.writes)
+
+    def evaluate(self, var, con):
+        """Reference semantics in python integers (for tests): var/con = lists of ints; returns the terms."""
+        tmp = {}
+
+        def get(ix):
+            k, i = ix
+            return {IDX_VARIABLE: lambda: var[i], IDX_CONSTANT_POLY: lambda: con[i], IDX_TEMPORARY: lambda: tmp[i],
+                    IDX_VALUE: lambda: self.values[i]}[k]() % P
+        for op, dst, a, b in self.relations:
+            x = get(a)
+            if op == OP_ADD: r = x + get(b)
+            elif op == OP_DOUBLE: r = 2 * x
+            elif op == OP_SUB: r = x - get(b)
+            elif op == OP_NEGATE: r = -x
+            elif op == OP_MUL: r = x * get(b)
+            elif op == OP_SQUARE: r = x * x
+            else: r = pow(x, P - 2, P)
+            tmp[dst] = r % P
+        return [get(w) for w in self.writes]
+
+
+# ---- the evaluators of the SHA bench as op lists (the same formulas quotient.hip hard-codes), and a few more gates ----
+def fma_program():
+    b = GateProgramBuilder()
+    a, bb, c, d = (b.var(i) for i in range(4))
+    b.push(b.const_poly(0) * (a * bb) + b.const_poly(1) * c - d)     # fma_gate_without_constant.rs:96-126
+    return b.build()
+
+
+def reduction4_program():
+    b = GateProgramBuilder()
+    acc = b.var(0) * b.const_poly(0)
+    for k in range(1, 4):
+        acc = acc + b.var(k) * b.const_poly(k)
+    b.push(acc - b.var(4))                                           # reduction_gate.rs:103-126
+    return b.build()
+
+
+def constants_allocator_program():
+    b = GateProgramBuilder()
+    b.push(b.var(0) - b.const_poly(0))                               # constant_allocator.rs:107-126
+    return b.build()
+
+
+def selection_program():
+    b = GateProgramBuilder()
+    a, bb, sel, out = (b.var(i) for i in range(4))
+    b.push(a * sel + (1 - sel) * bb - out)                           # selection_gate.rs:86-112
+    return b.build()
+
+
+def dot_product4_program():
+    b = GateProgramBuilder()
+    acc = b.var(0) * b.var(1)
+    for i in range(1, 4):
+        acc = acc + b.var(2 * i) * b.var(2 * i + 1)
+    b.push(acc - b.var(8))                                           # dot_product_gate.rs:85-113
+    return b.build()
+
+
+def zero_check_program():
+    b = GateProgramBuilder()
+    inp, flag, inv = b.var(0), b.var(1), b.var(2)
+    b.push(flag + inp * inv - 1)                                     # zero_check.rs:143-175
+    b.push(inp * flag)
+    return b.build()
+
+
+def uintx_add_program():
+    b = GateProgramBuilder()
+    a, bb, cin, c, cout = (b.var(i) for i in range(5))
+    b.push(a + bb + cin - c - b.const_poly(0) * cout)                # uintx_add.rs:96-130
+    b.push(cout.square() - cout)
+    return b.build()
+
+
+def boolean_program():
+    b = GateProgramBuilder()
+    a = b.var(0)
+    b.push(a * (1 - a))                                              # boolean_allocator.rs:86-107
+    return b.build()
+
+
+def parallel_selection4_program():
+    b = GateProgramBuilder()
+    sel = b.var(0)
+    for i in range(4):
+        a, bb, r = b.var(3 * i + 1), b.var(3 * i + 2), b.var(3 * i + 3)
+        b.push(a * sel + (1 - sel) * bb - r)                         # parallel_selection.rs:92-120
+    return b.build()
+
+
+def u8x4_fma_program():
+    """U8x4FMAGate (u32_fma.rs:96-280): a*b + c + carry_in = low + 2^32 * high over 8-bit limbs."""
+    b = GateProgramBuilder()
+    v = [b.var(i) for i in range(26)]
+    a, bb, c, carry, low, high, pc0, pc1 = v[0:4], v[4:8], v[8:12], v[12:16], v[16:20], v[20:24], v[24], v[25]
+    sh = lambda i: 1 << (8 * i)
+    t = c[0] + c[1] * sh(1) + c[2] * sh(2) + c[3] * sh(3)
+    t = t + carry[0] + carry[1] * sh(1) + carry[2] * sh(2) + carry[3] * sh(3)
+    for i in range(4):
+        t = t - low[i] * sh(i)
+    t = t + a[0] * bb[0]
+    t = t + (a[1] * bb[0] + a[0] * bb[1]) * sh(1)
+    t = t + (a[2] * bb[0] + a[1] * bb[1] + a[0] * bb[2]) * sh(2)
+    t = t + (a[3] * bb[0] + a[2] * bb[1] + a[1] * bb[2] + a[0] * bb[3]) * sh(3)
+    t = t - pc0 * sh(4) - pc1 * sh(5)
+    b.push(t)
+    u = pc0 + pc1 * sh(1)
+    for i in range(4):
+        u = u - high[i] * sh(i)
+    u = u + (a[3] * bb[1] + a[2] * bb[2] + a[1] * bb[3])
+    u = u + (a[3] * bb[2] + a[2] * bb[3]) * sh(1)
+    u = u + (a[3] * bb[3]) * sh(2)
+    b.push(u)
+    return b.build()

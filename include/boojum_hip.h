@@ -230,8 +230,39 @@ typedef enum bj_gate_kind {
     BJ_GATE_CONSTANT_ALLOCATOR = 1, /* a - c                      src/cs/gates/constant_allocator.rs:107-126          */
     BJ_GATE_FMA_NO_CONSTANT = 2,    /* q*a*b + l*c - d            src/cs/gates/fma_gate_without_constant.rs:96-126    */
     BJ_GATE_REDUCTION4 = 3,         /* sum_i c_i*v_i - r          src/cs/gates/reduction_gate.rs:103-126              */
-    BJ_GATE_NOP = 4                 /* no terms                   src/cs/gates/nop_gate.rs:41                         */
+    BJ_GATE_NOP = 4,                /* no terms                   src/cs/gates/nop_gate.rs:41                         */
+    BJ_GATE_PROGRAM = 5             /* any evaluator, given as the op list of seam S3 (bj_gate_program below)          */
 } bj_gate_kind;
+
+/* Seam S3 — a gate as the reference's gpu_synthesizer describes it (GPUDataCapture::from_evaluator,
+ * src/gpu_synthesizer/mod.rs:113-133, 354-444): `relations` are executed in order, each writes one temporary;
+ * operands are variable columns (relative to the repetition), constant columns (relative to the end of the selector
+ * path, plus the repetition's constant offset), temporaries or field constants; `writes` are the quotient terms of one
+ * repetition in push order (GPUPolyDestination::push_evaluation_result).  Witness columns are not supported. */
+typedef enum bj_gate_op { /* Relation<F>, gpu_synthesizer/mod.rs:123-133 */
+    BJ_OP_ADD = 1, BJ_OP_DOUBLE = 2, BJ_OP_SUB = 3, BJ_OP_NEGATE = 4, BJ_OP_MUL = 5, BJ_OP_SQUARE = 6, BJ_OP_INVERSE = 7
+} bj_gate_op;
+typedef enum bj_index_kind { /* Index<F>, gpu_synthesizer/mod.rs:113-121 */
+    BJ_IDX_VARIABLE_POLY = 0, BJ_IDX_WITNESS_POLY = 1, BJ_IDX_CONSTANT_POLY = 2, BJ_IDX_TEMPORARY = 3, BJ_IDX_CONSTANT_VALUE = 4
+} bj_index_kind;
+typedef struct bj_gate_index {
+    uint32_t kind;  /* bj_index_kind */
+    uint32_t index; /* column / temporary number; for BJ_IDX_CONSTANT_VALUE an index into bj_gate_program::values */
+} bj_gate_index;
+typedef struct bj_gate_relation {
+    uint32_t op;  /* bj_gate_op */
+    uint32_t dst; /* temporary written */
+    bj_gate_index a, b; /* b is ignored by the unary ops */
+} bj_gate_relation;
+typedef struct bj_gate_program {
+    const bj_gate_relation *relations;
+    uint32_t num_relations;
+    const uint64_t *values; /* field constants referenced by BJ_IDX_CONSTANT_VALUE */
+    uint32_t num_values;
+    const bj_gate_index *writes; /* num_terms entries */
+    uint32_t num_writes;
+    uint32_t num_temporaries; /* <= 96 */
+} bj_gate_program;
 
 typedef struct bj_gate_desc {
     int kind;                 /* bj_gate_kind */
@@ -241,7 +272,15 @@ typedef struct bj_gate_desc {
     unsigned var_stride;      /* per_chunk_offset.variables_offset */
     unsigned const_stride;    /* per_chunk_offset.constants_offset */
     unsigned num_terms;       /* quotient terms per repetition (0 for markers) */
+    const bj_gate_program *program; /* BJ_GATE_PROGRAM only, NULL otherwise */
 } bj_gate_desc;
+
+/* Evaluate a gate program at n_points points (stand-alone, for parity tests of S3): d_terms[(rep*num_writes + t)*n_points + i]
+ * = term t of repetition rep at point i.  d_vars / d_consts: columns with the given strides, constants WITHOUT a selector
+ * prefix. */
+int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint64_t *d_vars, size_t var_stride,
+                         const uint64_t *d_consts, size_t const_stride, unsigned num_repetitions, unsigned rep_var_stride,
+                         unsigned rep_const_stride, size_t n_points, uint64_t *d_terms);
 
 typedef struct bj_circuit {
     unsigned log_n;              /* trace length 2^log_n */
