@@ -24,6 +24,7 @@ from . import field_np as F
 P = F.P
 
 GATE_CONSTANT_ALLOCATOR, GATE_FMA, GATE_REDUCTION4, GATE_NOP = 1, 2, 3, 4
+GATE_PROGRAM = 5     # evaluated from an op list (seam S3): GateDesc.program is an era_boojum_amd.gate_program.GateProgram
 
 
 @dataclass
@@ -39,6 +40,7 @@ class GateDesc:
     num_terms: int           # quotient terms per repetition
     needs_selector: bool
     path: list = field(default_factory=list)   # selector path, True = constant, False = 1 - constant
+    program: object = None   # op list for kind GATE_PROGRAM (and, optionally, for the hand-written kinds)
 
 
 def sha_bench_gates(num_gp_vars=60, num_constant_cols=4):
@@ -50,6 +52,20 @@ def sha_bench_gates(num_gp_vars=60, num_constant_cols=4):
         GateDesc(GATE_REDUCTION4, "ReductionGate<4>", 2, 4, 5, num_gp_vars // 5, 5, 0, 1, True),
         GateDesc(GATE_NOP, "NopGate", 0, 0, 0, 1, 0, 0, 0, True),
     ]
+
+
+def extended_gates(num_gp_vars=60, num_constant_cols=4):
+    """The bench's gates plus three more evaluator types given only as op lists (seam S3): SelectionGate, ZeroCheckGate
+    (two terms per repetition), UIntXAddGate (two terms, one row-shared constant) — src/cs/gates/{selection_gate,
+    zero_check,uintx_add}.rs."""
+    from . import gate_program as GP
+    g = sha_bench_gates(num_gp_vars, num_constant_cols)
+    extra = [
+        GateDesc(GATE_PROGRAM, "SelectionGate", 2, 0, 4, num_gp_vars // 4, 4, 0, 1, True, program=GP.selection_program()),
+        GateDesc(GATE_PROGRAM, "ZeroCheckGate", 2, 0, 3, num_gp_vars // 3, 3, 0, 2, True, program=GP.zero_check_program()),
+        GateDesc(GATE_PROGRAM, "UIntXAddGate", 2, 1, 5, num_gp_vars // 5, 5, 0, 2, True, program=GP.uintx_add_program()),
+    ]
+    return g[:3] + extra + g[3:]
 
 
 # ---- selector placement: restatement of TreeNode::try_add_gate / try_find_placement_for_degree (setup.rs:1346-1572) ----
@@ -174,6 +190,7 @@ class Circuit:
     total_tables_len: int
     selector_tree: object = None    # ('gate', GateDesc) | ('fork', left, right); left = constant, right = 1 - constant
     max_allowed_constraint_degree: int = 4
+    geometry_constant_cols: int = 4    # CSGeometry::num_constant_columns (the rest of num_constants_for_gates are selector extras)
 
     @property
     def n(self):
@@ -185,13 +202,15 @@ class Circuit:
 
 
 def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
-                       lookup_width=4, lookup_reps=8, num_public_inputs=2):
+                       lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False):
     """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
     (ConstantsAllocator, FMA, Reduction); the rest are Nop rows."""
     n = 1 << log_n
     rng = np.random.default_rng(seed)
     rand_f = lambda shape: rng.integers(0, P, size=shape, dtype=np.uint64)
-    gates = sha_bench_gates(num_gp_vars, num_constant_cols)
+    gates = extended_gates(num_gp_vars, num_constant_cols) if extended else sha_bench_gates(num_gp_vars, num_constant_cols)
+    if extended:   # rows: the bench mix squeezed into 60 %, 10 % for each op-list gate, Nop for the rest
+        mix = tuple(0.6 * m for m in mix[:3]) + (0.1, 0.1, 0.1)
     max_deg, consts_for_gates = place_selectors(gates, num_constant_cols)
     q = 1
     while q < max_deg - 1:
@@ -205,7 +224,10 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
 
     # --- rows -> gate kinds, in contiguous blocks (prover cost does not depend on the arrangement; slices keep the
     #     generation of a 2^22-row circuit to seconds)
-    cuts = [0, int(n * mix[0]), int(n * (mix[0] + mix[1])), int(n * sum(mix)), n]
+    cuts = [0]
+    for m in mix:
+        cuts.append(cuts[-1] + int(n * m))
+    cuts.append(n)
     for gi, g in enumerate(gates):
         lo, hi = cuts[gi], cuts[gi + 1]
         rows, m = slice(lo, hi), hi - lo
@@ -233,6 +255,29 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
                 if prev_d is not None:
                     swaps.append((base + 2, base - 1, rows))
                 prev_d = dd
+        elif g.name == "SelectionGate":
+            for r in range(g.reps):
+                base = r * g.var_stride
+                a, b, sel = rand_f(m), rand_f(m), rng.integers(0, 2, size=m).astype(np.uint64)
+                variables[base, rows], variables[base + 1, rows], variables[base + 2, rows] = a, b, sel
+                variables[base + 3, rows] = np.where(sel == 1, a, b)
+        elif g.name == "ZeroCheckGate":
+            for r in range(g.reps):
+                base = r * g.var_stride
+                x = rand_f(m)
+                x[rng.random(m) < 0.3] = 0                                   # some genuine zeros
+                inv = np.array([pow(int(v), P - 2, P) for v in x], dtype=np.uint64)
+                variables[base, rows], variables[base + 1, rows], variables[base + 2, rows] = x, (x == 0).astype(np.uint64), inv
+        elif g.name == "UIntXAddGate":
+            constants[d, rows] = np.uint64(1 << 32)                          # the row-shared shift 2^N, N = 32
+            for r in range(g.reps):
+                base = r * g.var_stride
+                a = rng.integers(0, 1 << 32, size=m, dtype=np.uint64)
+                b = rng.integers(0, 1 << 32, size=m, dtype=np.uint64)
+                cin = rng.integers(0, 2, size=m).astype(np.uint64)
+                tot = a + b + cin
+                variables[base, rows], variables[base + 1, rows], variables[base + 2, rows] = a, b, cin
+                variables[base + 3, rows], variables[base + 4, rows] = tot & np.uint64(0xFFFFFFFF), tot >> np.uint64(32)
         elif g.kind == GATE_REDUCTION4:
             cs = [rand_f(m) for _ in range(4)]
             for i in range(4):
@@ -281,7 +326,7 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         pubs.append((col, row, int(variables[col, row])))
     return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
                    table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len,
-                   selector_tree=getattr(place_selectors, "last_tree", None))
+                   selector_tree=getattr(place_selectors, "last_tree", None), geometry_constant_cols=num_constant_cols)
 
 
 def check_satisfied(c: Circuit):

@@ -84,13 +84,13 @@ def vk_to_reference_json(circuit, setup_cap, fri_lde_factor, cap_size):
     return {
         "fixed_parameters": {
             "parameters": {"num_columns_under_copy_permutation": c.num_gp_vars, "num_witness_columns": 0,
-                           "num_constant_columns": c.num_constants_for_gates - _selector_depth(c),
+                           "num_constant_columns": c.geometry_constant_cols,
                            "max_allowed_constraint_degree": c.max_allowed_constraint_degree},
             "lookup_parameters": lookup,
             "domain_size": c.n,
             "total_tables_len": c.total_tables_len if c.lookup_reps else 0,
             "public_inputs_locations": [[int(col), int(row)] for col, row, _ in c.public_inputs],
-            "extra_constant_polys_for_selectors": _selector_depth(c),
+            "extra_constant_polys_for_selectors": c.num_constants_for_gates - c.geometry_constant_cols,
             "table_ids_column_idxes": [c.table_id_col] if c.lookup_reps else [],
             "quotient_degree": c.quotient_degree,
             "selectors_placement": _tree(c.selector_tree, gate_index),
@@ -99,10 +99,6 @@ def vk_to_reference_json(circuit, setup_cap, fri_lde_factor, cap_size):
         },
         "setup_merkle_tree_cap": [[int(x) for x in d] for d in setup_cap],
     }
-
-
-def _selector_depth(c):
-    return max(len(g.path) for g in c.gates)
 
 
 def dumps(obj):

@@ -53,8 +53,10 @@ def _gate_terms_at(vk, var, con):
                 for k in range(4):
                     t = eadd(t, emul(var[vb + k], con[d + k]))
                 terms.append(esub(t, var[vb + 4]))
-            else:
-                raise ValueError("unknown gate kind")
+            else:                # any other evaluator, by name: the golden-pinned formulas of oracle/gates.py
+                from oracle.gates import EVALUATORS
+                width, fn = EVALUATORS[g.name][0], EVALUATORS[g.name][5]
+                terms.extend(fn(var[vb:vb + width], con[cb:]))
         out.append((sel, terms))
     return out
 

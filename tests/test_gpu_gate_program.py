@@ -86,3 +86,47 @@ def test_bad_programs_are_rejected():
     d = DevBuf(nelems=64)
     with pytest.raises(E.BoojumHipError):
         ctx().gate_program_eval(prog, d.ptr, 8, d.ptr, 8, 1, 2, 0, 8, d.ptr)
+
+
+def test_circuit_with_more_gate_types_proves_and_verifies():
+    """Seven evaluator types, three of them (Selection, ZeroCheck with two terms, UIntXAdd with two terms and a row-shared
+    constant) known to the prover ONLY as op lists; quotient degree 8.  No oracle prover for this gate set, so the proof is
+    checked by the verifier restatement (Merkle paths, DEEP, FRI, quotient identity with the golden-pinned evaluators) and
+    by the golden-pinned identity code on the emitted VerificationKey JSON; a broken witness must be reported."""
+    import json
+    import oracle as O
+    from oracle import golden_quotient as GQ
+    from oracle import verifier as OV
+    from era_boojum_amd import wire_format as W
+    c = S.sha_shaped_circuit(11, seed=77, table_bits=2, extended=True)
+    assert c.quotient_degree == 8 and [g.name for g in c.gates][3:6] == ["SelectionGate", "ZeroCheckGate", "UIntXAddGate"]
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 40)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=40)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, gsetup.cap(), 8, 16)))
+    t = O.Transcript()
+    t.absorb_cap(gsetup.cap())
+    t.absorb(pg["public_inputs"])
+    t.absorb_cap(np.array(pg["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(pg["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(pg["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), [g.name for g in c.gates], [], c.non_residues,
+                                    dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    pg["values_at_z"], pg["values_at_z_omega"][0])
+    assert lhs == rhs
+    # break one ZeroCheck row: input * flag != 0
+    zc = next(g for g in c.gates if g.name == "ZeroCheckGate")
+    m = np.ones(c.n, dtype=bool)
+    for i, bit in enumerate(zc.path):
+        m &= c.constants[i] == (1 if bit else 0)
+    row = int(np.nonzero(m)[0][0])
+    bad = c.variables.copy()
+    bad[1, row] = 1                      # flag := 1
+    bad[0, row] = 5                      # input := 5   -> input * flag = 5
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        gsetup.prove(variables=bad)
+    gsetup.close()
