@@ -37,27 +37,59 @@ __device__ __forceinline__ u64 omega_pow_nat(const u64 *tw, unsigned log_n, u32 
 }
 
 // P[j][row] = prod_{i in chunk j} (w_i + beta*k_i*x + gamma) / (w_i + beta*sigma_i + gamma);  out: [n_chunks][2][n]
+// A lane handles RAT_PTS rows (256 apart, so every access stays coalesced) of one chunk and inverts their denominators
+// together (Montgomery's trick: one F_p^2 inversion = one x^(p-2) chain per RAT_PTS rows instead of per row — the inversion
+// was 60 % of this kernel's multiplications).
+static constexpr int RAT_PTS = 4;
 __global__ void __launch_bounds__(256)
 copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas, size_t sig_stride, const u64 *non_res,
                           unsigned V, unsigned chunk, unsigned log_n, const u64 *tw, gl::e2 beta, gl::e2 gamma, u64 *out) {
     const size_t n = (size_t)1 << log_n;
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * (256 * RAT_PTS) + threadIdx.x;
     const unsigned j = blockIdx.y;
-    if (r >= n) return;
-    const u64 x = omega_pow_nat(tw, log_n, (u32)r);
-    gl::e2 num{1, 0}, den{1, 0};
-    for (unsigned i = j * chunk; i < (j + 1) * chunk && i < V; i++) {
-        u64 w = gl::canon(vars[(size_t)i * var_stride + r]);
-        u64 kx = gl::mul(non_res[i], x);
-        gl::e2 a{gl::add(gl::add(gl::mul(kx, beta.c0), w), gamma.c0), gl::add(gl::mul(kx, beta.c1), gamma.c1)};
-        u64 s = gl::canon(sigmas[(size_t)i * sig_stride + r]);
-        gl::e2 b{gl::add(gl::add(gl::mul(s, beta.c0), w), gamma.c0), gl::add(gl::mul(s, beta.c1), gamma.c1)};
-        num = gl::e2_mul(num, a);
-        den = gl::e2_mul(den, b);
+    gl::e2 num[RAT_PTS], den[RAT_PTS];
+    u64 x[RAT_PTS];
+#pragma unroll
+    for (int k = 0; k < RAT_PTS; k++) {
+        const size_t r = base + (size_t)k * 256;
+        x[k] = r < n ? omega_pow_nat(tw, log_n, (u32)r) : 0;
+        num[k] = {1, 0};
+        den[k] = {1, 0};
     }
-    gl::e2 p = gl::e2_mul(num, e2_inv_dev(den));
-    out[((size_t)2 * j) * n + r] = p.c0;
-    out[((size_t)2 * j + 1) * n + r] = p.c1;
+    for (unsigned i = j * chunk; i < (j + 1) * chunk && i < V; i++) {
+        const u64 kr = non_res[i];
+#pragma unroll
+        for (int k = 0; k < RAT_PTS; k++) {
+            const size_t r = base + (size_t)k * 256;
+            if (r >= n) continue;
+            u64 w = gl::canon(vars[(size_t)i * var_stride + r]);
+            u64 kx = gl::mul(kr, x[k]);
+            gl::e2 a{gl::add(gl::add(gl::mul(kx, beta.c0), w), gamma.c0), gl::add(gl::mul(kx, beta.c1), gamma.c1)};
+            u64 s = gl::canon(sigmas[(size_t)i * sig_stride + r]);
+            gl::e2 b{gl::add(gl::add(gl::mul(s, beta.c0), w), gamma.c0), gl::add(gl::mul(s, beta.c1), gamma.c1)};
+            num[k] = gl::e2_mul(num[k], a);
+            den[k] = gl::e2_mul(den[k], b);
+        }
+    }
+    // 1/den[k] for all k from one inversion: pre[k] = den[0..k-1], inv(all) walked back
+    gl::e2 pre[RAT_PTS], run{1, 0};
+#pragma unroll
+    for (int k = 0; k < RAT_PTS; k++) {
+        pre[k] = run;
+        run = gl::e2_mul(run, den[k]);
+    }
+    gl::e2 inv_run = e2_inv_dev(run);
+#pragma unroll
+    for (int k = RAT_PTS - 1; k >= 0; k--) {
+        const gl::e2 inv_k = gl::e2_mul(inv_run, pre[k]);
+        inv_run = gl::e2_mul(inv_run, den[k]);
+        const size_t r = base + (size_t)k * 256;
+        if (r < n) {
+            gl::e2 p = gl::e2_mul(num[k], inv_k);
+            out[((size_t)2 * j) * n + r] = p.c0;
+            out[((size_t)2 * j + 1) * n + r] = p.c1;
+        }
+    }
 }
 
 // in place: P[j] <- prod_{j' <= j} P[j'] per row; almost_z = last prefix
@@ -169,7 +201,7 @@ void launch_copy_perm_stage2(const u64 *d_vars, size_t var_stride, const u64 *d_
     u64 *P = d_tmp;
     u64 *block_tot = d_tmp + (size_t)2 * n_chunks * n;
     const unsigned rb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(copy_perm_rational_kernel, dim3(rb, n_chunks), dim3(256), 0, s, d_vars, var_stride, d_sigmas,
+    hipLaunchKernelGGL(copy_perm_rational_kernel, dim3((unsigned)((n + 256 * RAT_PTS - 1) / (256 * RAT_PTS)), n_chunks), dim3(256), 0, s, d_vars, var_stride, d_sigmas,
                        sig_stride, d_non_res, V, chunk, log_n, d_tw_fwd, b, g, P);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(rb), dim3(256), 0, s, P, n_chunks, n);
     const u64 *a0 = P + ((size_t)2 * (n_chunks - 1)) * n, *a1 = a0 + n;
@@ -191,28 +223,47 @@ lookup_polys_kernel(const u64 *lvars, size_t var_stride, const u64 *table_id, co
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const u64 tid = gl::canon(table_id[r]);
-    for (unsigned i = 0; i <= reps; i++) {   // i == reps -> the table aggregate (B)
-        gl::e2 acc = a.beta;
-        if (i < reps) {
-            for (unsigned j = 0; j < w; j++) {
-                u64 v = gl::canon(lvars[(size_t)(i * w + j) * var_stride + r]);
-                acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[j], v));
+    // the reps + 1 denominators of a row are inverted in groups of up to LK_GROUP with one F_p^2 inversion per group
+    constexpr unsigned LK_GROUP = 9;
+    for (unsigned g0 = 0; g0 <= reps; g0 += LK_GROUP) {
+        const unsigned cnt = (reps + 1 - g0) < LK_GROUP ? (reps + 1 - g0) : LK_GROUP;
+        gl::e2 den[LK_GROUP], pre[LK_GROUP], run{1, 0};
+#pragma unroll
+        for (unsigned k = 0; k < LK_GROUP; k++) {
+            if (k >= cnt) break;
+            const unsigned i = g0 + k;                       // i == reps -> the table aggregate (B)
+            gl::e2 acc = a.beta;
+            if (i < reps) {
+                for (unsigned j = 0; j < w; j++) {
+                    u64 v = gl::canon(lvars[(size_t)(i * w + j) * var_stride + r]);
+                    acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[j], v));
+                }
+                acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[w], tid));
+            } else {
+                for (unsigned j = 0; j <= w; j++) {
+                    u64 v = gl::canon(tables[(size_t)j * tab_stride + r]);
+                    acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[j], v));
+                }
             }
-            acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[w], tid));
-        } else {
-            for (unsigned j = 0; j <= w; j++) {
-                u64 v = gl::canon(tables[(size_t)j * tab_stride + r]);
-                acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[j], v));
-            }
+            den[k] = acc;
+            pre[k] = run;
+            run = gl::e2_mul(run, acc);
         }
-        gl::e2 inv = e2_inv_dev(acc);
-        if (i < reps) {
-            outA[((size_t)2 * i) * n + r] = inv.c0;
-            outA[((size_t)2 * i + 1) * n + r] = inv.c1;
-        } else {
-            gl::e2 b = gl::e2_mul_base(inv, gl::canon(mult[r]));
-            outB[r] = b.c0;
-            outB[n + r] = b.c1;
+        gl::e2 inv_run = e2_inv_dev(run);
+#pragma unroll
+        for (int k = (int)LK_GROUP - 1; k >= 0; k--) {
+            if ((unsigned)k >= cnt) continue;
+            const unsigned i = g0 + (unsigned)k;
+            const gl::e2 inv = gl::e2_mul(inv_run, pre[k]);
+            inv_run = gl::e2_mul(inv_run, den[k]);
+            if (i < reps) {
+                outA[((size_t)2 * i) * n + r] = inv.c0;
+                outA[((size_t)2 * i + 1) * n + r] = inv.c1;
+            } else {
+                gl::e2 bb = gl::e2_mul_base(inv, gl::canon(mult[r]));
+                outB[r] = bb.c0;
+                outB[n + r] = bb.c1;
+            }
         }
     }
 }
