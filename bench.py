@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--mode", choices=["auto", "sharded", "replicas"], default="auto")
+    ap.add_argument("--transcript", choices=["poseidon", "poseidon2"], default="poseidon",
+                    help="poseidon = the bench script's GoldilocksPoisedonTranscript (v1 permutation, no KAT in the reference); "
+                         "poseidon2 = the golden proof's transcript (pinned)")
     ap.add_argument("--fri-lde", type=int, default=8)
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
@@ -92,7 +95,7 @@ def main():
     ctx = E.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     comm = E.TorchComm(ctx) if sharded else None
-    setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security, comm=comm)
+    setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security, comm=comm, transcript=args.transcript)
     # witness resident in HBM (torch owns the allocations)
     d_vars = torch.from_numpy(circuit.variables.view(np.int64)).to(dev)
     d_mult = torch.from_numpy(circuit.multiplicities.view(np.int64)).to(dev)
@@ -153,8 +156,9 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": "%s: full prove of a SHA-256-shaped circuit, 2^%d rows (92 variable + 1 multiplicity "
-                               "columns, 8x4 lookups, LDE %d, cap %d, security %d, Poseidon2 tree + transcript, PoW off)"
-                               % ({22: "cfg4", 20: "cfg3"}.get(log_n, "custom"), log_n, args.fri_lde, args.cap, args.security),
+                               "columns, 8x4 lookups, LDE %d, cap %d, security %d, Poseidon2 tree hasher + %s transcript, PoW off)"
+                               % ({22: "cfg4", 20: "cfg3"}.get(log_n, "custom"), log_n, args.fri_lde, args.cap, args.security,
+                                  {"poseidon": "Poseidon (v1)", "poseidon2": "Poseidon2"}[args.transcript]),
                    "log_n": log_n, "rows": n, "circuit": "SHA-shaped satisfiable synthetic (seed 42)",
                    "sharding": ("one proof sharded by LDE cosets over %d GPUs (%d cosets = %d Merkle leaves each), all-gather of "
                                 "caps / quotient / first FRI layer / query openings, %d collectives and %.1f MB received per "
@@ -193,7 +197,7 @@ def main():
         from era_boojum_amd import proof_format
         from oracle import verifier as OV
         pg = proof_format.parse(proof_buf, security_level=args.security)
-        if not OV.verify(OV.VerificationKey(circuit, setup.cap(), args.fri_lde, args.cap), pg):
+        if not OV.verify(OV.VerificationKey(circuit, setup.cap(), args.fri_lde, args.cap), pg, transcript_kind=setup.transcript_kind):
             raise SystemExit("parity failure: the verifier restatement rejects the HIP proof")
         out["config"]["verified"] = "oracle/verifier.py accepts the last timed proof"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

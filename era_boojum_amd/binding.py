@@ -308,10 +308,11 @@ class Context:
 class Transcript:
     """Host-side Poseidon2 Fiat–Shamir transcript of the product (bj_transcript_*); needs no GPU."""
 
-    def __init__(self):
+    def __init__(self, kind=1):
+        """kind 1 = Poseidon2 (BJ_TRANSCRIPT_POSEIDON2), 2 = Poseidon v1 (BJ_TRANSCRIPT_POSEIDON)."""
         self._lib = load_library()
         h = C.c_void_p()
-        rc = self._lib.bj_transcript_create(1, C.byref(h))
+        rc = self._lib.bj_transcript_create(int(kind), C.byref(h))
         if rc != 0:
             raise BoojumHipError("bj_transcript_create failed: %d" % rc)
         self._h = h
@@ -424,7 +425,8 @@ class _Circuit(C.Structure):
 
 
 class _ProofConfig(C.Structure):
-    _fields_ = [("fri_lde_factor", C.c_uint), ("cap_size", C.c_uint), ("security_level", C.c_uint), ("pow_bits", C.c_uint)]
+    _fields_ = [("fri_lde_factor", C.c_uint), ("cap_size", C.c_uint), ("security_level", C.c_uint), ("pow_bits", C.c_uint),
+                ("transcript", C.c_uint)]
 
 
 STAGE_NAMES = ["witness_lde_and_tree", "second_stage", "quotient_work_and_lde", "openings_at_z",
@@ -496,7 +498,8 @@ class ProverSetup:
     `prove` / `prove_dev` become collective: every rank passes the same witness and gets the same proof
     (bj_setup_create_sharded)."""
 
-    def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, comm=None):
+    def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, comm=None,
+                 transcript="poseidon2"):
         self._ctx, self._lib, self.circuit = ctx, ctx._lib, circuit
         self._comm = comm
         self.fri_lde_factor, self.cap_size, self.security_level, self.pow_bits = fri_lde_factor, cap_size, security_level, pow_bits
@@ -519,7 +522,8 @@ class ProverSetup:
         cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, 0, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
                       c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
                       cols, rows)
-        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits)
+        self.transcript_kind = {"poseidon2": 1, "poseidon": 2}[transcript]
+        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind)
         sig = np.ascontiguousarray(c.sigmas, dtype=np.uint64)
         con = np.ascontiguousarray(c.constants, dtype=np.uint64)
         tab = np.ascontiguousarray(c.tables, dtype=np.uint64)

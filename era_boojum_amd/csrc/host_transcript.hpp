@@ -58,7 +58,41 @@ inline void poseidon2_permutation(u64 *s) {
     }
 }
 
+// Poseidon (v1), the round function of GoldilocksPoisedonTranscript (transcript.rs:133-141) which the reference's SHA-256
+// bench script uses next to the Poseidon2 tree hasher (gadgets/sha256/mod.rs:289-293):
+// implementations/poseidon_goldilocks_naive.rs:10-160 — every round adds its 12 constants, x^7 on all (full) or on
+// element 0 (partial), then the circulant MDS with power-of-two entries, here as shift-and-add on 128-bit integers.
+// The reference has no known-answer vector for it: checked against two independent restatements only.
+inline void poseidon1_permutation(u64 *s) {
+    static const unsigned EXPS[12] = {0, 0, 1, 0, 3, 5, 1, 8, 12, 3, 16, 10};
+    const u64 *RC = rc_table();
+    for (int i = 0; i < 12; i++) s[i] = gl::canon(s[i]);
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        for (int k = 0; k < 12; k++) s[k] = gl::add(s[k], RC[12 * r + k]);
+        for (int k = 0; k < (full ? 12 : 1); k++) s[k] = pow7(s[k]);
+        u64 out[12];
+        for (int row = 0; row < 12; row++) {
+            u64 lo = 0, hi = 0;   // 128-bit accumulator; the sum stays below 2^81
+            for (int col = 0; col < 12; col++) {
+                const unsigned e = EXPS[(col + 12 - row) % 12];
+                const u64 add_lo = s[col] << e, add_hi = e ? s[col] >> (64 - e) : 0;
+                const u64 t = lo + add_lo;
+                hi += add_hi + (t < lo ? 1 : 0);
+                lo = t;
+            }
+            out[row] = gl::add(gl::canon(lo), gl::mul(hi, 0xFFFFFFFFULL));   // 2^64 = 2^32 - 1
+        }
+        for (int k = 0; k < 12; k++) s[k] = out[k];
+    }
+}
+
 struct Transcript {
+    int kind = 1;                 // BJ_TRANSCRIPT_POSEIDON2 = 1, BJ_TRANSCRIPT_POSEIDON = 2
+    void permute() {
+        if (kind == 2) poseidon1_permutation(state);
+        else poseidon2_permutation(state);
+    }
     u64 state[12] = {0};
     std::vector<u64> buffer;
     u64 avail[8];
@@ -70,13 +104,13 @@ struct Transcript {
     u64 challenge() {
         if (buffer.empty()) {
             if (avail_pos < avail_len) return avail[avail_pos++];
-            poseidon2_permutation(state);
+            permute();
         } else {
             buffer.push_back(1);
             while (buffer.size() % 8) buffer.push_back(0);
             for (size_t i = 0; i < buffer.size(); i += 8) {
                 for (int k = 0; k < 8; k++) state[k] = buffer[i + k];
-                poseidon2_permutation(state);
+                permute();
             }
             buffer.clear();
         }

@@ -62,7 +62,7 @@ struct bj_setup {
     std::vector<u64> non_residues;
     std::vector<unsigned> pub_cols, pub_rows;
     // proof config
-    unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0;
+    unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0, transcript = BJ_TRANSCRIPT_POSEIDON2;
     unsigned L = 0, log_L = 0, log_fri = 0, log_q = 0;
     unsigned n_cols = 0;           // V sigmas + nC constants + (w+1) tables
     // shard of the LDE domain held by this GPU: cosets [c0, c0 + cl), i.e. flat indices [c0*n, (c0+cl)*n)
@@ -203,6 +203,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     if (!bj::is_pow2(c->quotient_degree) || !bj::is_pow2(cfg->fri_lde_factor) || cfg->fri_lde_factor < 2 ||
         !bj::is_pow2(cfg->cap_size))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: quotient degree / fri_lde_factor / cap must be powers of two");
+    if (cfg->transcript > BJ_TRANSCRIPT_POSEIDON) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: unknown transcript kind");
     if (cfg->pow_bits != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: PoW is not supported (benches run with pow_bits = 0)");
     if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || c->table_id_col >= c->num_constant_cols))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad lookup parameters");
@@ -264,6 +265,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         s->pub_rows.push_back(c->public_input_rows[i]);
     }
     s->fri_lde = cfg->fri_lde_factor; s->cap_size = cfg->cap_size; s->security = cfg->security_level; s->pow_bits = cfg->pow_bits;
+    s->transcript = cfg->transcript ? cfg->transcript : BJ_TRANSCRIPT_POSEIDON2;
     s->L = s->fri_lde > s->q ? s->fri_lde : s->q;   // used_lde_degree (prover.rs:313)
     s->log_L = bj::log2_exact(s->L); s->log_fri = bj::log2_exact(s->fri_lde); s->log_q = bj::log2_exact(s->q);
     const size_t n = (size_t)1 << s->log_n;
@@ -380,6 +382,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     } in_proof(ctx);
     StageTimer timer(st);
     bj::host::Transcript tr;
+    tr.kind = (int)S->transcript;
     tr.absorb(S->cap.data(), S->cap.size());                               // prover.rs:211
     if (!S->pub_cols.empty()) tr.absorb(h_public_values, S->pub_cols.size());   // prover.rs:257-259
     auto challenge2 = [&](u64 *o) {

@@ -188,6 +188,10 @@ int bj_deep_quotient_accumulate(bj_ctx *ctx, const uint64_t *const *h_src_c0, co
  * ------------------------------------------------------------------------------------------------------------- */
 typedef struct bj_transcript bj_transcript;
 #define BJ_TRANSCRIPT_POSEIDON2 1
+/* GoldilocksPoisedonTranscript (transcript.rs:133-141): the same sponge over the Poseidon (v1) permutation, which is what
+ * the SHA-256 bench script pairs with the Poseidon2 tree hasher (gadgets/sha256/mod.rs:289-293).  The reference holds no
+ * known-answer vector for that permutation. */
+#define BJ_TRANSCRIPT_POSEIDON 2
 int bj_transcript_create(int kind, bj_transcript **out);
 void bj_transcript_destroy(bj_transcript *t);
 int bj_transcript_absorb(bj_transcript *t, const uint64_t *els, size_t n);
@@ -305,6 +309,7 @@ typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */
     unsigned cap_size;
     unsigned security_level;
     unsigned pow_bits; /* must be 0 */
+    unsigned transcript; /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON */
 } bj_proof_config;
 
 typedef struct bj_setup bj_setup; /* device-resident SetupStorage + setup Merkle tree + VK cap; reusable across proofs */

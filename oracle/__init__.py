@@ -152,6 +152,13 @@ def poseidon2_permutation(state):
     return s
 
 
+def poseidon_permutation(state):
+    """Poseidon (v1, naive) permutation — bench-script transcript only."""
+    s = _arr(state).copy()
+    lib().orc_poseidon_permutation(_p(s))
+    return s
+
+
 def hash_leaf(els):
     e = _arr(els)
     out = np.zeros(4, dtype=np.uint64)
@@ -217,11 +224,17 @@ def merkle_verify(path, cap, leaf_hash, idx):
 
 
 # ---------------- transcript ----------------
-class Transcript:
-    """Poseidon2 algebraic transcript (transcript.rs:48-131, 144-151)."""
+TRANSCRIPT_POSEIDON2, TRANSCRIPT_POSEIDON = 1, 2
 
-    def __init__(self):
-        self._h = C.c_void_p(lib().orc_transcript_new())
+
+class Transcript:
+    """Algebraic sponge transcript (transcript.rs:48-131) over Poseidon2 (:144-151, the golden proof's) or, kind=2, over
+    the Poseidon (v1) permutation of the SHA-256 bench script (:133-141; no KAT exists for that permutation)."""
+
+    def __init__(self, kind=TRANSCRIPT_POSEIDON2):
+        lib().orc_transcript_new_kind.restype = C.c_void_p
+        self.kind = kind
+        self._h = C.c_void_p(lib().orc_transcript_new_kind(int(kind)))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -31,6 +31,7 @@ void orc_lde_batch(const uint64_t *mono, uint64_t *out, unsigned log_n, unsigned
 
 /* ---- poseidon2.c ---- */
 void orc_poseidon2_permutation(uint64_t *state12);
+void orc_poseidon_permutation(uint64_t *state12);   /* Poseidon v1 (naive), bench-script transcript only; parity unpinned */
 void orc_hash_leaf(const uint64_t *els, size_t n, uint64_t *out4);
 void orc_hash_node(const uint64_t *l4, const uint64_t *r4, uint64_t *out4);
 size_t orc_merkle_tree_digests(size_t num_leaves, size_t cap_size);
@@ -45,6 +46,7 @@ int orc_merkle_verify(const uint64_t *path, size_t depth, const uint64_t *cap, c
 /* ---- transcript.c ---- */
 typedef struct orc_transcript orc_transcript;
 orc_transcript *orc_transcript_new(void);
+orc_transcript *orc_transcript_new_kind(int kind);   /* 1 = Poseidon2, 2 = Poseidon (v1) */
 void orc_transcript_free(orc_transcript *t);
 void orc_transcript_absorb(orc_transcript *t, const uint64_t *els, size_t n);
 uint64_t orc_transcript_challenge(orc_transcript *t);

@@ -56,6 +56,34 @@ void orc_poseidon2_permutation(uint64_t *s) {     /* state_generic_impl.rs:221-2
     for (int i = 0; i < 4; i++) full_round(s, r++);
 }
 
+/* Poseidon (v1) permutation of the reference's naive implementation, used only by the GoldilocksPoisedonTranscript of
+ * the SHA-256 bench script (implementations/poseidon_goldilocks_naive.rs:10-160): 4 full + 22 partial + 4 full rounds; every
+ * round adds its 12 constants (ALL_ROUND_CONSTANTS, the same table Poseidon2 draws from), applies x^7 to all / to element 0,
+ * and multiplies by the circulant MDS matrix M[row][col] = 2^EXPS[(col - row) mod 12].
+ * PARITY UNPINNED: the reference holds no known-answer vector for this permutation (its tests compare the naive and the
+ * optimised implementation, poseidon_goldilocks.rs:1036-1076), and its matrix is not Plonky2's; it is cross-checked
+ * against an independent big-integer restatement (tests/test_poseidon1.py). */
+static const unsigned MDS_EXPS[12] = {0, 0, 1, 0, 3, 5, 1, 8, 12, 3, 16, 10};
+static void poseidon1_mds(gl_t *s) {
+    gl_t out[12];
+    for (int row = 0; row < 12; row++) {
+        unsigned __int128 acc = 0;                                      /* < 2^81 (poseidon_goldilocks_naive.rs:37-60) */
+        for (int col = 0; col < 12; col++) acc += (unsigned __int128)s[col] << MDS_EXPS[(col + 12 - row) % 12];
+        uint64_t lo = (uint64_t)acc, hi = (uint64_t)(acc >> 64);      /* hi < 2^17: hi * 2^64 = hi * (2^32 - 1) */
+        out[row] = gl_add(gl_canon(lo), gl_canon(hi * 0xFFFFFFFFULL));
+    }
+    memcpy(s, out, sizeof(out));
+}
+void orc_poseidon_permutation(uint64_t *s) {
+    for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
+    for (int r = 0; r < 30; r++) {
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], RC[12 * r + i]);
+        const int full = r < 4 || r >= 26;
+        for (int i = 0; i < (full ? 12 : 1); i++) s[i] = pow7(s[i]);
+        poseidon1_mds(s);
+    }
+}
+
 /* hash_into_leaf: sponge.rs:224-346 + oracle/mod.rs:141-151 */
 void orc_hash_leaf(const uint64_t *els, size_t n, uint64_t *out4) {
     gl_t st[12] = {0};

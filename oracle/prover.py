@@ -103,7 +103,8 @@ class Setup:
         self.cap = O.merkle_cap(self.tree, N, cap_size)
 
 
-def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, threads=1, return_aux=False):
+def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, threads=1, return_aux=False,
+          transcript_kind=1):
     assert pow_bits == 0, "PoW is off in the benches (sha256/mod.rs:313); not restated"
     c = circuit
     n, log_n = c.n, c.log_n
@@ -115,7 +116,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     N = n * fri_lde_factor
     Q = n * q
     has_lookup = c.lookup_reps > 0
-    t = O.Transcript()
+    t = O.Transcript(transcript_kind)   # 1: Poseidon2 (golden proof), 2: Poseidon v1 (the SHA-256 bench script)
     t.absorb_cap(setup.cap)                                # prover.rs:211
     pub_vals = [v for (_, _, v) in c.public_inputs]
     t.absorb(pub_vals)                                     # prover.rs:257-259

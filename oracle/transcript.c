@@ -11,11 +11,21 @@
 #include <string.h>
 
 struct orc_transcript {
+    int kind;                    /* 2: Poseidon (v1) round function (GoldilocksPoisedonTranscript, transcript.rs:133-141), else Poseidon2 */
     gl_t state[12];
     gl_t *buf; size_t buf_len, buf_cap;
     gl_t avail[8]; size_t avail_pos, avail_len;
 };
 orc_transcript *orc_transcript_new(void) { return (orc_transcript *)calloc(1, sizeof(orc_transcript)); }
+orc_transcript *orc_transcript_new_kind(int kind) {
+    orc_transcript *t = orc_transcript_new();
+    if (t) t->kind = kind;
+    return t;
+}
+static void round_function(orc_transcript *t) {
+    if (t->kind == 2) orc_poseidon_permutation(t->state);
+    else orc_poseidon2_permutation(t->state);
+}
 void orc_transcript_free(orc_transcript *t) { if (t) { free(t->buf); free(t); } }
 void orc_transcript_absorb(orc_transcript *t, const uint64_t *els, size_t n) {
     if (t->buf_len + n + 9 > t->buf_cap) {
@@ -27,13 +37,13 @@ void orc_transcript_absorb(orc_transcript *t, const uint64_t *els, size_t n) {
 uint64_t orc_transcript_challenge(orc_transcript *t) {
     if (t->buf_len == 0) {
         if (t->avail_pos < t->avail_len) return t->avail[t->avail_pos++];
-        orc_poseidon2_permutation(t->state);                 /* run_round_function + try_get_commitment */
+        round_function(t);                                   /* run_round_function + try_get_commitment */
     } else {
         t->buf[t->buf_len++] = 1;                            /* rescue-prime style padding */
         while (t->buf_len % 8) t->buf[t->buf_len++] = 0;
         for (size_t i = 0; i < t->buf_len; i += 8) {         /* overwrite absorption, one permutation per block */
             memcpy(t->state, t->buf + i, 8 * sizeof(gl_t));
-            orc_poseidon2_permutation(t->state);
+            round_function(t);
         }
         t->buf_len = 0;
     }

@@ -61,7 +61,7 @@ def _gate_terms_at(vk, var, con):
     return out
 
 
-def verify(vk, proof, verbose=False):
+def verify(vk, proof, verbose=False, transcript_kind=1):
     def fail(msg):
         if verbose:
             print("verify:", msg)
@@ -79,7 +79,7 @@ def verify(vk, proof, verbose=False):
     n_partials = n_chunks - 1
     nC = vk.num_constant_cols
     # ---- transcript replay (verifier.rs:924-1076)
-    t = O.Transcript()
+    t = O.Transcript(transcript_kind)
     t.absorb_cap(vk.setup_cap)
     t.absorb(proof["public_inputs"])
     t.absorb_cap(np.array(proof["witness_oracle_cap"], dtype=np.uint64))

@@ -116,3 +116,20 @@ def test_golden_pinned_quotient_identity_accepts_hip_proof():
                                     proof["values_at_z"], proof["values_at_z_omega"][0])
     assert lhs == rhs
     gsetup.close()
+
+
+def test_poseidon_v1_transcript_proof_equals_oracle_proof():
+    """The bench script's pairing: Poseidon2 tree hasher + Poseidon (v1) transcript (gadgets/sha256/mod.rs:289-293)."""
+    c = S.sha_shaped_circuit(10, seed=41, table_bits=2)
+    osetup = OP.Setup(c, 8, 16, threads=4)
+    po = OP.prove(c, osetup, 8, 16, security_level=40, threads=4, transcript_kind=2)
+    p2 = OP.prove(c, osetup, 8, 16, security_level=40, threads=4, transcript_kind=1)
+    assert po["values_at_z"] != p2["values_at_z"]            # different challenges, as expected
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 40, transcript="poseidon")
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=40)
+    _compare(pg, po)
+    vk = OV.VerificationKey(c, gsetup.cap(), 8, 16)
+    assert OV.verify(vk, pg, verbose=True, transcript_kind=2)
+    assert not OV.verify(vk, pg, transcript_kind=1)
+    gsetup.close()
