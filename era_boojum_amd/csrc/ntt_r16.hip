@@ -32,7 +32,7 @@ struct R16Args {
 };
 
 #ifndef BJ_R16_WAVES
-#define BJ_R16_WAVES 2   // min waves per SIMD requested from the register allocator (tuned on MI355X)
+#define BJ_R16_WAVES 3   // min waves per SIMD requested from the register allocator (tuned on MI355X: 2 -> 8.6 ms, 3 -> 7.9 ms, 4 -> 10.9 ms per 93 x 2^20 x 8 LDE)
 #endif
 static constexpr u32 TILE = 4096;
 static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
