@@ -63,6 +63,8 @@ _SIGNATURES = {
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
     "bj_transcript_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "bj_transcript_destroy": (None, [C.c_void_p]),
+    "bj_transcript_absorb_cap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bj_ctx_set_tree_hasher": (C.c_int, [C.c_void_p, C.c_int]),
     "bj_transcript_absorb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_transcript_challenge": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "bj_transcript_query_index": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]),
@@ -156,6 +158,10 @@ class Context:
                                              self._lib.bj_last_error(self._h).decode()))
 
     # -- plumbing
+    def set_tree_hasher(self, hasher):
+        """1 = Poseidon2 (default), 2 = Blake2s-256: hasher of the merkle_tree_* / fri calls on this context."""
+        self._check(self._lib.bj_ctx_set_tree_hasher(self._h, int(hasher)))
+
     def set_stream(self, stream_handle):
         self._check(self._lib.bj_ctx_set_stream(self._h, C.c_void_p(stream_handle)))
 
@@ -330,7 +336,11 @@ class Transcript:
                 raise BoojumHipError("bj_transcript_absorb failed: %d" % rc)
 
     def absorb_cap(self, cap):
-        self.absorb(cap)
+        a = np.ascontiguousarray(np.asarray(cap, dtype=np.uint64)).reshape(-1)
+        if a.size:
+            rc = self._lib.bj_transcript_absorb_cap(self._h, _np_ptr(a), a.size)
+            if rc != 0:
+                raise BoojumHipError("bj_transcript_absorb_cap failed: %d" % rc)
 
     def challenge(self):
         out = C.c_uint64()
@@ -426,7 +436,7 @@ class _Circuit(C.Structure):
 
 class _ProofConfig(C.Structure):
     _fields_ = [("fri_lde_factor", C.c_uint), ("cap_size", C.c_uint), ("security_level", C.c_uint), ("pow_bits", C.c_uint),
-                ("transcript", C.c_uint)]
+                ("transcript", C.c_uint), ("tree_hasher", C.c_uint)]
 
 
 STAGE_NAMES = ["witness_lde_and_tree", "second_stage", "quotient_work_and_lde", "openings_at_z",
@@ -522,8 +532,9 @@ class ProverSetup:
         cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, 0, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
                       c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
                       cols, rows)
-        self.transcript_kind = {"poseidon2": 1, "poseidon": 2}[transcript]
-        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind)
+        self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3}[transcript]
+        self.hasher_kind = 2 if transcript == "blake2s" else 1      # Transcript::CompatibleCap = TreeHasher::Output
+        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind, self.hasher_kind)
         sig = np.ascontiguousarray(c.sigmas, dtype=np.uint64)
         con = np.ascontiguousarray(c.constants, dtype=np.uint64)
         tab = np.ascontiguousarray(c.tables, dtype=np.uint64)

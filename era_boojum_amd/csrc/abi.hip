@@ -218,6 +218,14 @@ int bj_memcpy_d2d(bj_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
     return BJ_OK;
 }
 
+int bj_ctx_set_tree_hasher(bj_ctx *ctx, int hasher) {
+    if (int rc = bind(ctx)) return rc;
+    if (hasher != BJ_HASHER_POSEIDON2 && hasher != BJ_HASHER_BLAKE2S)
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ctx_set_tree_hasher: unknown hasher %d", hasher);
+    ctx->hasher = hasher;
+    return BJ_OK;
+}
+
 int bj_timer_start(bj_ctx *ctx) {
     if (int rc = bind(ctx)) return rc;
     BJ_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -400,7 +408,7 @@ static int check_tree_args(bj_ctx *ctx, const char *fn, size_t num_leaves, size_
 int bj_merkle_tree_nodes(bj_ctx *ctx, uint64_t *d_tree, size_t num_leaves, size_t cap_size) {
     if (int rc = bind(ctx)) return rc;
     if (int rc = check_tree_args(ctx, "bj_merkle_tree_nodes", num_leaves, cap_size, d_tree)) return rc;
-    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    bj::launch_tree_node_layers(ctx->hasher, d_tree, num_leaves, cap_size, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }
@@ -412,8 +420,8 @@ int bj_merkle_tree_build(bj_ctx *ctx, const uint64_t *d_cols, size_t col_stride,
     if (!d_cols || n_cols == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build: no columns");
     if (n_cols > 1 && col_stride < num_leaves)
         return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build: col_stride smaller than num_leaves");
-    bj::launch_poseidon2_leaves(d_cols, col_stride, nullptr, n_cols, num_leaves, d_tree, ctx->stream);
-    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    bj::launch_tree_leaves(ctx->hasher, d_cols, col_stride, nullptr, n_cols, num_leaves, d_tree, ctx->stream);
+    bj::launch_tree_node_layers(ctx->hasher, d_tree, num_leaves, cap_size, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }
@@ -439,8 +447,8 @@ int bj_merkle_tree_build_ptrs(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, un
     BJ_HIP(ctx, hipMemcpyAsync((void *)ctx->d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *), hipMemcpyHostToDevice,
                                ctx->stream));
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's pointer array may be transient
-    bj::launch_poseidon2_leaves(nullptr, 0, ctx->d_ptrs, n_cols, num_leaves, d_tree, ctx->stream);
-    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    bj::launch_tree_leaves(ctx->hasher, nullptr, 0, ctx->d_ptrs, n_cols, num_leaves, d_tree, ctx->stream);
+    bj::launch_tree_node_layers(ctx->hasher, d_tree, num_leaves, cap_size, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }
@@ -453,8 +461,8 @@ int bj_merkle_tree_build_chunked(bj_ctx *ctx, const uint64_t *d_c0, const uint64
         return fail(ctx, BJ_ERR_INVALID_ARG, "bj_merkle_tree_build_chunked: bad length / elements per leaf");
     size_t num_leaves = len >> log_elems_per_leaf;
     if (int rc = check_tree_args(ctx, "bj_merkle_tree_build_chunked", num_leaves, cap_size, d_tree)) return rc;
-    bj::launch_poseidon2_leaves_chunked(d_c0, d_c1, 2, log_elems_per_leaf, num_leaves, d_tree, ctx->stream);
-    bj::launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, ctx->stream);
+    bj::launch_tree_leaves_chunked(ctx->hasher, d_c0, d_c1, 2, log_elems_per_leaf, num_leaves, d_tree, ctx->stream);
+    bj::launch_tree_node_layers(ctx->hasher, d_tree, num_leaves, cap_size, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

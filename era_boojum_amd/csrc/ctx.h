@@ -25,6 +25,7 @@ struct bj_ctx {
     // synchronising); grown on demand, reset at the start of every bj_prove_dev
     gl::u64 *arena = nullptr;
     size_t arena_elems = 0, arena_off = 0;
+    int hasher = BJ_HASHER_POSEIDON2;   // tree hasher of the bj_merkle_tree_* calls (bj_ctx_set_tree_hasher / bj_prove)
     bool in_proof = false;       // bj_prove_dev is running: temporaries come out of the arena instead of hipMalloc
 };
 

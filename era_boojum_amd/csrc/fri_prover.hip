@@ -18,7 +18,7 @@ extern "C" {
 int bj_transcript_create(int kind, bj_transcript **out) {
     if (!out) return BJ_ERR_INVALID_ARG;
     *out = nullptr;
-    if (kind != BJ_TRANSCRIPT_POSEIDON2 && kind != BJ_TRANSCRIPT_POSEIDON) return BJ_ERR_UNSUPPORTED;
+    if (kind != BJ_TRANSCRIPT_POSEIDON2 && kind != BJ_TRANSCRIPT_POSEIDON && kind != BJ_TRANSCRIPT_BLAKE2S) return BJ_ERR_UNSUPPORTED;
     *out = new bj_transcript();
     (*out)->t.kind = kind;
     return BJ_OK;
@@ -27,6 +27,11 @@ void bj_transcript_destroy(bj_transcript *t) { delete t; }
 int bj_transcript_absorb(bj_transcript *t, const uint64_t *els, size_t n) {
     if (!t || (!els && n)) return BJ_ERR_INVALID_ARG;
     t->t.absorb(els, n);
+    return BJ_OK;
+}
+int bj_transcript_absorb_cap(bj_transcript *t, const uint64_t *digest_words, size_t n_words) {
+    if (!t || (!digest_words && n_words)) return BJ_ERR_INVALID_ARG;
+    t->t.absorb_cap(digest_words, n_words);
     return BJ_OK;
 }
 int bj_transcript_challenge(bj_transcript *t, uint64_t *out) {
@@ -161,7 +166,7 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
         else
             rc = bj::gather_cap(ctx, sh, oo.d_tree, oo.num_leaves, cap_size, oo.cap.data());
         if (rc) return bail(rc);
-        tr->t.absorb(oo.cap.data(), oo.cap.size());
+        tr->t.absorb_cap(oo.cap.data(), oo.cap.size());
         oo.ch0 = tr->t.challenge();
         oo.ch1 = tr->t.challenge();
         // fold by 2^k in one fused launch; alpha and kappa are squared per inner fold inside the kernel

@@ -7,6 +7,7 @@
 #pragma once
 #include "gl.cuh"
 #include "poseidon_rc.inc"
+#include <cstdint>
 #include <vector>
 
 namespace bj {
@@ -87,8 +88,110 @@ inline void poseidon1_permutation(u64 *s) {
     }
 }
 
+// Blake2s-256 (RFC 7693, unkeyed) with the update / finalize_reset interface of the `blake2` crate the reference uses.
+struct Blake2s {
+    uint32_t h[8];
+    unsigned char buf[64];
+    size_t buf_len = 0;
+    uint64_t t = 0;
+    Blake2s() { reset(); }
+    void reset() {
+        static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+        for (int i = 0; i < 8; i++) h[i] = IV[i];
+        h[0] ^= 0x01010020u;
+        buf_len = 0;
+        t = 0;
+    }
+    static uint32_t rotr(uint32_t x, unsigned n) { return (x >> n) | (x << (32 - n)); }
+    void compress(const unsigned char *block, bool last) {
+        static const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+        static const unsigned char SIGMA[10][16] = {
+            {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+            {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+            {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+            {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+            {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+        uint32_t m[16], v[16];
+        for (int i = 0; i < 16; i++)
+            m[i] = (uint32_t)block[4 * i] | ((uint32_t)block[4 * i + 1] << 8) | ((uint32_t)block[4 * i + 2] << 16) | ((uint32_t)block[4 * i + 3] << 24);
+        for (int i = 0; i < 8; i++) {
+            v[i] = h[i];
+            v[8 + i] = IV[i];
+        }
+        v[12] ^= (uint32_t)t;
+        v[13] ^= (uint32_t)(t >> 32);
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, uint32_t x, uint32_t y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr(v[d] ^ v[a], 16); v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 12);
+            v[a] = v[a] + v[b] + y; v[d] = rotr(v[d] ^ v[a], 8);  v[c] = v[c] + v[d]; v[b] = rotr(v[b] ^ v[c], 7);
+        };
+        for (int r = 0; r < 10; r++) {
+            const unsigned char *s = SIGMA[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+    }
+    void update(const unsigned char *data, size_t n) {
+        while (n) {
+            if (buf_len == 64) {   // a full buffer is only compressed when more input follows (the last block is special)
+                t += 64;
+                compress(buf, false);
+                buf_len = 0;
+            }
+            size_t take = 64 - buf_len < n ? 64 - buf_len : n;
+            for (size_t i = 0; i < take; i++) buf[buf_len + i] = data[i];
+            buf_len += take;
+            data += take;
+            n -= take;
+        }
+    }
+    void finalize_reset(unsigned char out[32]) {
+        t += buf_len;
+        for (size_t i = buf_len; i < 64; i++) buf[i] = 0;
+        compress(buf, true);
+        for (int i = 0; i < 8; i++)
+            for (int b = 0; b < 4; b++) out[4 * i + b] = (unsigned char)(h[i] >> (8 * b));
+        reset();
+    }
+};
+
 struct Transcript {
-    int kind = 1;                 // BJ_TRANSCRIPT_POSEIDON2 = 1, BJ_TRANSCRIPT_POSEIDON = 2
+    int kind = 1;                 // BJ_TRANSCRIPT_POSEIDON2 = 1, BJ_TRANSCRIPT_POSEIDON = 2, BJ_TRANSCRIPT_BLAKE2S = 3
+    // --- byte transcript (Blake2sTranscript, transcript.rs:155-262)
+    Blake2s inner;
+    std::vector<unsigned char> bytes, avail_bytes;
+    void reseed() {
+        unsigned char out[32];
+        inner.finalize_reset(out);
+        inner.update(out, 32);
+        avail_bytes.assign(out, out + 32);
+    }
+    void flush_bytes() {
+        if (!bytes.empty()) {
+            inner.update(bytes.data(), bytes.size());
+            bytes.clear();
+            reseed();
+        }
+    }
+    void challenge_bytes(unsigned char *out, size_t n) {   // get_challenge_bytes
+        flush_bytes();
+        while (avail_bytes.size() < n) reseed();
+        for (size_t i = 0; i < n; i++) out[i] = avail_bytes[i];
+        avail_bytes.erase(avail_bytes.begin(), avail_bytes.begin() + n);
+    }
+    // Merkle caps: digests of the tree hasher.  Algebraic transcripts take them as field elements, the byte transcript
+    // as their 32 raw bytes each (witness_merkle_tree_cap)
+    void absorb_cap(const u64 *digest_words, size_t n_words) {
+        if (kind != 3) {
+            absorb(digest_words, n_words);
+            return;
+        }
+        for (size_t i = 0; i < n_words; i++)
+            for (int b = 0; b < 8; b++) bytes.push_back((unsigned char)(digest_words[i] >> (8 * b)));
+    }
     void permute() {
         if (kind == 2) poseidon1_permutation(state);
         else poseidon2_permutation(state);
@@ -99,9 +202,26 @@ struct Transcript {
     size_t avail_pos = 0, avail_len = 0;
 
     void absorb(const u64 *els, size_t n) {
+        if (kind == 3) {   // witness_field_elements: as_u64_reduced().to_le_bytes()
+            for (size_t i = 0; i < n; i++) {
+                const u64 v = gl::canon(els[i]);
+                for (int b = 0; b < 8; b++) bytes.push_back((unsigned char)(v >> (8 * b)));
+            }
+            return;
+        }
         for (size_t i = 0; i < n; i++) buffer.push_back(gl::canon(els[i]));
     }
     u64 challenge() {
+        if (kind == 3) {   // get_challenge: 8 bytes, little endian, from_u64_with_reduction
+            unsigned char b8[8];
+            flush_bytes();
+            if (avail_bytes.empty()) reseed();
+            for (int i = 0; i < 8; i++) b8[i] = avail_bytes[i];
+            avail_bytes.erase(avail_bytes.begin(), avail_bytes.begin() + 8);
+            u64 x = 0;
+            for (int i = 0; i < 8; i++) x |= (u64)b8[i] << (8 * i);
+            return gl::canon(x);
+        }
         if (buffer.empty()) {
             if (avail_pos < avail_len) return avail[avail_pos++];
             permute();
@@ -130,6 +250,14 @@ struct BoolsBuffer {
         while (bits.size() - pos < need) {
             bits.erase(bits.begin(), bits.begin() + pos);
             pos = 0;
+            if (t.kind == 3) {   // non-algebraic transcripts hand out 8 uniform bytes, all 64 bits are used (transcript.rs:398-411)
+                unsigned char b8[8];
+                t.challenge_bytes(b8, 8);
+                u64 x = 0;
+                for (int i = 0; i < 8; i++) x |= (u64)b8[i] << (8 * i);
+                for (unsigned i = 0; i < 64; i++) bits.push_back((x >> i) & 1);
+                continue;
+            }
             u64 x = gl::canon(t.challenge());
             for (unsigned i = 0; i < 64 - max_needed; i++) bits.push_back((x >> i) & 1);
         }

@@ -35,6 +35,12 @@ void launch_poseidon2_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsig
                                      size_t num_leaves, u64 *d_digests, hipStream_t s);
 void launch_poseidon2_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s);
 void launch_poseidon2_permute_states(u64 *d_states, size_t n_states, hipStream_t s);
+// blake2s.hip: the same tree with Blake2s-256 digests, and the hasher-dispatching entry points (hasher = BJ_HASHER_*)
+void launch_tree_leaves(int hasher, const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
+                        size_t num_leaves, u64 *d_digests, hipStream_t s);
+void launch_tree_leaves_chunked(int hasher, const u64 *d_src0, const u64 *d_src1, unsigned n_srcs, unsigned log_e,
+                                size_t num_leaves, u64 *d_digests, hipStream_t s);
+void launch_tree_node_layers(int hasher, u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s);
 
 // fri.hip
 void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u64 *d_o1, const u64 *d_roots,

@@ -226,7 +226,10 @@ __global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
 // ---------------------------------------------------------------------------------------------------------
 static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_cosets) {
     // amortise the per-workgroup twiddle preparation over several columns, but keep >= ~4096 workgroups in flight
-    unsigned cpb = 8;
+#ifndef BJ_R16_CPB
+#define BJ_R16_CPB 8
+#endif
+    unsigned cpb = BJ_R16_CPB;
     while (cpb > 1 && (size_t)tiles * ((n_cols + cpb - 1) / cpb) * n_cosets < 4096) cpb >>= 1;
     return cpb;
 }

@@ -62,7 +62,7 @@ struct bj_setup {
     std::vector<u64> non_residues;
     std::vector<unsigned> pub_cols, pub_rows;
     // proof config
-    unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0, transcript = BJ_TRANSCRIPT_POSEIDON2;
+    unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0, transcript = BJ_TRANSCRIPT_POSEIDON2, hasher = BJ_HASHER_POSEIDON2;
     unsigned L = 0, log_L = 0, log_fri = 0, log_q = 0;
     unsigned n_cols = 0;           // V sigmas + nC constants + (w+1) tables
     // shard of the LDE domain held by this GPU: cosets [c0, c0 + cl), i.e. flat indices [c0*n, (c0+cl)*n)
@@ -203,7 +203,13 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     if (!bj::is_pow2(c->quotient_degree) || !bj::is_pow2(cfg->fri_lde_factor) || cfg->fri_lde_factor < 2 ||
         !bj::is_pow2(cfg->cap_size))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: quotient degree / fri_lde_factor / cap must be powers of two");
-    if (cfg->transcript > BJ_TRANSCRIPT_POSEIDON) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: unknown transcript kind");
+    {
+        const unsigned tk = cfg->transcript ? cfg->transcript : BJ_TRANSCRIPT_POSEIDON2, hk = cfg->tree_hasher ? cfg->tree_hasher : BJ_HASHER_POSEIDON2;
+        if (tk > BJ_TRANSCRIPT_BLAKE2S || hk > BJ_HASHER_BLAKE2S) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: unknown transcript / tree hasher");
+        if ((hk == BJ_HASHER_BLAKE2S) != (tk == BJ_TRANSCRIPT_BLAKE2S))   // Transcript::CompatibleCap = TreeHasher::Output (prover.rs:153-168)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: the Blake2s tree hasher goes with the Blake2s transcript and the "
+                                                     "Poseidon2 tree hasher with an algebraic transcript");
+    }
     if (cfg->pow_bits != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: PoW is not supported (benches run with pow_bits = 0)");
     if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || c->table_id_col >= c->num_constant_cols))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad lookup parameters");
@@ -226,6 +232,12 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     }
     bj_setup *s = new bj_setup();
     s->device = ctx->device;
+    struct HasherGuard {   // the tree kernels of the calls below follow the proof config, then the context's own setting returns
+        bj_ctx *c;
+        int saved;
+        ~HasherGuard() { c->hasher = saved; }
+    } hasher_guard{ctx, ctx->hasher};
+    ctx->hasher = cfg->tree_hasher ? (int)cfg->tree_hasher : BJ_HASHER_POSEIDON2;
     if (comm && comm->world > 1) {
         s->sh.rank = comm->rank;
         s->sh.world = comm->world;
@@ -266,6 +278,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     }
     s->fri_lde = cfg->fri_lde_factor; s->cap_size = cfg->cap_size; s->security = cfg->security_level; s->pow_bits = cfg->pow_bits;
     s->transcript = cfg->transcript ? cfg->transcript : BJ_TRANSCRIPT_POSEIDON2;
+    s->hasher = cfg->tree_hasher ? cfg->tree_hasher : BJ_HASHER_POSEIDON2;
     s->L = s->fri_lde > s->q ? s->fri_lde : s->q;   // used_lde_degree (prover.rs:313)
     s->log_L = bj::log2_exact(s->L); s->log_fri = bj::log2_exact(s->fri_lde); s->log_q = bj::log2_exact(s->q);
     const size_t n = (size_t)1 << s->log_n;
@@ -380,10 +393,16 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         explicit InProof(bj_ctx *x) : c(x) { c->in_proof = true; }
         ~InProof() { c->in_proof = false; }
     } in_proof(ctx);
+    struct HasherGuard {
+        bj_ctx *c;
+        int saved;
+        ~HasherGuard() { c->hasher = saved; }
+    } hasher_guard{ctx, ctx->hasher};
+    ctx->hasher = (int)S->hasher;
     StageTimer timer(st);
     bj::host::Transcript tr;
     tr.kind = (int)S->transcript;
-    tr.absorb(S->cap.data(), S->cap.size());                               // prover.rs:211
+    tr.absorb_cap(S->cap.data(), S->cap.size());                           // prover.rs:211
     if (!S->pub_cols.empty()) tr.absorb(h_public_values, S->pub_cols.size());   // prover.rs:257-259
     auto challenge2 = [&](u64 *o) {
         o[0] = tr.challenge();
@@ -402,15 +421,15 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
     // witness tree; the leaf kernel (the dominant kernel of a proof) is bracketed by HIP events on the launch stream
     BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
-    bj::launch_poseidon2_leaves(wit_lde.p, Ln, nullptr, nW, N, wit_tree.p, st);
+    bj::launch_tree_leaves(ctx->hasher, wit_lde.p, Ln, nullptr, nW, N, wit_tree.p, st);
     BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
-    bj::launch_poseidon2_node_layers(wit_tree.p, N, capl, st);
+    bj::launch_tree_node_layers(ctx->hasher, wit_tree.p, N, capl, st);
     BJ_CHECK_LAUNCH(ctx);
     std::vector<u64> wit_cap(4 * cap), s2_cap(4 * cap), q_cap(4 * cap);
     rc = bj::gather_cap(ctx, sh, wit_tree.p, N, cap, wit_cap.data());
     if (rc) return rc;
     BJ_HIP(ctx, hipEventElapsedTime(&proof->stage_ms[7], ctx->ev0, ctx->ev1));
-    tr.absorb(wit_cap.data(), wit_cap.size());
+    tr.absorb_cap(wit_cap.data(), wit_cap.size());
     proof->stage_ms[0] = timer.lap();
 
     // ---------------- round 2: copy-permutation + lookup polys (prover.rs:360-554) ----------------
@@ -439,7 +458,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     rc = bj_merkle_tree_build(ctx, s2_lde.p, Ln, nS2, N, capl, s2_tree.p);
     if (!rc) rc = bj::gather_cap(ctx, sh, s2_tree.p, N, cap, s2_cap.data());
     if (rc) return rc;
-    tr.absorb(s2_cap.data(), s2_cap.size());
+    tr.absorb_cap(s2_cap.data(), s2_cap.size());
     proof->stage_ms[1] = timer.lap();
 
     // ---------------- round 3: quotient (prover.rs:560-1495) ----------------
@@ -525,7 +544,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     rc = bj_merkle_tree_build(ctx, q_lde.p, N, 2 * q, N, capl, q_tree.p);
     if (!rc) rc = bj::gather_cap(ctx, sh, q_tree.p, N, cap, q_cap.data());
     if (rc) return rc;
-    tr.absorb(q_cap.data(), q_cap.size());
+    tr.absorb_cap(q_cap.data(), q_cap.size());
     proof->stage_ms[2] = timer.lap();
 
     // ---------------- round 4: openings (prover.rs:1501-1802) ----------------

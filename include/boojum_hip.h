@@ -61,6 +61,9 @@ int bj_free(bj_ctx *ctx, void *d_ptr);
 int bj_memcpy_h2d(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int bj_memcpy_d2d(bj_ctx *ctx, void *d_dst, const void *d_src, size_t bytes); /* stream-ordered, then synchronised */
+/* Tree hasher used by the bj_merkle_tree_* / bj_fri_prove calls on this context (BJ_HASHER_*, default Poseidon2);
+ * bj_prove sets it from its proof config for the duration of the proof. */
+int bj_ctx_set_tree_hasher(bj_ctx *ctx, int hasher);
 
 /* HIP-event stopwatch on the context's stream (used by bench.py to time the kernels where they are launched). */
 int bj_timer_start(bj_ctx *ctx);
@@ -192,9 +195,18 @@ typedef struct bj_transcript bj_transcript;
  * the SHA-256 bench script pairs with the Poseidon2 tree hasher (gadgets/sha256/mod.rs:289-293).  The reference holds no
  * known-answer vector for that permutation. */
 #define BJ_TRANSCRIPT_POSEIDON 2
+/* Blake2sTranscript (transcript.rs:155-262): byte transcript over Blake2s-256 (RFC 7693), paired with the Blake2s tree
+ * hasher in the non-recursive configuration (gadgets/sha256/mod.rs:265-270).  Caps are absorbed as raw digest bytes. */
+#define BJ_TRANSCRIPT_BLAKE2S 3
+
+/* Tree hashers (TreeHasher impls, src/cs/oracle/mod.rs:114-245).  Digests are 32 bytes = four u64 words either way. */
+#define BJ_HASHER_POSEIDON2 1 /* GoldilocksPoseidon2Sponge<AbsorptionModeOverwrite>: four canonical field elements */
+#define BJ_HASHER_BLAKE2S 2   /* blake2::Blake2s256: the 32 digest bytes, little-endian packed into the four words */
 int bj_transcript_create(int kind, bj_transcript **out);
 void bj_transcript_destroy(bj_transcript *t);
 int bj_transcript_absorb(bj_transcript *t, const uint64_t *els, size_t n);
+/* witness_merkle_tree_cap: digests as 4 u64 words each; field elements for the algebraic transcripts, raw bytes for Blake2s */
+int bj_transcript_absorb_cap(bj_transcript *t, const uint64_t *digest_words, size_t n_words);
 int bj_transcript_challenge(bj_transcript *t, uint64_t *out);
 int bj_transcript_query_index(bj_transcript *t, unsigned log_n, unsigned log_lde, uint64_t *out_index);
 
@@ -309,7 +321,9 @@ typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */
     unsigned cap_size;
     unsigned security_level;
     unsigned pow_bits; /* must be 0 */
-    unsigned transcript; /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON */
+    unsigned transcript;  /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON, BJ_TRANSCRIPT_BLAKE2S */
+    unsigned tree_hasher; /* 0 or BJ_HASHER_POSEIDON2 (default, with an algebraic transcript), BJ_HASHER_BLAKE2S (with
+                           * BJ_TRANSCRIPT_BLAKE2S): the transcript's CompatibleCap must be the hasher's Output */
 } bj_proof_config;
 
 typedef struct bj_setup bj_setup; /* device-resident SetupStorage + setup Merkle tree + VK cap; reusable across proofs */

@@ -82,10 +82,19 @@ def quotient(vars_q, consts_q, sigmas_q, z_q, partials_q, A_q, B_q, mult_q, tabl
     return out
 
 
+def hashing_layer(hasher):
+    """The module providing merkle_* / Transcript / QueryIndexer / do_fri for a tree hasher."""
+    if hasher == 2:
+        from oracle import blake
+        return blake
+    return O
+
+
 class Setup:
     """get_full_setup's prover-side outputs (setup.rs:1273-1300): setup LDEs, the setup tree and the VK cap."""
 
-    def __init__(self, circuit, fri_lde_factor, cap_size, threads=1):
+    def __init__(self, circuit, fri_lde_factor, cap_size, threads=1, hasher=1):
+        H = hashing_layer(hasher)            # 1: Poseidon2 sponge, 2: Blake2s-256 (oracle/blake.py)
         c = self.circuit = circuit
         self.fri_lde = fri_lde_factor
         self.cap_size = cap_size
@@ -99,8 +108,8 @@ class Setup:
         self.lde = O.lde_batch(self.mono, self.log_L, threads)            # [cols][L][n]
         N = n * fri_lde_factor
         self.leaves_view = np.ascontiguousarray(self.lde[:, :fri_lde_factor, :].reshape(-1, N))
-        self.tree = O.merkle_construct(self.leaves_view, cap_size, threads)
-        self.cap = O.merkle_cap(self.tree, N, cap_size)
+        self.tree = H.merkle_construct(self.leaves_view, cap_size, threads)
+        self.cap = H.merkle_cap(self.tree, N, cap_size)
 
 
 def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, threads=1, return_aux=False,
@@ -116,7 +125,10 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     N = n * fri_lde_factor
     Q = n * q
     has_lookup = c.lookup_reps > 0
-    t = O.Transcript(transcript_kind)   # 1: Poseidon2 (golden proof), 2: Poseidon v1 (the SHA-256 bench script)
+    # transcript 1: Poseidon2 (golden proof), 2: Poseidon v1 (SHA-256 bench script), 3: Blake2s (non-recursive config, with the
+    # Blake2s tree hasher: Transcript::CompatibleCap = TreeHasher::Output)
+    H = hashing_layer(2 if transcript_kind == 3 else 1)
+    t = H.Transcript(transcript_kind)
     t.absorb_cap(setup.cap)                                # prover.rs:211
     pub_vals = [v for (_, _, v) in c.public_inputs]
     t.absorb(pub_vals)                                     # prover.rs:257-259
@@ -125,8 +137,8 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
         mono = O.ifft_batch(cols_nat, 1, threads)
         lde = O.lde_batch(mono, log_L, threads)
         view = np.ascontiguousarray(lde[:, :fri_lde_factor, :].reshape(-1, N))
-        tree = O.merkle_construct(view, cap_size, threads)
-        return lde, view, tree, O.merkle_cap(tree, N, cap_size)
+        tree = H.merkle_construct(view, cap_size, threads)
+        return lde, view, tree, H.merkle_cap(tree, N, cap_size)
 
     # ---- round 1: witness (prover.rs:270-353); leaf = variables || witness || multiplicities
     wit_nat = np.concatenate([c.variables, c.multiplicities], axis=0) if has_lookup else c.variables
@@ -174,8 +186,8 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
         chunks += [qmono[0][j * n:(j + 1) * n], qmono[1][j * n:(j + 1) * n]]
     q_lde = O.lde_batch(np.stack(chunks), log_fri, threads)             # LDE only to fri_lde_factor (prover.rs:1473-1480)
     q_view = np.ascontiguousarray(q_lde.reshape(-1, N))
-    q_tree = O.merkle_construct(q_view, cap_size, threads)
-    q_cap = O.merkle_cap(q_tree, N, cap_size)
+    q_tree = H.merkle_construct(q_view, cap_size, threads)
+    q_cap = H.merkle_cap(q_tree, N, cap_size)
     t.absorb_cap(q_cap)
     # ---- round 4: openings (prover.rs:1501-1802)
     z = t.challenge_ext()
@@ -258,13 +270,13 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     assert off == len(chs)
     # ---- round 5b: FRI (prover.rs:2075-2105)
     new_pow, num_queries, sched, final_degree = O.fri_schedule(security_level, cap_size, pow_bits, log_fri, log_n)
-    fri = O.do_fri(d0, d1, log_fri, sched, cap_size, t, threads)
+    fri = H.do_fri(d0, d1, log_fri, sched, cap_size, t, threads)
     # ---- round 6: queries (prover.rs:2161-2266)
-    qi = O.QueryIndexer(log_n, log_fri)
+    qi = H.QueryIndexer(log_n, log_fri)
     queries = []
 
     def open_base(view, tree, idx):
-        lh, path = O.merkle_proof(tree, N, cap_size, idx)
+        lh, path = H.merkle_proof(tree, N, cap_size, idx)
         return {"leaf_elements": [int(x) for x in view[:, idx]], "proof": [[int(x) for x in p] for p in path]}
 
     for _ in range(num_queries):
@@ -279,7 +291,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
             j = f_idx >> k
             s0, s1 = srcs[i]
             leaf = np.concatenate([s0[j * E:(j + 1) * E], s1[j * E:(j + 1) * E]])
-            lh, path = O.merkle_proof(fri["trees"][i], ln >> k, cap_size, j)
+            lh, path = H.merkle_proof(fri["trees"][i], ln >> k, cap_size, j)
             qd["fri_queries"].append({"leaf_elements": [int(x) for x in leaf], "proof": [[int(x) for x in p] for p in path]})
             f_idx >>= k
             ln >>= k

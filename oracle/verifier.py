@@ -79,7 +79,9 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
     n_partials = n_chunks - 1
     nC = vk.num_constant_cols
     # ---- transcript replay (verifier.rs:924-1076)
-    t = O.Transcript(transcript_kind)
+    from oracle.prover import hashing_layer
+    H = hashing_layer(2 if transcript_kind == 3 else 1)
+    t = H.Transcript(transcript_kind)
     t.absorb_cap(vk.setup_cap)
     t.absorb(proof["public_inputs"])
     t.absorb_cap(np.array(proof["witness_oracle_cap"], dtype=np.uint64))
@@ -206,7 +208,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
     while len(chs) < total_ch:
         chs.append(emul(chs[-1], cch))
     roots = O.twiddles(LOGN, inverse=True)
-    qi = O.QueryIndexer(log_n, log_fri)
+    qi = H.QueryIndexer(log_n, log_fri)
     z_omega = escale(z, om)
     base = lambda l: [(e, 0) for e in l]
     ext = lambda l: [(l[i], l[i + 1]) for i in range(0, len(l), 2)]
@@ -223,8 +225,8 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
             le, path = query[name]["leaf_elements"], query[name]["proof"]
             if len(le) != widths[name] or len(path) != depth:
                 return fail("bad opening shape for %s" % name)
-            if not O.merkle_verify(np.array(path, dtype=np.uint64).reshape(-1, 4), np.array(cap, dtype=np.uint64),
-                                   O.hash_leaf(le), idx):
+            if not H.merkle_verify(np.array(path, dtype=np.uint64).reshape(-1, 4), np.array(cap, dtype=np.uint64),
+                                   H.hash_leaf(le), idx):
                 return fail("Merkle path of %s does not verify" % name)
         W, S2, Q_, SU = (query[k]["leaf_elements"] for k in ("witness_query", "stage_2_query", "quotient_query", "setup_query"))
         # source order of verifier.rs:2233-2290 == opening order: vars, constants, sigmas, z, partials, mult, A, B, tables, quotient
@@ -265,7 +267,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
             path = np.array(fq["proof"], dtype=np.uint64).reshape(-1, 4)
             if path.shape[0] != ((ln >> k) // cap_size).bit_length() - 1:
                 return fail("bad FRI path length")
-            if not O.merkle_verify(path, np.array(caps[layer], dtype=np.uint64), O.hash_leaf(le), tree_idx):
+            if not H.merkle_verify(path, np.array(caps[layer], dtype=np.uint64), H.hash_leaf(le), tree_idx):
                 return fail("FRI layer %d: Merkle path does not verify" % layer)
             chal, start = fri_ch[layer], tree_idx * m
             for _ in range(k):

@@ -52,3 +52,28 @@ def test_fri_schedule_matches_oracle_and_reference_shapes():
                  (80, 4, 7, 2, 10), (100, 64, 0, 1, 8), (63, 1, 0, 4, 13), (100, 16, 0, 3, 4), (100, 2, 0, 1, 1)]:
         assert E.fri_schedule(*args) == O.fri_schedule(*args), args
     assert E.fri_schedule(100, 32, 0, 1, 20) == (0, 100, [3, 3, 3, 3, 3, 1], 16)   # the golden proof's shape
+
+
+def test_product_blake2s_transcript_matches_hashlib_oracle():
+    """Blake2sTranscript (transcript.rs:155-262) of the product's host code against oracle/blake.py (hashlib.blake2s):
+    byte absorption of field elements and raw caps, reseeding, 8-byte challenges, 64-bit query words."""
+    from oracle import blake as B
+    rng = np.random.default_rng(3)
+    tp, to = E.Transcript(kind=3), B.Transcript()
+    seq = [("c", 3), ("a", 5), ("c", 9), ("cap", 8), ("c", 2), ("a", 64), ("c", 5), ("a", 1), ("c", 1), ("cap", 1), ("c", 4)]
+    for kind, n in seq:
+        if kind == "a":
+            els = rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)
+            els[0] = np.uint64(2**64 - 1)                      # non-canonical input: reduced before it is serialised
+            tp.absorb(els); to.absorb(els)
+        elif kind == "cap":
+            cap = rng.integers(0, 2**64 - 1, size=(n, 4), dtype=np.uint64)
+            cap[0, 0] = np.uint64(2**64 - 1)                   # digest bytes are NOT reduced
+            tp.absorb_cap(cap); to.absorb_cap(cap)
+        else:
+            assert [tp.challenge() for _ in range(n)] == [to.challenge() for _ in range(n)]
+    qi = B.QueryIndexer(10, 3)
+    assert [tp.query_index(10, 3) for _ in range(12)] == [qi.next(to) for _ in range(12)]
+    # RFC 7693 appendix B known answer, through the same hashlib the oracle uses
+    import hashlib
+    assert hashlib.blake2s(b"abc").hexdigest() == "508c5e8c327c14e2e1a72ba34eeb452f37458b209ed63a294d999b4c86675982"

@@ -17,13 +17,14 @@ def main():
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
     ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--transcript", default="poseidon2", choices=["poseidon2", "poseidon", "blake2s"])
     a = ap.parse_args()
     t0 = time.time()
     c = S.sha_shaped_circuit(a.log_n, seed=42, table_bits=4 if a.log_n >= 14 else 2)
     t_gen = time.time() - t0
     ctx = E.Context(0)
     t0 = time.time()
-    setup = E.ProverSetup(ctx, c, a.fri_lde, a.cap, a.security)
+    setup = E.ProverSetup(ctx, c, a.fri_lde, a.cap, a.security, transcript=a.transcript)
     ctx.sync()
     t_setup = time.time() - t0
     d_vars = ctx.upload(c.variables)
@@ -45,7 +46,7 @@ def main():
         from oracle import verifier as OV
         pg = proof_format.parse(buf, security_level=a.security)
         t0 = time.time()
-        out["verifier_accepts"] = bool(OV.verify(OV.VerificationKey(c, setup.cap(), a.fri_lde, a.cap), pg, verbose=True))
+        out["verifier_accepts"] = bool(OV.verify(OV.VerificationKey(c, setup.cap(), a.fri_lde, a.cap), pg, verbose=True, transcript_kind=setup.transcript_kind))
         out["verify_s"] = round(time.time() - t0, 2)
     print(json.dumps(out))
 
