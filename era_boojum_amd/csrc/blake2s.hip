@@ -156,7 +156,41 @@ __global__ void __launch_bounds__(256) blake2s_nodes_kernel(const u64 *prev, u64
     st.store(next + 4 * i);
 }
 
+// Proof of work (impl PoWRunner for Blake2s256, src/cs/implementations/pow.rs:50-133): the smallest nonce such that the
+// first 8 digest bytes of Blake2s(seed || le64(nonce)), read as a little-endian u64, have >= pow_bits trailing zeros.
+// seed = 5 field elements = 40 bytes, so seed || nonce is one 48-byte block.  lane = nonce; the minimum over the launch.
+struct PowSeed {
+    u32 w[10];
+};
+__global__ void __launch_bounds__(256) blake2s_pow_kernel(PowSeed seed, unsigned pow_bits, u64 base, u64 count, unsigned long long *result) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64 nonce = base + i;
+    u32 m[16];
+#pragma unroll
+    for (int k = 0; k < 10; k++) m[k] = seed.w[k];
+    m[10] = gl::lo32(nonce);
+    m[11] = gl::hi32(nonce);
+    m[12] = m[13] = m[14] = m[15] = 0;
+    B2s st;
+    st.init();
+    st.compress(m, 48, true);
+    const u64 first = gl::pack(st.h[0], st.h[1]);
+    const unsigned tz = first ? (unsigned)__builtin_ctzll(first) : 64u;
+    if (tz >= pow_bits) atomicMin(result, (unsigned long long)nonce);
+}
+
 }  // namespace
+
+void launch_blake2s_pow(const u64 *seed5, unsigned pow_bits, u64 base, u64 count, u64 *d_result, hipStream_t s) {
+    PowSeed ps;
+    for (int k = 0; k < 5; k++) {
+        ps.w[2 * k] = gl::lo32(seed5[k]);
+        ps.w[2 * k + 1] = gl::hi32(seed5[k]);
+    }
+    hipLaunchKernelGGL(blake2s_pow_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, ps, pow_bits, base, count,
+                       (unsigned long long *)d_result);
+}
 
 void launch_blake2s_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
                            size_t num_leaves, u64 *d_digests, hipStream_t s) {

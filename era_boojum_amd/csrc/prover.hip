@@ -210,7 +210,8 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: the Blake2s tree hasher goes with the Blake2s transcript and the "
                                                      "Poseidon2 tree hasher with an algebraic transcript");
     }
-    if (cfg->pow_bits != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: PoW is not supported (benches run with pow_bits = 0)");
+    if (cfg->pow_bits > 32 || cfg->pow_bits >= cfg->security_level)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: pow_bits must be <= 32 and below the security level (pow.rs:53, prover.rs:2293)");
     if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || c->table_id_col >= c->num_constant_cols))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad lookup parameters");
     if (c->num_vars < c->num_gp_vars + c->lookup_width * c->lookup_reps || !c->non_residues)
@@ -712,6 +713,26 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         ~FriGuard() { bj_fri_destroy(f); }
     } fri_guard{fri_obj};
     tr = trw.t;
+    // ---------------- proof of work (prover.rs:2107-2131; Blake2s256 as PoWRunner, pow.rs:50-133) ----------------
+    u64 pow_challenge = 0;
+    if (new_pow) {
+        u64 seed[5];   // 256 / CHAR_BITS = 4, "+1 if not a multiple of CHAR_BITS" -> 5 challenges = 40 seed bytes
+        for (int i = 0; i < 5; i++) seed[i] = gl::canon(tr.challenge());
+        ArenaBuf d_res;
+        if ((rc = d_res.alloc(ctx, 8))) return rc;
+        const u64 none = ~(u64)0, batch = (u64)1 << 24;
+        u64 found = none;
+        for (u64 base = 0; found == none; base += batch) {   // batches in order + minimum inside a batch = the smallest nonce,
+            if ((rc = bj_memcpy_h2d(ctx, d_res.p, &none, 8))) return rc;   // i.e. what the reference's serial search returns
+            bj::launch_blake2s_pow(seed, new_pow, base, batch, d_res.p, st);
+            BJ_CHECK_LAUNCH(ctx);
+            if ((rc = bj_memcpy_d2h(ctx, &found, d_res.p, 8))) return rc;
+            if (base > ((u64)1 << 40)) return bj::fail(ctx, BJ_ERR_HIP, "bj_prove: proof of work did not terminate");
+        }
+        pow_challenge = found;
+        const u64 lh[2] = {found & 0xFFFFFFFFULL, found >> 32};
+        tr.absorb(lh, 2);
+    }
     proof->stage_ms[5] = timer.lap();
 
     // ---------------- round 6: queries (prover.rs:2161-2266) ----------------
@@ -808,8 +829,8 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     // ---------------- serialise ----------------
     std::vector<u64> &D = proof->data;
     auto put = [&](const u64 *p, size_t k) { D.insert(D.end(), p, p + k); };
-    const u64 header[] = {0x424A5046ULL, 1, S->pub_cols.size(), cap, vz.size() / 2, vzo.size() / 2, v0.size() / 2, sched_len,
-                          final_degree, num_queries, nW, nS2, 2 * q, S->n_cols, depth, log_n, fri};
+    const u64 header[] = {0x424A5046ULL, 2, S->pub_cols.size(), cap, vz.size() / 2, vzo.size() / 2, v0.size() / 2, sched_len,
+                          final_degree, num_queries, nW, nS2, 2 * q, S->n_cols, depth, log_n, fri, S->pow_bits, pow_challenge};
     put(header, sizeof(header) / 8);
     for (size_t i = 0; i < sched_len; i++) D.push_back(sched[i]);
     for (size_t i = 0; i < S->pub_cols.size(); i++) D.push_back(gl::canon(h_public_values[i]));

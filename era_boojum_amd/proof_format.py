@@ -2,9 +2,9 @@
 names of the reference's `Proof` (src/cs/implementations/proof.rs:121-136).
 
 Layout (all u64, little endian):
-  header[17] = magic 'BJPF', version, n_public, cap_size, n_values_at_z, n_values_at_z_omega, n_values_at_0, n_fri_oracles,
+  header[19] = magic 'BJPF', version (2), n_public, cap_size, n_values_at_z, n_values_at_z_omega, n_values_at_0, n_fri_oracles,
                final_degree, n_queries, witness leaf width, stage-2 leaf width, quotient leaf width, setup leaf width,
-               base-oracle path depth, log_n, fri_lde_factor
+               base-oracle path depth, log_n, fri_lde_factor, pow_bits, pow_challenge      (version 1: the first 17 only)
   schedule[n_fri_oracles] | public inputs | witness cap | stage-2 cap | quotient cap (cap_size*4 each)
   values_at_z (2 each) | values_at_z_omega | values_at_0 | FRI caps (n_fri_oracles * cap_size*4)
   final monomials c0[final_degree], c1[final_degree]
@@ -29,9 +29,12 @@ def parse(buf, security_level=None, pow_bits=0):
         return out
 
     h = [int(x) for x in take(17)]
-    if h[0] != MAGIC or h[1] != 1:
-        raise ValueError("not a BJPF v1 proof")
-    (_, _, n_pub, cap, nz, nzo, n0, n_fri, final_degree, n_queries, w_wit, w_s2, w_q, w_su, depth, log_n, fri_lde) = h
+    if h[0] != MAGIC or h[1] not in (1, 2):
+        raise ValueError("not a BJPF v1/v2 proof")
+    (_, version, n_pub, cap, nz, nzo, n0, n_fri, final_degree, n_queries, w_wit, w_s2, w_q, w_su, depth, log_n, fri_lde) = h
+    pow_challenge = 0
+    if version == 2:
+        pow_bits, pow_challenge = (int(x) for x in take(2))
     sched = [int(x) for x in take(n_fri)]
     caps4 = lambda: take(cap * 4).reshape(cap, 4).tolist()
     pairs = lambda k: take(2 * k).reshape(k, 2).tolist()
@@ -65,7 +68,7 @@ def parse(buf, security_level=None, pow_bits=0):
     if pos != a.size:
         raise ValueError("trailing data in proof buffer")
     proof["queries_per_fri_repetition"] = queries
-    proof["pow_challenge"] = 0
+    proof["pow_challenge"] = pow_challenge
     proof["_query_indices"] = indices
     proof["_schedule"] = sched
     return proof

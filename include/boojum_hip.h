@@ -320,7 +320,7 @@ typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */
     unsigned fri_lde_factor;
     unsigned cap_size;
     unsigned security_level;
-    unsigned pow_bits; /* must be 0 */
+    unsigned pow_bits; /* Blake2s proof of work (PoWRunner for Blake2s256, pow.rs:50-133), <= 32; 0 = off as in the benches */
     unsigned transcript;  /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON, BJ_TRANSCRIPT_BLAKE2S */
     unsigned tree_hasher; /* 0 or BJ_HASHER_POSEIDON2 (default, with an algebraic transcript), BJ_HASHER_BLAKE2S (with
                            * BJ_TRANSCRIPT_BLAKE2S): the transcript's CompatibleCap must be the hasher's Output */

@@ -82,6 +82,26 @@ def quotient(vars_q, consts_q, sigmas_q, z_q, partials_q, A_q, B_q, mult_q, tabl
     return out
 
 
+def pow_seed(t):
+    """256 / CHAR_BITS = 4 challenges, +1 because 4 is not a multiple of CHAR_BITS (prover.rs:2114-2119): 40 seed bytes."""
+    return b"".join(int(t.challenge()).to_bytes(8, "little") for _ in range(5))
+
+
+def pow_ok(seed, pow_bits, nonce):
+    import hashlib
+    first = int.from_bytes(hashlib.blake2s(seed + int(nonce).to_bytes(8, "little")).digest()[:8], "little")
+    tz = 64 if first == 0 else (first & -first).bit_length() - 1
+    return tz >= pow_bits
+
+
+def pow_search(seed, pow_bits):
+    """The serial search of pow.rs:60-73: the smallest valid nonce."""
+    nonce = 0
+    while not pow_ok(seed, pow_bits, nonce):
+        nonce += 1
+    return nonce
+
+
 def hashing_layer(hasher):
     """The module providing merkle_* / Transcript / QueryIndexer / do_fri for a tree hasher."""
     if hasher == 2:
@@ -114,7 +134,6 @@ class Setup:
 
 def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, threads=1, return_aux=False,
           transcript_kind=1):
-    assert pow_bits == 0, "PoW is off in the benches (sha256/mod.rs:313); not restated"
     c = circuit
     n, log_n = c.n, c.log_n
     V = c.num_vars
@@ -271,6 +290,11 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     # ---- round 5b: FRI (prover.rs:2075-2105)
     new_pow, num_queries, sched, final_degree = O.fri_schedule(security_level, cap_size, pow_bits, log_fri, log_n)
     fri = H.do_fri(d0, d1, log_fri, sched, cap_size, t, threads)
+    # ---- proof of work (prover.rs:2107-2131; PoWRunner = Blake2s256, pow.rs:50-133; hashlib is the hash)
+    pow_challenge = 0
+    if new_pow:
+        pow_challenge = pow_search(pow_seed(t), new_pow)
+        t.absorb([pow_challenge & 0xFFFFFFFF, pow_challenge >> 32])
     # ---- round 6: queries (prover.rs:2161-2266)
     qi = H.QueryIndexer(log_n, log_fri)
     queries = []
@@ -307,7 +331,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
         "values_at_0": [list(v) for v in values_at_0],
         "fri_base_oracle_cap": fri["caps"][0].tolist(),
         "fri_intermediate_oracles_caps": [cap.tolist() for cap in fri["caps"][1:]],
-        "queries_per_fri_repetition": queries, "pow_challenge": 0,
+        "queries_per_fri_repetition": queries, "pow_challenge": pow_challenge,
     }
     if return_aux:
         aux = dict(beta=beta, gamma=gamma, lbeta=lbeta, lgamma=lgamma, alpha=alpha, z=z, deep_challenge=cch,

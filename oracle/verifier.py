@@ -191,6 +191,12 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
         return fail("unexpected final monomials length")
     t.absorb(fm[0])
     t.absorb(fm[1])
+    if new_pow:          # verifier.rs:1957-1983: the nonce must solve the puzzle seeded by the transcript, then it is absorbed
+        from oracle.prover import pow_seed, pow_ok
+        nonce = int(proof["pow_challenge"])
+        if not pow_ok(pow_seed(t), new_pow, nonce):
+            return fail("invalid proof of work")
+        t.absorb([nonce & 0xFFFFFFFF, nonce >> 32])
     if len(proof["queries_per_fri_repetition"]) != num_queries:
         return fail("unexpected number of queries")
     om = O.omega(log_n)

@@ -133,3 +133,27 @@ def test_poseidon_v1_transcript_proof_equals_oracle_proof():
     assert OV.verify(vk, pg, verbose=True, transcript_kind=2)
     assert not OV.verify(vk, pg, transcript_kind=1)
     gsetup.close()
+
+
+@pytest.mark.parametrize("pow_bits,transcript,kind", [(10, "poseidon2", 1), (17, "poseidon", 2), (12, "blake2s", 3)])
+def test_proof_of_work(pow_bits, transcript, kind):
+    """Blake2s PoW (pow.rs:50-133) after the FRI commit phase: fewer queries (compute_fri_schedule), the smallest valid nonce
+    (what the reference's serial search returns), nonce absorbed as (low, high); proof identical to the oracle prover's
+    (whose PoW runs on hashlib) and accepted by the verifier restatement; a wrong nonce is rejected."""
+    c = S.sha_shaped_circuit(9, seed=60 + pow_bits, table_bits=2)
+    osetup = OP.Setup(c, 8, 16, threads=4, hasher=2 if kind == 3 else 1)
+    po = OP.prove(c, osetup, 8, 16, security_level=40, pow_bits=pow_bits, threads=4, transcript_kind=kind)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 40, pow_bits=pow_bits, transcript=transcript)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=40)
+    assert pg["proof_config"]["pow_bits"] == pow_bits
+    assert pg["pow_challenge"] == po["pow_challenge"] and pg["pow_challenge"] != 0
+    _compare(pg, po)
+    p0 = OP.prove(c, osetup, 8, 16, security_level=40, pow_bits=0, threads=4, transcript_kind=kind)
+    assert len(pg["queries_per_fri_repetition"]) < len(p0["queries_per_fri_repetition"])
+    vk = OV.VerificationKey(c, gsetup.cap(), 8, 16)
+    assert OV.verify(vk, pg, verbose=True, transcript_kind=kind)
+    bad = dict(pg)
+    bad["pow_challenge"] = pg["pow_challenge"] + 1
+    assert not OV.verify(vk, bad, transcript_kind=kind)
+    gsetup.close()
