@@ -203,6 +203,48 @@ void launch_barycentric_eval(const u64 *const *d_col_ptrs, unsigned n_cols, size
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// out[i] = sum_k (coef0_k + coef1_k u) * col_k[i]  over n entries — the DEEP numerator of a large opening set taken on the
+// MONOMIAL forms: sum_k c_k f_k is a polynomial of degree < n, so it is combined once over n coefficients (1/lde_factor of
+// the LDE-domain traffic) and extended to the FRI domain by one two-column LDE; exact arithmetic, identical values.
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int LC_PTS = 4;
+__global__ void __launch_bounds__(256)
+linear_combination_kernel(const u64 *const *cols, const u64 *coefs /*[n_cols][2]*/, unsigned n_cols, size_t n, u64 *out0,
+                          u64 *out1) {
+    const size_t base = (size_t)blockIdx.x * (256 * LC_PTS) + threadIdx.x;
+    Acc160 s0[LC_PTS], s1[LC_PTS];
+#pragma unroll
+    for (int k = 0; k < LC_PTS; k++) {
+        s0[k].clear();
+        s1[k].clear();
+    }
+    for (unsigned c = 0; c < n_cols; c++) {
+        const u64 *f = cols[c];
+        const u64 a = coefs[2 * c], b = coefs[2 * c + 1];
+#pragma unroll
+        for (int k = 0; k < LC_PTS; k++) {
+            const size_t i = base + (size_t)k * 256;
+            const u64 v = i < n ? f[i] : 0;
+            s0[k].fma(v, a);
+            s1[k].fma(v, b);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LC_PTS; k++) {
+        const size_t i = base + (size_t)k * 256;
+        if (i < n) {
+            out0[i] = s0[k].reduce();
+            out1[i] = s1[k].reduce();
+        }
+    }
+}
+void launch_linear_combination(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t n, u64 *d_out0,
+                               u64 *d_out1, hipStream_t s) {
+    hipLaunchKernelGGL(linear_combination_kernel, dim3((unsigned)((n + 256 * LC_PTS - 1) / (256 * LC_PTS))), dim3(256), 0, s,
+                       d_col_ptrs, d_coefs, n_cols, n, d_out0, d_out1);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // DEEP:  dst[I] (+)= ( sum_k (coef0_k + coef1_k u) * f_k[I] - (C0 + C1 u) ) / (x_I - at)
 // x_I = g * w_N^{bitrev(I)} = 7 * T[I>>1] * (-1)^(I&1).  A thread owns DEEP_PTS points so that one field inversion
 // (Montgomery batch trick over the norms of x_I - at) serves all of them.

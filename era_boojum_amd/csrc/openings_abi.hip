@@ -17,6 +17,10 @@ void launch_deep_accumulate(const u64 *const *d_col_ptrs, const u64 *d_coefs, un
 }  // namespace bj
 
 namespace bj {
+void launch_linear_combination(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t n, u64 *d_out0,
+                               u64 *d_out1, hipStream_t s);
+int combine_monomials(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
+                      const uint64_t *h_challenges, size_t n, uint64_t *d_out0, uint64_t *d_out1);
 int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
                           const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
                           unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
@@ -90,6 +94,38 @@ int bj_deep_quotient_accumulate(bj_ctx *ctx, const uint64_t *const *h_src_c0, co
 }  // extern "C"
 
 namespace bj {
+// out = sum_k ch_k * src_k over n entries (sources: base columns, or F_p^2 columns as (c0, c1) pairs) — same flattening
+// of F_p^2 sources into base columns with F_p^2 coefficients as the DEEP call below
+int combine_monomials(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
+                      const uint64_t *h_challenges, size_t n, uint64_t *d_out0, uint64_t *d_out1) {
+    if (int rc = bj::bind(ctx)) return rc;
+    std::vector<const u64 *> ptrs;
+    std::vector<u64> coefs;
+    for (size_t k = 0; k < n_src; k++) {
+        gl::e2 ch{gl::canon(h_challenges[2 * k]), gl::canon(h_challenges[2 * k + 1])};
+        ptrs.push_back(h_src_c0[k]);
+        coefs.push_back(ch.c0);
+        coefs.push_back(ch.c1);
+        if (h_src_c1 && h_src_c1[k]) {
+            ptrs.push_back(h_src_c1[k]);
+            coefs.push_back(gl::mul(gl::GEN, ch.c1));
+            coefs.push_back(ch.c0);
+        }
+    }
+    const unsigned n_cols = (unsigned)ptrs.size();
+    DevArgs args;
+    if (int rc = args.alloc(ctx, n_cols * sizeof(u64 *) + coefs.size() * sizeof(u64))) return rc;
+    const u64 **d_ptrs = (const u64 **)args.d;
+    u64 *d_coefs = (u64 *)(d_ptrs + n_cols);
+    BJ_HIP(ctx, hipMemcpyAsync((void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
+    BJ_HIP(ctx, hipMemcpyAsync(d_coefs, coefs.data(), coefs.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bj::launch_linear_combination(d_ptrs, d_coefs, n_cols, n, d_out0, d_out1, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    if (!args.from_arena) BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return BJ_OK;
+}
+
 // the same over the LOCAL index range [I0, I0 + N_local) of the LDE domain (a contiguous range of cosets owned by one GPU);
 // source and destination pointers address the local range
 int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,

@@ -46,6 +46,8 @@ void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, c
                          u64 *d_out, hipStream_t s);
 void launch_gather_fri_leaves(const u64 *d_c0, const u64 *d_c1, unsigned log_e, const u64 *d_leaf_idx, unsigned n_idx,
                               u64 *d_out, hipStream_t s);
+int combine_monomials(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
+                      const uint64_t *h_challenges, size_t n, uint64_t *d_out0, uint64_t *d_out1);
 int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
                           const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
                           unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
@@ -72,6 +74,7 @@ struct bj_setup {
     size_t Nl = 0;                 // Merkle leaves held here (n * fri_lde / world)
     size_t cap_l = 0;              // cap nodes of the local subtree (cap_size / world)
     u64 *d_nat = nullptr;          // [n_cols][n] natural-order values (replicated)
+    u64 *d_mono = nullptr;         // [n_cols][n] monomial forms (replicated; the DEEP numerator is combined on them)
     u64 *d_lde = nullptr;          // [n_cols][cl][n]
     u64 *d_tree = nullptr;         // local subtree
     u64 *d_non_res = nullptr;
@@ -179,6 +182,7 @@ void bj_setup_destroy(bj_setup *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->d_nat) (void)hipFree(s->d_nat);
+    if (s->d_mono) (void)hipFree(s->d_mono);
     if (s->d_lde) (void)hipFree(s->d_lde);
     if (s->d_tree) (void)hipFree(s->d_tree);
     if (s->d_non_res) (void)hipFree(s->d_non_res);
@@ -305,11 +309,11 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     if (!rc && nT) rc = bj_memcpy_h2d(ctx, s->d_nat + (size_t)(s->V + s->nC) * n, h_tables, (size_t)nT * n * 8);
     if (!rc) rc = bj_memcpy_h2d(ctx, s->d_non_res, s->non_residues.data(), s->V * 8);
     if (rc) return bail(rc);
-    {   // monomials in a temporary, LDE into d_lde
-        DevBuf mono;
-        if ((rc = mono.alloc(ctx, (size_t)s->n_cols * n))) return bail(rc);
-        rc = bj_intt_batch(ctx, s->d_nat, mono.p, s->log_n, s->n_cols, n, 1);
-        if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, s->d_lde, s->log_n, s->n_cols, s->log_L, s->c0, s->cl);
+    {   // monomials (kept), LDE into d_lde
+        if (hipMalloc((void **)&s->d_mono, (size_t)s->n_cols * n * 8) != hipSuccess)
+            return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: device allocation failed"));
+        rc = bj_intt_batch(ctx, s->d_nat, s->d_mono, s->log_n, s->n_cols, n, 1);
+        if (!rc) rc = bj_lde_cosets_batch(ctx, s->d_mono, n, s->d_lde, s->log_n, s->n_cols, s->log_L, s->c0, s->cl);
         if (!rc) rc = bj_sync(ctx);
         if (rc) return bail(rc);
     }
@@ -381,10 +385,10 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     } guard{proof};
     {   // one reservation for every buffer below (sizes mirror the allocations; +1 MiB slack per buffer for alignment)
         const size_t tree_elems = bj_merkle_tree_digests(N, capl) * 4, slack = (size_t)1 << 17;
-        size_t need = (size_t)nW * Ln + (size_t)(nW > nS2 ? nW : nS2) * n + tree_elems            // wit_lde, mono, wit_tree
+        size_t need = (size_t)nW * Ln + (size_t)(nW + nS2) * n + tree_elems                        // wit_lde, monomials, wit_tree
                     + (size_t)nS2 * n + ((size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16)   // s2_nat, tmp
                     + (size_t)nS2 * Ln + tree_elems                                                // s2_lde, s2_tree
-                    + 2 * Q + (sh.world > 1 ? 2 * Ln * (sh.world + 1) : 0) + (size_t)2 * q * N + tree_elems + 2 * n + 2 * N                       // T (+ gather staging), q_lde, q_tree, w, deep
+                    + 2 * Q + (sh.world > 1 ? 2 * Ln * (sh.world + 1) : 0) + (size_t)2 * q * N + tree_elems + 4 * n + 4 * N                       // T (+ gather staging), q_lde, q_tree, w, deep
                     + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
                     + 4 * N + (N * sh.world) / 2;                                                  // FRI layers + trees, DEEP argument blocks
         if ((rc = bj::arena_reset(ctx, need))) return rc;
@@ -412,9 +416,10 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = bj::ensure_twiddles(ctx, log_n + (L > fri ? bj::log2_exact(L) : S->log_fri), false))) return rc;
 
     // ---------------- round 1: witness LDE + tree (prover.rs:270-353) ----------------
-    ArenaBuf wit_lde, wit_tree, mono;
+    ArenaBuf wit_lde, wit_tree, mono, mono_s2;   // mono: witness monomials, mono_s2: stage-2 monomials (both kept for DEEP)
     if ((rc = wit_lde.alloc(ctx, (size_t)nW * Ln))) return rc;
-    if ((rc = mono.alloc(ctx, (size_t)(nW > nS2 ? nW : nS2) * n))) return rc;
+    if ((rc = mono.alloc(ctx, (size_t)nW * n))) return rc;
+    if ((rc = mono_s2.alloc(ctx, (size_t)nS2 * n))) return rc;
     rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
     if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
     if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L, S->c0, S->cl);
@@ -452,8 +457,8 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     }
     BJ_CHECK_LAUNCH(ctx);
     if ((rc = s2_lde.alloc(ctx, (size_t)nS2 * Ln))) return rc;
-    rc = bj_intt_batch(ctx, s2_nat.p, mono.p, log_n, nS2, n, 1);
-    if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, s2_lde.p, log_n, nS2, S->log_L, S->c0, S->cl);
+    rc = bj_intt_batch(ctx, s2_nat.p, mono_s2.p, log_n, nS2, n, 1);
+    if (!rc) rc = bj_lde_cosets_batch(ctx, mono_s2.p, n, s2_lde.p, log_n, nS2, S->log_L, S->c0, S->cl);
     if (rc) return rc;
     if ((rc = s2_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
     rc = bj_merkle_tree_build(ctx, s2_lde.p, Ln, nS2, N, capl, s2_tree.p);
@@ -555,20 +560,29 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = w.alloc(ctx, 2 * n))) return rc;
     // base columns whose coset 0 is evaluated, in the order of prover.rs:1550-1683; F_p^2 polys contribute two columns
     struct Src { const u64 *c0, *c1; };
-    std::vector<Src> srcs;
-    for (unsigned i = 0; i < V; i++) srcs.push_back({wit_lde.p + (size_t)i * Ln, nullptr});
-    for (unsigned i = 0; i < nC; i++) srcs.push_back({d_con_lde + (size_t)i * Ln, nullptr});
-    for (unsigned i = 0; i < V; i++) srcs.push_back({d_sig_lde + (size_t)i * Ln, nullptr});
-    for (unsigned j = 0; j < 1 + n_part; j++) srcs.push_back({s2_lde.p + (size_t)(2 * j) * Ln, s2_lde.p + (size_t)(2 * j + 1) * Ln});
+    std::vector<Src> srcs, msrcs;   // msrcs: the monomial forms of the same polynomials, same order (for the DEEP numerator)
+    const u64 *m_sig = S->d_mono, *m_con = S->d_mono + (size_t)V * n, *m_tab = S->d_mono + (size_t)(V + nC) * n;
+    for (unsigned i = 0; i < V; i++) srcs.push_back({wit_lde.p + (size_t)i * Ln, nullptr}), msrcs.push_back({mono.p + (size_t)i * n, nullptr});
+    for (unsigned i = 0; i < nC; i++) srcs.push_back({d_con_lde + (size_t)i * Ln, nullptr}), msrcs.push_back({m_con + (size_t)i * n, nullptr});
+    for (unsigned i = 0; i < V; i++) srcs.push_back({d_sig_lde + (size_t)i * Ln, nullptr}), msrcs.push_back({m_sig + (size_t)i * n, nullptr});
+    for (unsigned j = 0; j < 1 + n_part; j++) {
+        srcs.push_back({s2_lde.p + (size_t)(2 * j) * Ln, s2_lde.p + (size_t)(2 * j + 1) * Ln});
+        msrcs.push_back({mono_s2.p + (size_t)(2 * j) * n, mono_s2.p + (size_t)(2 * j + 1) * n});
+    }
     if (has_lookup) {
         srcs.push_back({wit_lde.p + (size_t)V * Ln, nullptr});
+        msrcs.push_back({mono.p + (size_t)V * n, nullptr});
         for (unsigned i = 0; i < S->lookup_reps + 1; i++) {
             size_t o = (size_t)(2 + 2 * n_part + 2 * i);
             srcs.push_back({s2_lde.p + o * Ln, s2_lde.p + (o + 1) * Ln});
+            msrcs.push_back({mono_s2.p + o * n, mono_s2.p + (o + 1) * n});
         }
-        for (unsigned i = 0; i < nT; i++) srcs.push_back({d_tab_lde + (size_t)i * Ln, nullptr});
+        for (unsigned i = 0; i < nT; i++) srcs.push_back({d_tab_lde + (size_t)i * Ln, nullptr}), msrcs.push_back({m_tab + (size_t)i * n, nullptr});
     }
-    for (unsigned j = 0; j < q; j++) srcs.push_back({q_lde.p + (size_t)(2 * j) * N, q_lde.p + (size_t)(2 * j + 1) * N});
+    for (unsigned j = 0; j < q; j++) {   // chunk j of the quotient: coefficients [j*n, (j+1)*n) of T's monomial form
+        srcs.push_back({q_lde.p + (size_t)(2 * j) * N, q_lde.p + (size_t)(2 * j + 1) * N});
+        msrcs.push_back({T.p + (size_t)j * n, T.p + Q + (size_t)j * n});
+    }
     // every rank evaluates from ITS first coset (shift 7*w^bitrev(c0)): the polynomials have degree < n, so the value
     // is the same field element whichever coset it is interpolated from — no exchange, identical transcripts
     const u64 open_shift = gl::mul(gl::GEN, gl::pow(gl::omega(log_n + S->log_L), gl::bitrev32(S->c0, S->log_L)));
@@ -668,33 +682,69 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     ArenaBuf deep;
     if ((rc = deep.alloc(ctx, 2 * N))) return rc;
     size_t choff = 0;
-    auto deep_call = [&](const std::vector<Src> &ss, const u64 *vals, const u64 *at, int accumulate) -> int {
+    // Every opening set goes the same way: the numerator sum_k ch_k f_k is a polynomial of degree < n, so it is combined on
+    // the MONOMIAL forms (n coefficients per column instead of the fri_lde_factor * n values of the FRI domain), extended by
+    // one two-column LDE and divided by (x - at) pointwise.  Exact arithmetic: the same values as combining on the LDE.
+    ArenaBuf num_mono, num_lde;
+    if ((rc = num_mono.alloc(ctx, 2 * n))) return rc;
+    if ((rc = num_lde.alloc(ctx, 2 * N))) return rc;
+    auto deep_set = [&](const std::vector<Src> &ls, const std::vector<Src> &ms, const u64 *vals, const u64 *at, int accumulate) -> int {
+        const u64 *ch = chs.data() + 2 * choff;
         std::vector<const u64 *> p0, p1;
-        for (auto &s : ss) {
-            p0.push_back(s.c0);
-            p1.push_back(s.c1);
+        size_t n_base = 0;
+        for (auto &m : ms) n_base += m.c1 ? 2 : 1;
+        if (n_base < 16) {   // a handful of columns: streaming them over the FRI domain is cheaper than an extra LDE pass
+            for (auto &l : ls) {
+                p0.push_back(l.c0);
+                p1.push_back(l.c1);
+            }
+            int r = bj::deep_accumulate_range(ctx, p0.data(), p1.data(), ls.size(), vals, ch, at, log_n, S->log_fri, N,
+                                              sh.world > 1 ? I0 : 0, deep.p, deep.p + N, accumulate);
+            choff += ls.size();
+            return r;
         }
-        int r = bj::deep_accumulate_range(ctx, p0.data(), p1.data(), ss.size(), vals, chs.data() + 2 * choff, at, log_n,
-                                          S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p, deep.p + N, accumulate);
-        choff += ss.size();
+        for (auto &m : ms) {
+            p0.push_back(m.c0);
+            p1.push_back(m.c1);
+        }
+        int r = bj::combine_monomials(ctx, p0.data(), p1.data(), ms.size(), ch, n, num_mono.p, num_mono.p + n);
+        if (r) return r;
+        if (sh.world > 1)
+            r = bj_lde_cosets_batch(ctx, num_mono.p, n, num_lde.p, log_n, 2, S->log_L, S->c0, S->cl);
+        else
+            r = bj::lde_cosets_strided(ctx, num_mono.p, n, num_lde.p, N, log_n, 2, S->log_fri, 0, fri);
+        if (r) return r;
+        gl::e2 C{0, 0};   // sum_k ch_k * v_k
+        for (size_t k = 0; k < ms.size(); k++) C = gl::e2_add(C, gl::e2_mul(e2c(ch + 2 * k), e2c(vals + 2 * k)));
+        const u64 one_ch[2] = {1, 0}, cv[2] = {C.c0, C.c1};
+        const u64 *g0 = num_lde.p, *g1 = num_lde.p + N;
+        r = bj::deep_accumulate_range(ctx, &g0, &g1, 1, cv, one_ch, at, log_n, S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p,
+                                      deep.p + N, accumulate);
+        choff += ms.size();
         return r;
     };
-    if ((rc = deep_call(srcs, vz.data(), z, 0))) return rc;
-    if ((rc = deep_call(zsrc, vzo.data(), zo, 1))) return rc;
+    if ((rc = deep_set(srcs, msrcs, vz.data(), z, 0))) return rc;
+    {
+        std::vector<Src> mz{msrcs[V + nC + V]};                      // z(x) at z*omega
+        if ((rc = deep_set(zsrc, mz, vzo.data(), zo, 1))) return rc;
+    }
     if (has_lookup) {
+        std::vector<Src> ml;
+        for (unsigned i = 0; i < S->lookup_reps + 1; i++) ml.push_back(msrcs[V + nC + V + 1 + n_part + 1 + i]);
         u64 zero2[2] = {0, 0};
-        if ((rc = deep_call(lsrc, v0.data(), zero2, 1))) return rc;
+        if ((rc = deep_set(lsrc, ml, v0.data(), zero2, 1))) return rc;
     }
     for (auto &p : pubs) {
-        std::vector<Src> ps;
+        std::vector<Src> ps, pl;
         std::vector<u64> pv;
         for (size_t i = 0; i < p.cols.size(); i++) {
-            ps.push_back({wit_lde.p + (size_t)p.cols[i] * Ln, nullptr});
+            pl.push_back({wit_lde.p + (size_t)p.cols[i] * Ln, nullptr});
+            ps.push_back({mono.p + (size_t)p.cols[i] * n, nullptr});
             pv.push_back(p.vals[i]);
             pv.push_back(0);
         }
         u64 at2[2] = {p.at, 0};
-        if ((rc = deep_call(ps, pv.data(), at2, 1))) return rc;
+        if ((rc = deep_set(pl, ps, pv.data(), at2, 1))) return rc;
     }
     proof->stage_ms[4] = timer.lap();
 
