@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--mode", choices=["auto", "sharded", "replicas"], default="auto")
-    ap.add_argument("--transcript", choices=["poseidon", "poseidon2", "blake2s"], default="poseidon",
+    ap.add_argument("--transcript", choices=["poseidon", "poseidon2", "blake2s", "keccak256"], default="poseidon",
                     help="poseidon = the bench script's GoldilocksPoisedonTranscript (v1 permutation, no KAT in the reference); "
                          "poseidon2 = the golden proof's transcript (pinned)")
     ap.add_argument("--fri-lde", type=int, default=8)
@@ -159,7 +159,8 @@ def main():
                                "columns, 8x4 lookups, LDE %d, cap %d, security %d, %s, PoW off)"
                                % ({22: "cfg4", 20: "cfg3"}.get(log_n, "custom"), log_n, args.fri_lde, args.cap, args.security,
                                   {"poseidon": "Poseidon2 tree hasher + Poseidon (v1) transcript", "poseidon2": "Poseidon2 tree hasher + Poseidon2 transcript",
-                                   "blake2s": "Blake2s tree hasher + Blake2s transcript (the non-recursive configuration)"}[args.transcript]),
+                                   "blake2s": "Blake2s tree hasher + Blake2s transcript (the non-recursive configuration)",
+                                   "keccak256": "Keccak256 tree hasher + Keccak256 transcript"}[args.transcript]),
                    "log_n": log_n, "rows": n, "circuit": "SHA-shaped satisfiable synthetic (seed 42)",
                    "sharding": ("one proof sharded by LDE cosets over %d GPUs (%d cosets = %d Merkle leaves each), all-gather of "
                                 "caps / quotient / first FRI layer / query openings, %d collectives and %.1f MB received per "
@@ -168,7 +169,7 @@ def main():
                    "proof_bytes": int(proof_buf.size * 8)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "bj::%s_leaves_kernel (witness tree: %d leaves x %d elements per launch)" % ("blake2s" if args.transcript == "blake2s" else "poseidon2", leaves, W),
+                     "kernel": "bj::%s_leaves_kernel (witness tree: %d leaves x %d elements per launch)" % ({"blake2s": "blake2s", "keccak256": "keccak"}.get(args.transcript, "poseidon2"), leaves, W),
                      "kernel_ms": round(leaf_s * 1e3, 3), "algorithmic_bytes_per_launch": leaf_bytes,
                      "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},
         "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},

@@ -532,8 +532,8 @@ class ProverSetup:
         cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, 0, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
                       c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
                       cols, rows)
-        self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3}[transcript]
-        self.hasher_kind = 2 if transcript == "blake2s" else 1      # Transcript::CompatibleCap = TreeHasher::Output
+        self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3, "keccak256": 4}[transcript]
+        self.hasher_kind = {"blake2s": 2, "keccak256": 3}.get(transcript, 1)      # Transcript::CompatibleCap = TreeHasher::Output
         cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind, self.hasher_kind)
         sig = np.ascontiguousarray(c.sigmas, dtype=np.uint64)
         con = np.ascontiguousarray(c.constants, dtype=np.uint64)

@@ -220,7 +220,7 @@ int bj_memcpy_d2d(bj_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
 
 int bj_ctx_set_tree_hasher(bj_ctx *ctx, int hasher) {
     if (int rc = bind(ctx)) return rc;
-    if (hasher != BJ_HASHER_POSEIDON2 && hasher != BJ_HASHER_BLAKE2S)
+    if (hasher < BJ_HASHER_POSEIDON2 || hasher > BJ_HASHER_KECCAK256)
         return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ctx_set_tree_hasher: unknown hasher %d", hasher);
     ctx->hasher = hasher;
     return BJ_OK;

@@ -219,6 +219,8 @@ void launch_tree_leaves(int hasher, const u64 *d_base, size_t col_stride, const 
                         size_t num_leaves, u64 *d_digests, hipStream_t s) {
     if (hasher == BJ_HASHER_BLAKE2S)
         launch_blake2s_leaves(d_base, col_stride, d_col_ptrs, n_cols, num_leaves, d_digests, s);
+    else if (hasher == BJ_HASHER_KECCAK256)
+        launch_keccak_leaves(d_base, col_stride, d_col_ptrs, n_cols, num_leaves, d_digests, s);
     else
         launch_poseidon2_leaves(d_base, col_stride, d_col_ptrs, n_cols, num_leaves, d_digests, s);
 }
@@ -226,12 +228,16 @@ void launch_tree_leaves_chunked(int hasher, const u64 *d_src0, const u64 *d_src1
                                 size_t num_leaves, u64 *d_digests, hipStream_t s) {
     if (hasher == BJ_HASHER_BLAKE2S)
         launch_blake2s_leaves_chunked(d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests, s);
+    else if (hasher == BJ_HASHER_KECCAK256)
+        launch_keccak_leaves_chunked(d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests, s);
     else
         launch_poseidon2_leaves_chunked(d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests, s);
 }
 void launch_tree_node_layers(int hasher, u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s) {
     if (hasher == BJ_HASHER_BLAKE2S)
         launch_blake2s_node_layers(d_tree, num_leaves, cap_size, s);
+    else if (hasher == BJ_HASHER_KECCAK256)
+        launch_keccak_node_layers(d_tree, num_leaves, cap_size, s);
     else
         launch_poseidon2_node_layers(d_tree, num_leaves, cap_size, s);
 }

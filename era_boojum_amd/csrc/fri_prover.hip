@@ -18,7 +18,7 @@ extern "C" {
 int bj_transcript_create(int kind, bj_transcript **out) {
     if (!out) return BJ_ERR_INVALID_ARG;
     *out = nullptr;
-    if (kind != BJ_TRANSCRIPT_POSEIDON2 && kind != BJ_TRANSCRIPT_POSEIDON && kind != BJ_TRANSCRIPT_BLAKE2S) return BJ_ERR_UNSUPPORTED;
+    if (kind < BJ_TRANSCRIPT_POSEIDON2 || kind > BJ_TRANSCRIPT_KECCAK256) return BJ_ERR_UNSUPPORTED;
     *out = new bj_transcript();
     (*out)->t.kind = kind;
     return BJ_OK;

@@ -158,20 +158,89 @@ struct Blake2s {
     }
 };
 
+// Keccak-256 with the original padding (sha3::Keccak256), same interface.
+struct Keccak256 {
+    uint64_t a[25];
+    unsigned char buf[136];
+    size_t buf_len = 0;
+    Keccak256() { reset(); }
+    void reset() {
+        for (int i = 0; i < 25; i++) a[i] = 0;
+        buf_len = 0;
+    }
+    static uint64_t rotl(uint64_t x, unsigned n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+    void permute() {
+        static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                                        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                                        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                                        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                                        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                                        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+        static const unsigned ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+        for (int r = 0; r < 24; r++) {
+            uint64_t c[5], b[25];
+            for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+            for (int x = 0; x < 5; x++) {
+                const uint64_t d = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
+                for (int y = 0; y < 25; y += 5) a[y + x] ^= d;
+            }
+            for (int x = 0; x < 5; x++)
+                for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl(a[x + 5 * y], ROT[x][y]);
+            for (int y = 0; y < 25; y += 5)
+                for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+            a[0] ^= RC[r];
+        }
+    }
+    void absorb_block() {
+        for (int i = 0; i < 17; i++) {
+            uint64_t w = 0;
+            for (int b = 0; b < 8; b++) w |= (uint64_t)buf[8 * i + b] << (8 * b);
+            a[i] ^= w;
+        }
+        permute();
+        buf_len = 0;
+    }
+    void update(const unsigned char *data, size_t n) {
+        for (size_t i = 0; i < n; i++) {
+            buf[buf_len++] = data[i];
+            if (buf_len == 136) absorb_block();
+        }
+    }
+    void finalize_reset(unsigned char out[32]) {
+        for (size_t i = buf_len; i < 136; i++) buf[i] = 0;
+        buf[buf_len] ^= 0x01;
+        buf[135] ^= 0x80;
+        absorb_block();
+        for (int i = 0; i < 4; i++)
+            for (int b = 0; b < 8; b++) out[8 * i + b] = (unsigned char)(a[i] >> (8 * b));
+        reset();
+    }
+};
+
 struct Transcript {
-    int kind = 1;                 // BJ_TRANSCRIPT_POSEIDON2 = 1, BJ_TRANSCRIPT_POSEIDON = 2, BJ_TRANSCRIPT_BLAKE2S = 3
-    // --- byte transcript (Blake2sTranscript, transcript.rs:155-262)
+    int kind = 1;   // BJ_TRANSCRIPT_POSEIDON2 = 1, BJ_TRANSCRIPT_POSEIDON = 2, BJ_TRANSCRIPT_BLAKE2S = 3, BJ_TRANSCRIPT_KECCAK256 = 4
+    bool is_bytes() const { return kind == 3 || kind == 4; }
+    // --- byte transcripts (Blake2sTranscript / Keccak256Transcript, transcript.rs:155-372)
     Blake2s inner;
+    Keccak256 inner_k;
     std::vector<unsigned char> bytes, avail_bytes;
     void reseed() {
         unsigned char out[32];
-        inner.finalize_reset(out);
-        inner.update(out, 32);
+        if (kind == 4) {
+            inner_k.finalize_reset(out);
+            inner_k.update(out, 32);
+        } else {
+            inner.finalize_reset(out);
+            inner.update(out, 32);
+        }
         avail_bytes.assign(out, out + 32);
     }
     void flush_bytes() {
         if (!bytes.empty()) {
-            inner.update(bytes.data(), bytes.size());
+            if (kind == 4)
+                inner_k.update(bytes.data(), bytes.size());
+            else
+                inner.update(bytes.data(), bytes.size());
             bytes.clear();
             reseed();
         }
@@ -185,7 +254,7 @@ struct Transcript {
     // Merkle caps: digests of the tree hasher.  Algebraic transcripts take them as field elements, the byte transcript
     // as their 32 raw bytes each (witness_merkle_tree_cap)
     void absorb_cap(const u64 *digest_words, size_t n_words) {
-        if (kind != 3) {
+        if (!is_bytes()) {
             absorb(digest_words, n_words);
             return;
         }
@@ -202,7 +271,7 @@ struct Transcript {
     size_t avail_pos = 0, avail_len = 0;
 
     void absorb(const u64 *els, size_t n) {
-        if (kind == 3) {   // witness_field_elements: as_u64_reduced().to_le_bytes()
+        if (is_bytes()) {   // witness_field_elements: as_u64_reduced().to_le_bytes()
             for (size_t i = 0; i < n; i++) {
                 const u64 v = gl::canon(els[i]);
                 for (int b = 0; b < 8; b++) bytes.push_back((unsigned char)(v >> (8 * b)));
@@ -212,7 +281,7 @@ struct Transcript {
         for (size_t i = 0; i < n; i++) buffer.push_back(gl::canon(els[i]));
     }
     u64 challenge() {
-        if (kind == 3) {   // get_challenge: 8 bytes, little endian, from_u64_with_reduction
+        if (is_bytes()) {   // get_challenge: 8 bytes, little endian, from_u64_with_reduction
             unsigned char b8[8];
             flush_bytes();
             if (avail_bytes.empty()) reseed();
@@ -250,7 +319,7 @@ struct BoolsBuffer {
         while (bits.size() - pos < need) {
             bits.erase(bits.begin(), bits.begin() + pos);
             pos = 0;
-            if (t.kind == 3) {   // non-algebraic transcripts hand out 8 uniform bytes, all 64 bits are used (transcript.rs:398-411)
+            if (t.is_bytes()) {   // non-algebraic transcripts hand out 8 uniform bytes, all 64 bits are used (transcript.rs:398-411)
                 unsigned char b8[8];
                 t.challenge_bytes(b8, 8);
                 u64 x = 0;

@@ -209,10 +209,11 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: quotient degree / fri_lde_factor / cap must be powers of two");
     {
         const unsigned tk = cfg->transcript ? cfg->transcript : BJ_TRANSCRIPT_POSEIDON2, hk = cfg->tree_hasher ? cfg->tree_hasher : BJ_HASHER_POSEIDON2;
-        if (tk > BJ_TRANSCRIPT_BLAKE2S || hk > BJ_HASHER_BLAKE2S) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: unknown transcript / tree hasher");
-        if ((hk == BJ_HASHER_BLAKE2S) != (tk == BJ_TRANSCRIPT_BLAKE2S))   // Transcript::CompatibleCap = TreeHasher::Output (prover.rs:153-168)
-            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: the Blake2s tree hasher goes with the Blake2s transcript and the "
-                                                     "Poseidon2 tree hasher with an algebraic transcript");
+        if (tk > BJ_TRANSCRIPT_KECCAK256 || hk > BJ_HASHER_KECCAK256) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: unknown transcript / tree hasher");
+        const bool byte_hasher = hk != BJ_HASHER_POSEIDON2, byte_transcript = tk == BJ_TRANSCRIPT_BLAKE2S || tk == BJ_TRANSCRIPT_KECCAK256;
+        if (byte_hasher != byte_transcript)   // Transcript::CompatibleCap = TreeHasher::Output (prover.rs:153-168)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: a byte tree hasher (Blake2s / Keccak256) goes with a byte transcript and "
+                                                     "the Poseidon2 tree hasher with an algebraic transcript");
     }
     if (cfg->pow_bits > 32 || cfg->pow_bits >= cfg->security_level)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: pow_bits must be <= 32 and below the security level (pow.rs:53, prover.rs:2293)");

@@ -198,10 +198,12 @@ typedef struct bj_transcript bj_transcript;
 /* Blake2sTranscript (transcript.rs:155-262): byte transcript over Blake2s-256 (RFC 7693), paired with the Blake2s tree
  * hasher in the non-recursive configuration (gadgets/sha256/mod.rs:265-270).  Caps are absorbed as raw digest bytes. */
 #define BJ_TRANSCRIPT_BLAKE2S 3
+#define BJ_TRANSCRIPT_KECCAK256 4 /* Keccak256Transcript (transcript.rs:264-372): the same byte transcript over Keccak-256 */
 
 /* Tree hashers (TreeHasher impls, src/cs/oracle/mod.rs:114-245).  Digests are 32 bytes = four u64 words either way. */
 #define BJ_HASHER_POSEIDON2 1 /* GoldilocksPoseidon2Sponge<AbsorptionModeOverwrite>: four canonical field elements */
 #define BJ_HASHER_BLAKE2S 2   /* blake2::Blake2s256: the 32 digest bytes, little-endian packed into the four words */
+#define BJ_HASHER_KECCAK256 3 /* sha3::Keccak256 (original 0x01 padding, oracle/mod.rs:247-312): digest bytes as above */
 int bj_transcript_create(int kind, bj_transcript **out);
 void bj_transcript_destroy(bj_transcript *t);
 int bj_transcript_absorb(bj_transcript *t, const uint64_t *els, size_t n);
@@ -321,9 +323,9 @@ typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */
     unsigned cap_size;
     unsigned security_level;
     unsigned pow_bits; /* Blake2s proof of work (PoWRunner for Blake2s256, pow.rs:50-133), <= 32; 0 = off as in the benches */
-    unsigned transcript;  /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON, BJ_TRANSCRIPT_BLAKE2S */
-    unsigned tree_hasher; /* 0 or BJ_HASHER_POSEIDON2 (default, with an algebraic transcript), BJ_HASHER_BLAKE2S (with
-                           * BJ_TRANSCRIPT_BLAKE2S): the transcript's CompatibleCap must be the hasher's Output */
+    unsigned transcript;  /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON, BJ_TRANSCRIPT_BLAKE2S, _KECCAK256 */
+    unsigned tree_hasher; /* 0 or BJ_HASHER_POSEIDON2 (default, with an algebraic transcript), BJ_HASHER_BLAKE2S /
+                           * BJ_HASHER_KECCAK256 (with a byte transcript): the transcript's CompatibleCap must be the hasher's Output */
 } bj_proof_config;
 
 typedef struct bj_setup bj_setup; /* device-resident SetupStorage + setup Merkle tree + VK cap; reusable across proofs */

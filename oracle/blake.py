@@ -21,108 +21,154 @@ def _digest_words(b):
     return np.frombuffer(b, dtype="<u8").copy()
 
 
-def _canon_bytes(els):
-    a = np.asarray(els, dtype=np.uint64).reshape(-1)
-    a = np.where(a >= np.uint64(P), a - np.uint64(P), a)
-    return a.astype("<u8").tobytes()
+def _canon_words(els):
+    a = np.asarray(els, dtype=np.uint64)
+    return np.where(a >= np.uint64(P), a - np.uint64(P), a)
 
 
-def hash_leaf(els):
-    return _digest_words(hashlib.blake2s(_canon_bytes(els)).digest())
+class ByteHashLayer:
+    """merkle_* / Transcript / QueryIndexer / do_fri over a 32-byte hash of byte strings (`impl TreeHasher for
+    Blake2s256 / Keccak256`, oracle/mod.rs:179-312; Blake2sTranscript / Keccak256Transcript, transcript.rs:155-372).
+    hash_bytes(bytes) -> 32 bytes; hash_many(words (B, n) uint64) -> (B, 4) uint64 (optional vectorised form)."""
 
+    def __init__(self, hash_bytes, hash_many=None, kind=3):
+        self.hash_bytes, self.hash_many, self.kind = hash_bytes, hash_many, kind
+        layer = self
 
-def hash_node(l, r):
-    return _digest_words(hashlib.blake2s(np.asarray(l, dtype="<u8").tobytes() + np.asarray(r, dtype="<u8").tobytes()).digest())
+        class Transcript:
+            """A running hasher (modelled by the bytes fed since the last reset), a byte buffer, unused challenge bytes."""
+            kind = layer.kind
 
+            def __init__(self, kind=None):
+                self.pending, self.buffer, self.avail = b"", b"", b""
 
-def _nodes(leaf_hashes, cap_size):
-    layers = [leaf_hashes]
-    while layers[-1].shape[0] > cap_size:
-        prev = layers[-1]
-        layers.append(np.stack([hash_node(prev[2 * i], prev[2 * i + 1]) for i in range(prev.shape[0] // 2)]))
-    return np.concatenate(layers, axis=0)            # all layers back to back, like the C oracle / the GPU tree
+            def absorb(self, els):
+                self.buffer += _canon_words(np.asarray(els, dtype=np.uint64).reshape(-1)).astype("<u8").tobytes()
 
+            def absorb_cap(self, cap):
+                self.buffer += np.asarray(cap, dtype="<u8").tobytes()      # raw digest bytes
 
-def merkle_construct(cols, cap_size, threads=1):
-    """cols: (n_cols, num_leaves) view; leaf I = hash of column values at I."""
-    cols = np.asarray(cols, dtype=np.uint64)
-    rows = np.ascontiguousarray(cols.T)
-    return _nodes(np.stack([hash_leaf(rows[i]) for i in range(rows.shape[0])]), cap_size)
+            def _reseed(self):
+                out = layer.hash_bytes(self.pending)       # finalize_reset, then the new state starts from the output
+                self.pending = out
+                self.avail = out
 
+            def _flush(self):
+                if self.buffer:
+                    self.pending += self.buffer
+                    self.buffer = b""
+                    self._reseed()
 
-def merkle_construct_chunked(srcs, elems_per_leaf, cap_size, threads=1):
-    srcs = [np.asarray(s, dtype=np.uint64) for s in srcs]
-    n_leaves = srcs[0].size // elems_per_leaf
-    E = elems_per_leaf
-    return _nodes(np.stack([hash_leaf(np.concatenate([s[j * E:(j + 1) * E] for s in srcs])) for j in range(n_leaves)]), cap_size)
+            def challenge_bytes(self, n):
+                self._flush()
+                while len(self.avail) < n:
+                    self._reseed()
+                out, self.avail = self.avail[:n], self.avail[n:]
+                return out
 
+            def challenge(self):
+                self._flush()
+                if not self.avail:
+                    self._reseed()
+                b8, self.avail = self.avail[:8], self.avail[8:]
+                return int.from_bytes(b8, "little") % P            # from_u64_with_reduction
 
-def merkle_cap(tree, num_leaves, cap_size):
-    return tree[2 * num_leaves - 2 * cap_size: 2 * num_leaves - cap_size]
+            def challenge_ext(self):
+                return (self.challenge(), self.challenge())
 
+        self.Transcript = Transcript
+        self.QueryIndexer = QueryIndexer
 
-def merkle_proof(tree, num_leaves, cap_size, idx):
-    path, off, ln, i = [], 0, num_leaves, idx
-    leaf_hash = tree[idx]
-    while ln > cap_size:
-        path.append(tree[off + (i ^ 1)])
-        off += ln
-        ln //= 2
-        i //= 2
-    return leaf_hash, (np.stack(path) if path else np.zeros((0, 4), dtype=np.uint64))
+    # ---- tree hasher
+    def hash_leaf(self, els):
+        return _digest_words(self.hash_bytes(_canon_words(np.asarray(els, dtype=np.uint64).reshape(-1)).astype("<u8").tobytes()))
 
+    def hash_node(self, l, r):
+        return _digest_words(self.hash_bytes(np.asarray(l, dtype="<u8").tobytes() + np.asarray(r, dtype="<u8").tobytes()))
 
-def merkle_verify(path, cap, leaf_hash, idx):
-    cur, i = np.asarray(leaf_hash, dtype=np.uint64), idx
-    for sib in np.asarray(path, dtype=np.uint64).reshape(-1, 4):
-        cur = hash_node(cur, sib) if i % 2 == 0 else hash_node(sib, cur)
-        i //= 2
-    return bool(np.array_equal(cur, np.asarray(cap, dtype=np.uint64).reshape(-1, 4)[i]))
+    def _leaves(self, rows):
+        rows = _canon_words(rows)
+        if self.hash_many is not None:
+            return self.hash_many(rows)
+        return np.stack([_digest_words(self.hash_bytes(rows[i].astype("<u8").tobytes())) for i in range(rows.shape[0])])
 
+    def _nodes(self, leaf_hashes, cap_size):
+        layers = [leaf_hashes]
+        while layers[-1].shape[0] > cap_size:
+            prev = layers[-1]
+            pairs = prev.reshape(-1, 8)
+            if self.hash_many is not None:
+                layers.append(self.hash_many(pairs))
+            else:
+                layers.append(np.stack([_digest_words(self.hash_bytes(pairs[i].astype("<u8").tobytes())) for i in range(pairs.shape[0])]))
+        return np.concatenate(layers, axis=0)            # all layers back to back, like the C oracle / the GPU tree
 
-class Transcript:
-    """Blake2sTranscript: a running hasher, a byte buffer and the unused challenge bytes."""
-    kind = 3
+    def merkle_construct(self, cols, cap_size, threads=1):
+        """cols: (n_cols, num_leaves) view; leaf I = hash of column values at I."""
+        return self._nodes(self._leaves(np.ascontiguousarray(np.asarray(cols, dtype=np.uint64).T)), cap_size)
 
-    def __init__(self, kind=3):
-        self.inner = hashlib.blake2s()
-        self.buffer = b""
-        self.avail = b""
+    def merkle_construct_chunked(self, srcs, elems_per_leaf, cap_size, threads=1):
+        srcs = [np.asarray(s, dtype=np.uint64) for s in srcs]
+        E = elems_per_leaf
+        rows = np.concatenate([s.reshape(-1, E) for s in srcs], axis=1)
+        return self._nodes(self._leaves(rows), cap_size)
 
-    def absorb(self, els):
-        self.buffer += _canon_bytes(els)                       # witness_field_elements
+    @staticmethod
+    def merkle_cap(tree, num_leaves, cap_size):
+        return tree[2 * num_leaves - 2 * cap_size: 2 * num_leaves - cap_size]
 
-    def absorb_cap(self, cap):
-        self.buffer += np.asarray(cap, dtype="<u8").tobytes()  # witness_merkle_tree_cap: raw digest bytes
+    @staticmethod
+    def merkle_proof(tree, num_leaves, cap_size, idx):
+        path, off, ln, i = [], 0, num_leaves, idx
+        leaf_hash = tree[idx]
+        while ln > cap_size:
+            path.append(tree[off + (i ^ 1)])
+            off += ln
+            ln //= 2
+            i //= 2
+        return leaf_hash, (np.stack(path) if path else np.zeros((0, 4), dtype=np.uint64))
 
-    def _reseed(self):
-        out = self.inner.digest()                              # finalize_reset ...
-        self.inner = hashlib.blake2s()
-        self.inner.update(out)                                 # ... then the new state starts from the output
-        self.avail = out
+    def merkle_verify(self, path, cap, leaf_hash, idx):
+        cur, i = np.asarray(leaf_hash, dtype=np.uint64), idx
+        for sib in np.asarray(path, dtype=np.uint64).reshape(-1, 4):
+            cur = self.hash_node(cur, sib) if i % 2 == 0 else self.hash_node(sib, cur)
+            i //= 2
+        return bool(np.array_equal(cur, np.asarray(cap, dtype=np.uint64).reshape(-1, 4)[i]))
 
-    def _flush(self):
-        if self.buffer:
-            self.inner.update(self.buffer)
-            self.buffer = b""
-            self._reseed()
-
-    def challenge_bytes(self, n):
-        self._flush()
-        while len(self.avail) < n:
-            self._reseed()
-        out, self.avail = self.avail[:n], self.avail[n:]
+    def do_fri(self, c0, c1, log_lde, schedule, cap_size, transcript, threads=1):
+        """do_fri (fri/mod.rs:49-358) with byte-hash oracles: same dict as oracle.do_fri.  Folding / interpolation reuse the
+        C oracle (hash independent); the trees and the transcript are the ones of this layer."""
+        c0, c1 = np.asarray(c0, dtype=np.uint64), np.asarray(c1, dtype=np.uint64)
+        log_full = int(c0.size).bit_length() - 1
+        roots = O.twiddles(log_full, inverse=True)
+        kappa = O.inv(7)
+        out = {"trees": [], "caps": [], "sources": [], "challenges": []}
+        cur0, cur1 = c0, c1
+        for k in schedule:
+            E = 1 << k
+            leaves = cur0.size // E
+            tree = self.merkle_construct_chunked([cur0, cur1], E, cap_size)
+            cap = self.merkle_cap(tree, leaves, cap_size)
+            out["trees"].append(tree)
+            out["caps"].append(cap)
+            out["sources"].append((cur0, cur1))
+            transcript.absorb_cap(cap)
+            ch = transcript.challenge_ext()
+            out["challenges"].append(ch)
+            alpha = ch
+            for _ in range(k):
+                cur0, cur1 = O.fri_fold(cur0, cur1, roots, kappa, alpha)
+                kappa = kappa * kappa % P
+                alpha = ((alpha[0] * alpha[0] + 7 * alpha[1] * alpha[1]) % P, (2 * alpha[0] * alpha[1]) % P)
+        out["last_folded"] = (cur0, cur1)
+        coset = O.inv(kappa)
+        f0 = O.ifft_natural_to_natural(O.bitreverse(cur0), coset)
+        f1 = O.ifft_natural_to_natural(O.bitreverse(cur1), coset)
+        out["final_monomials"] = (f0, f1)
+        out["final_degree"] = cur0.size >> log_lde
+        transcript.absorb(f0[:out["final_degree"]])
+        transcript.absorb(f1[:out["final_degree"]])
         return out
-
-    def challenge(self):
-        self._flush()
-        if not self.avail:
-            self._reseed()
-        b8, self.avail = self.avail[:8], self.avail[8:]
-        return int.from_bytes(b8, "little") % P                # from_u64_with_reduction
-
-    def challenge_ext(self):
-        return (self.challenge(), self.challenge())
 
 
 class QueryIndexer:
@@ -142,37 +188,9 @@ class QueryIndexer:
         return (coset << self.log_n) + inner
 
 
-def do_fri(c0, c1, log_lde, schedule, cap_size, transcript, threads=1):
-    """do_fri (fri/mod.rs:49-358) with Blake2s oracles: same dict as oracle.do_fri.  Folding / interpolation reuse the C
-    oracle (hash independent); the trees and the transcript are the ones of this module."""
-    c0, c1 = np.asarray(c0, dtype=np.uint64), np.asarray(c1, dtype=np.uint64)
-    log_full = int(c0.size).bit_length() - 1
-    roots = O.twiddles(log_full, inverse=True)
-    kappa = O.inv(7)
-    out = {"trees": [], "caps": [], "sources": [], "challenges": []}
-    cur0, cur1 = c0, c1
-    for k in schedule:
-        E = 1 << k
-        leaves = cur0.size // E
-        tree = merkle_construct_chunked([cur0, cur1], E, cap_size)
-        cap = merkle_cap(tree, leaves, cap_size)
-        out["trees"].append(tree)
-        out["caps"].append(cap)
-        out["sources"].append((cur0, cur1))
-        transcript.absorb_cap(cap)
-        ch = transcript.challenge_ext()
-        out["challenges"].append(ch)
-        alpha = ch
-        for _ in range(k):
-            cur0, cur1 = O.fri_fold(cur0, cur1, roots, kappa, alpha)
-            kappa = kappa * kappa % P
-            alpha = ((alpha[0] * alpha[0] + 7 * alpha[1] * alpha[1]) % P, (2 * alpha[0] * alpha[1]) % P)
-    out["last_folded"] = (cur0, cur1)
-    coset = O.inv(kappa)
-    f0 = O.ifft_natural_to_natural(O.bitreverse(cur0), coset)
-    f1 = O.ifft_natural_to_natural(O.bitreverse(cur1), coset)
-    out["final_monomials"] = (f0, f1)
-    out["final_degree"] = cur0.size >> log_lde
-    transcript.absorb(f0[:out["final_degree"]])
-    transcript.absorb(f1[:out["final_degree"]])
-    return out
+# ---- the Blake2s layer itself (module-level names, so `from oracle import blake as B; B.hash_leaf(...)` keeps working)
+_LAYER = ByteHashLayer(lambda data: hashlib.blake2s(data).digest(), None, kind=3)
+hash_leaf, hash_node = _LAYER.hash_leaf, _LAYER.hash_node
+merkle_construct, merkle_construct_chunked = _LAYER.merkle_construct, _LAYER.merkle_construct_chunked
+merkle_cap, merkle_proof, merkle_verify, do_fri = _LAYER.merkle_cap, _LAYER.merkle_proof, _LAYER.merkle_verify, _LAYER.do_fri
+Transcript = _LAYER.Transcript

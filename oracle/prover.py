@@ -107,6 +107,9 @@ def hashing_layer(hasher):
     if hasher == 2:
         from oracle import blake
         return blake
+    if hasher == 3:
+        from oracle import keccak
+        return keccak.layer()
     return O
 
 
@@ -146,7 +149,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     has_lookup = c.lookup_reps > 0
     # transcript 1: Poseidon2 (golden proof), 2: Poseidon v1 (SHA-256 bench script), 3: Blake2s (non-recursive config, with the
     # Blake2s tree hasher: Transcript::CompatibleCap = TreeHasher::Output)
-    H = hashing_layer(2 if transcript_kind == 3 else 1)
+    H = hashing_layer({3: 2, 4: 3}.get(transcript_kind, 1))
     t = H.Transcript(transcript_kind)
     t.absorb_cap(setup.cap)                                # prover.rs:211
     pub_vals = [v for (_, _, v) in c.public_inputs]

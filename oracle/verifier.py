@@ -80,7 +80,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
     nC = vk.num_constant_cols
     # ---- transcript replay (verifier.rs:924-1076)
     from oracle.prover import hashing_layer
-    H = hashing_layer(2 if transcript_kind == 3 else 1)
+    H = hashing_layer({3: 2, 4: 3}.get(transcript_kind, 1))
     t = H.Transcript(transcript_kind)
     t.absorb_cap(vk.setup_cap)
     t.absorb(proof["public_inputs"])

@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
     ap.add_argument("--verify", action="store_true")
-    ap.add_argument("--transcript", default="poseidon2", choices=["poseidon2", "poseidon", "blake2s"])
+    ap.add_argument("--transcript", default="poseidon2", choices=["poseidon2", "poseidon", "blake2s", "keccak256"])
     a = ap.parse_args()
     t0 = time.time()
     c = S.sha_shaped_circuit(a.log_n, seed=42, table_bits=4 if a.log_n >= 14 else 2)
