@@ -134,12 +134,13 @@ def main():
     achieved = leaf_bytes / leaf_s / 1e9
     # HBM traffic of that kernel: PMC counters cannot be collected from inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh) is used when it matches the launch shape
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_2p22_leaf_traffic.json")))
         if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
             traffic = pm["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_bench_2p22_leaf_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc passes over this command"
+            valu = pm.get("valu") or None
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -168,7 +169,7 @@ def main():
                                if sharded else ("one GPU" if world == 1 else "one independent proof per rank (replicas), no data-path collective"),
                    "proof_bytes": int(proof_buf.size * 8)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu_pmc": valu,
                      "kernel": "bj::%s_leaves_kernel (witness tree: %d leaves x %d elements per launch)" % ({"blake2s": "blake2s", "keccak256": "keccak"}.get(args.transcript, "poseidon2"), leaves, W),
                      "kernel_ms": round(leaf_s * 1e3, 3), "algorithmic_bytes_per_launch": leaf_bytes,
                      "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},

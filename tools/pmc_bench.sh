@@ -16,6 +16,6 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVES SQ_INSTS_VALU SQ_
   rm -rf $out
 done
 cd $repo
-python3 tools/pmc_leaf_traffic.py gpurun_out/pmcb_${tag}_fetch.raw.csv gpurun_out/pmcb_${tag}_write.raw.csv > gpurun_out/pmc_bench_${tag}.json
+python3 tools/pmc_leaf_traffic.py gpurun_out/pmcb_${tag}_fetch.raw.csv gpurun_out/pmcb_${tag}_write.raw.csv gpurun_out/pmcb_${tag}_sq.raw.csv > gpurun_out/pmc_bench_${tag}.json
 cat gpurun_out/pmc_bench_${tag}.json
 rm -f gpurun_out/pmcb_${tag}_*.raw.csv
