@@ -76,6 +76,27 @@ __device__ __forceinline__ void radix16(u64 (&x)[16], const u64 (&tw)[15]) {
     }
 }
 
+// the same with the 15 twiddles read from LDS where they are used (short live ranges instead of 30 resident VGPRs)
+template <bool UNIT_FIRST>
+__device__ __forceinline__ void radix16_lds(u64 (&x)[16], const u64 *tw) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const u64 w = (UNIT_FIRST && s == 0) ? 1 : tw[(1 << s) - 1 + g];
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const int iu = g * 2 * half + j, iv = iu + half;
+                u64 u = x[iu];
+                u64 v = (UNIT_FIRST && s == 0) ? x[iv] : gl::mul(x[iv], w);
+                x[iu] = gl::add(u, v);
+                x[iv] = gl::sub(u, v);
+            }
+        }
+    }
+}
+
 // block-uniform step twiddles: 15 lanes compute them once, everyone reads them back as LDS broadcasts
 template <bool SCALED>
 __device__ __forceinline__ void stage_uniform_twiddles(u64 *lds_tw, const u64 *__restrict__ T, u32 kb, unsigned r,
@@ -93,8 +114,9 @@ __device__ __forceinline__ void stage_uniform_twiddles(u64 *lds_tw, const u64 *_
 // ---------------------------------------------------------------------------------------------------------
 template <bool SCALED>
 __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args a) {
-    __shared__ u64 lds[LDS_ELEMS + 16];
+    __shared__ u64 lds[LDS_ELEMS + 16 + 16 * 16];
     u64 *lds_tw = lds + LDS_ELEMS;
+    u64 *lds_twB = lds_tw + 16;               // [t >> 4][15 (+1 pad)] twiddles of step B (shared by 16 lanes each)
     const u32 t = threadIdx.x;
     const u32 b = blockIdx.x;
     const unsigned coset = blockIdx.z;
@@ -102,10 +124,17 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
     const size_t n = (size_t)1 << a.log_n;
     const u64 *sc = SCALED ? a.round_scale + (size_t)coset * 32 : nullptr;
 
-    u64 twB[15], twC[15];
-    load_step_twiddles<SCALED>(twB, a.tw, b * 16 + (t >> 4), r0 + 4, sc);
+    u64 twC[15];
     load_step_twiddles<SCALED>(twC, a.tw, b * 256 + t, r0 + 8, sc);
     stage_uniform_twiddles<SCALED>(lds_tw, a.tw, b, r0, sc);
+    if (t < 240) {
+        const u32 m = t / 15, i = t % 15;
+        const int s = 31 - __clz(i + 1);
+        const int g = (int)(i + 1) - (1 << s);
+        u64 v = a.tw[(((size_t)b * 16 + m) << s) + g];
+        if (SCALED) v = gl::mul(v, sc[r0 + 4 + s]);
+        lds_twB[m * 16 + i] = v;
+    }
     __syncthreads();
 
     const unsigned col0 = blockIdx.y * a.cols_per_block;
@@ -129,7 +158,7 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(ta * 256 + j * 16 + tc)];
         __syncthreads();
-        radix16<false>(x, twB);   // step B: bits 7..4
+        radix16_lds<false>(x, lds_twB + ta * 16);   // step B: bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(ta * 256 + j * 16 + tc)] = x[j];
         __syncthreads();
@@ -147,10 +176,15 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+#ifndef BJ_S8_WAVES
+#define BJ_S8_WAVES 3   // tuned: 3 -> 7.6 ms, 4 -> 9.7 ms (spills) per 93 x 2^20 x 8 LDE
+#endif
 template <bool SCALED, bool UNIT_FIRST>
-__global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_strided8_kernel(R16Args a) {
-    __shared__ u64 lds[LDS_ELEMS + 16];
-    u64 *lds_tw = lds + LDS_ELEMS;
+__global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args a) {
+    __shared__ u64 lds[LDS_ELEMS + 16 + 16 * 16];
+    u64 *lds_tw = lds + LDS_ELEMS;            // 15 block-uniform twiddles of the first step
+    u64 *lds_tw2 = lds_tw + 16;               // [tm][15 (+1 pad)] twiddles of the second step: all twiddles live in LDS, which
+                                              // leaves the VGPRs to the 16 data elements and lets four waves share a SIMD
     const u32 t = threadIdx.x;
     const unsigned coset = blockIdx.z;
     const unsigned rem_log = a.log_n - a.r0 - 8;          // bits of "lo" (>= 4)
@@ -160,9 +194,15 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_strided8_kernel(R16Args
     const u64 *sc = SCALED ? a.round_scale + (size_t)coset * 32 : nullptr;
     const u32 tm = t >> 4, tl = t & 15;
 
-    u64 tw2[15];
-    load_step_twiddles<SCALED>(tw2, a.tw, hi * 16 + tm, a.r0 + 4, sc);
     stage_uniform_twiddles<SCALED>(lds_tw, a.tw, hi, a.r0, sc);
+    if (t < 240) {   // second-step twiddles: T[((hi*16 + m) << s) + g] * sc[r0 + 4 + s] for m < 16
+        const u32 m = t / 15, i = t % 15;
+        const int s = 31 - __clz(i + 1);
+        const int g = (int)(i + 1) - (1 << s);
+        u64 v = a.tw[(((size_t)hi * 16 + m) << s) + g];
+        if (SCALED) v = gl::mul(v, sc[a.r0 + 4 + s]);
+        lds_tw2[m * 16 + i] = v;
+    }
     __syncthreads();
 
     const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 4) + tl;
@@ -174,19 +214,14 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_strided8_kernel(R16Args
         u64 x[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = gl::canon(src[(size_t)(j * 16 + tm) << rem_log]);
-        {
-            u64 tw1[15];
-#pragma unroll
-            for (int i = 0; i < 15; i++) tw1[i] = lds_tw[i];
-            radix16<UNIT_FIRST>(x, tw1);   // mid bits 7..4
-        }
+        radix16_lds<UNIT_FIRST>(x, lds_tw);    // mid bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(tm * 256 + j * 16 + tl)];
         __syncthreads();
-        radix16<false>(x, tw2);            // mid bits 3..0
+        radix16_lds<false>(x, lds_tw2 + tm * 16);   // mid bits 3..0
 #pragma unroll
         for (int j = 0; j < 16; j++) dst[(size_t)(tm * 16 + j) << rem_log] = x[j];
     }
