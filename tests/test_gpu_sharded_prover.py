@@ -62,3 +62,24 @@ def test_sharded_setup_rejects_bad_world():
     for rank, world, fri, cap in [(0, 3, 8, 16), (0, 16, 8, 16), (4, 4, 8, 16), (0, 8, 8, 4)]:
         with pytest.raises(E.BoojumHipError):
             E.ProverSetup(ctx(), c, fri, cap, 20, comm=FakeComm(rank, world))
+
+
+def test_torchcomm_all_gather_over_rccl_world_1():
+    """The production transport of bj_comm: torch.distributed backend nccl (= RCCL) on device staging tensors.  A one-GPU box
+    can only form a world of 1, which still exercises the whole TorchComm path (D2D staging, all_gather_into_tensor on uint8,
+    synchronisation, copy back)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = E.TorchComm(ctx())
+        assert comm._on_device and (comm.rank, comm.world) == (0, 1)
+        src = torch.arange(1 << 18, dtype=torch.int64, device="cuda") * 3 + 1
+        dst = torch.zeros_like(src)
+        assert comm._all_gather(None, src.data_ptr(), dst.data_ptr(), src.numel() * 8) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst) and comm.calls == 1
+    finally:
+        dist.destroy_process_group()
