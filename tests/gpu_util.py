@@ -11,6 +11,14 @@ def ctx():
     """One context for the whole test session; raises (no skip, no fallback) when there is no GPU."""
     global _ctx
     if _ctx is None:
+        # PyTorch-ROCm ships its own libamdhip64; whichever copy is loaded first serves the whole process, and torch cannot
+        # initialise on top of the system copy.  bench.py and the sharded workers import torch first — do the same here so
+        # that tests which use torch.distributed in this process (TorchComm over RCCL) see the GPU.
+        try:
+            import torch
+            torch.cuda.init()
+        except Exception:
+            pass
         _ctx = E.Context(0)
     return _ctx
 
