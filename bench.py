@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--transcript", choices=["poseidon", "poseidon2", "blake2s", "keccak256"], default="poseidon",
                     help="poseidon = the bench script's GoldilocksPoisedonTranscript (v1 permutation, no KAT in the reference); "
                          "poseidon2 = the golden proof's transcript (pinned)")
+    ap.add_argument("--circuit", choices=["sha256", "synthetic"], default="sha256",
+                    help="sha256: the reference bench's real SHA-256 circuit over as many random message bytes as fit 2^log_n "
+                         "rows (era_boojum_amd/sha256_circuit.py); synthetic: random satisfiable circuit of the same geometry")
     ap.add_argument("--fri-lde", type=int, default=8)
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
@@ -91,7 +94,18 @@ def main():
     n = 1 << log_n
     table_bits = 4 if log_n >= 14 else 2
     sharded = world > 1 and args.mode != "replicas"
-    circuit = S.sha_shaped_circuit(log_n, seed=42 if sharded else 42 + rank, table_bits=table_bits)
+    seed = 42 if sharded else 42 + rank
+    t_gen = time.perf_counter()
+    if args.circuit == "sha256" and log_n >= 14:
+        from era_boojum_amd import sha256_circuit as SHA
+        msg_len = SHA.message_len_for_log_n(log_n)
+        circuit = SHA.sha256_circuit(SHA.bench_message(msg_len, seed=seed))
+        assert circuit.log_n == log_n
+        circuit_name = "SHA-256 of %d random bytes (seed %d), synthesised like the reference bench (sha256/mod.rs:296-470)" % (msg_len, seed)
+    else:
+        circuit = S.sha_shaped_circuit(log_n, seed=seed, table_bits=table_bits)
+        circuit_name = "SHA-shaped satisfiable synthetic (seed %d)" % seed
+    t_gen = time.perf_counter() - t_gen
     ctx = E.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     comm = E.TorchComm(ctx) if sharded else None
@@ -156,13 +170,13 @@ def main():
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {"workload": "%s: full prove of a SHA-256-shaped circuit, 2^%d rows (92 variable + 1 multiplicity "
+        "config": {"workload": "%s: full prove of the SHA-256 circuit, 2^%d rows (92 variable + 1 multiplicity "
                                "columns, 8x4 lookups, LDE %d, cap %d, security %d, %s, PoW off)"
                                % ({22: "cfg4", 20: "cfg3"}.get(log_n, "custom"), log_n, args.fri_lde, args.cap, args.security,
                                   {"poseidon": "Poseidon2 tree hasher + Poseidon (v1) transcript", "poseidon2": "Poseidon2 tree hasher + Poseidon2 transcript",
                                    "blake2s": "Blake2s tree hasher + Blake2s transcript (the non-recursive configuration)",
                                    "keccak256": "Keccak256 tree hasher + Keccak256 transcript"}[args.transcript]),
-                   "log_n": log_n, "rows": n, "circuit": "SHA-shaped satisfiable synthetic (seed 42)",
+                   "log_n": log_n, "rows": n, "circuit": circuit_name, "circuit_synthesis_s": round(t_gen, 1),
                    "sharding": ("one proof sharded by LDE cosets over %d GPUs (%d cosets = %d Merkle leaves each), all-gather of "
                                 "caps / quotient / first FRI layer / query openings, %d collectives and %.1f MB received per "
                                 "rank per proof" % (world, args.fri_lde // world, leaves, comm_calls, comm_mb))
@@ -207,13 +221,16 @@ def main():
         from oracle import prover as OP
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         threads = min(threads, 64)
-        csmall = S.sha_shaped_circuit(args.cpu_log_n, seed=42, table_bits=4 if args.cpu_log_n >= 14 else 2)
+        if args.circuit == "sha256" and args.cpu_log_n >= 14:
+            csmall = SHA.sha256_circuit(SHA.bench_message(SHA.message_len_for_log_n(args.cpu_log_n), seed=42))
+        else:
+            csmall = S.sha_shaped_circuit(args.cpu_log_n, seed=42, table_bits=4 if args.cpu_log_n >= 14 else 2)
         osetup = OP.Setup(csmall, args.fri_lde, args.cap, threads=threads)
         c0 = time.perf_counter()
         OP.prove(csmall, osetup, args.fri_lde, args.cap, security_level=args.security, threads=threads)
         t_cpu = time.perf_counter() - c0
         out["cpu_baseline"] = {"value": round((1 << args.cpu_log_n) / t_cpu, 1), "unit": "rows/s", "cores": threads, "kind": "port",
-                               "sample": "one proof of the same SHA-shaped circuit at 2^%d rows by the oracle prover (C bulk ops "
+                               "sample": "one proof of the same kind of circuit at 2^%d rows by the oracle prover (C bulk ops "
                                          "+ python orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (args.cpu_log_n, t_cpu)}
     if rank == 0:
         print(json.dumps(out))

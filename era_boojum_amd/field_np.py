@@ -26,7 +26,11 @@ def _load_native():
     lib.synth_mul_scalar.argtypes = [vp, u64, vp, sz]
     lib.synth_fma2.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.synth_powers.argtypes = [u64, vp, sz]
-    for f in (lib.synth_mul, lib.synth_mul_scalar, lib.synth_fma2, lib.synth_powers):
+    lib.synth_sigma_from_placement.argtypes = [vp, sz, sz, sz, vp]
+    lib.synth_sha256_states.argtypes = [vp, sz, vp, vp]
+    lib.synth_gather_values.argtypes = [vp, vp, vp, sz]
+    for f in (lib.synth_mul, lib.synth_mul_scalar, lib.synth_fma2, lib.synth_powers, lib.synth_sigma_from_placement,
+              lib.synth_sha256_states, lib.synth_gather_values):
         f.restype = None
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     lib.synth_set_threads(max(1, min(16, cores)))

@@ -1,0 +1,52 @@
+"""-m gpu: the HIP prover on the REAL SHA-256 bench circuit (era_boojum_amd/sha256_circuit.py): the proof equals the
+oracle prover's and the verifier restatement accepts it; at the reference bench's own size (8 KiB of input, 2^16 rows,
+BASELINE config 1) the proof is checked by the verifier restatement."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import era_boojum_amd as E
+from era_boojum_amd import proof_format
+from era_boojum_amd import sha256_circuit as S
+from gpu_util import ctx
+from oracle import prover as OP
+from oracle import verifier as OV
+from test_gpu_prover import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_proof_of_real_sha256_equals_oracle_proof():
+    msg = S.bench_message(100, seed=7)
+    c, info = S.sha256_circuit(msg, return_info=True)
+    assert info["digest"] == hashlib.sha256(msg).digest() and c.log_n == 14
+    osetup = OP.Setup(c, 8, 16, threads=8)
+    po = OP.prove(c, osetup, 8, 16, security_level=40, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 40)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=40)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    gsetup.close()
+
+
+@pytest.mark.parametrize("transcript", ["poseidon2", "poseidon"])
+def test_hip_proof_of_the_8_kib_bench_circuit_verifies(transcript):
+    """`prove_sha256(8 * (1 << 10))` with the bench's parameters: LDE 8, cap 16, security 100, no PoW
+    (sha256/mod.rs:294, 309-316); "poseidon" is the bench script's transcript."""
+    c = S.sha256_circuit(S.bench_message(8 << 10))
+    assert c.log_n == 16
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript=transcript)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=100)
+    kind = {"poseidon2": 1, "poseidon": 2}[transcript]
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, transcript_kind=kind)
+    # a witness with one wrong bit of the message is rejected by the prover's own satisfiability check
+    bad = c.variables.copy()
+    r = int(np.flatnonzero(c.constants[0] == 1)[0])
+    bad[3, r] = (int(bad[3, r]) + 1) % E.P
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        gsetup.prove(variables=bad)
+    gsetup.close()
