@@ -769,7 +769,8 @@ def sha256_circuit(message: bytes, return_info=False):
     info = dict(digest=bytes(int(v) for v in vals[np.array(output, dtype=np.int64)]), gp_rows=gp_rows, lookup_rows=lk_rows,
                 num_variables=int(next_id), num_blocks=(len(message) + 9 + 63) // 64,
                 gate_instances={"%s%s" % (k, list(c)): int(g_totals[i]) for i, (k, c) in enumerate(cs.key_list)},
-                lookups={t: int(l_totals[t]) for t in sorted(l_totals)})
+                lookups={t: int(l_totals[t]) for t in sorted(l_totals)},
+                var_ids=var_ids, all_values=vals)             # placement and values by variable (WitnessVec + copy hint)
     return circuit, info
 
 

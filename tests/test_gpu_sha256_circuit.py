@@ -50,3 +50,24 @@ def test_hip_proof_of_the_8_kib_bench_circuit_verifies(transcript):
     with pytest.raises(E.BoojumHipError, match="not satisfied"):
         gsetup.prove(variables=bad)
     gsetup.close()
+
+
+def test_prove_from_memcopy_dumps():
+    """A Rust host's `SetupBaseStorage` / `WitnessVec` / `DenseVariablesCopyHint` dumps (era_boojum_amd/memcopy_format.py)
+    give the same proof as the in-memory circuit."""
+    from era_boojum_amd import memcopy_format as M
+    from era_boojum_amd.synthetic import sha_bench_gates
+    c, info = S.sha256_circuit(S.bench_message(33, seed=3), return_info=True)
+    total = sum(t.shape[0] for t in S.sha_tables())
+    back = M.circuit_from_dumps(M.write_setup_base(c),
+                                M.write_witness_vec([], info["all_values"], c.multiplicities[0, :total].astype(np.uint32)),
+                                M.write_variables_hint(info["var_ids"]), sha_bench_gates(), num_gp_vars=60, lookup_width=4,
+                                lookup_reps=8)
+    a = E.ProverSetup(ctx(), c, 8, 16, 30)
+    b = E.ProverSetup(ctx(), back, 8, 16, 30)
+    assert np.array_equal(a.cap(), b.cap())
+    pa, _ = a.prove()
+    pb, _ = b.prove()
+    assert np.array_equal(pa, pb)
+    assert OV.verify(OV.VerificationKey(back, b.cap(), 8, 16), proof_format.parse(pb, security_level=30))
+    a.close(); b.close()
