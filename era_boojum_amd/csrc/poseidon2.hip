@@ -15,6 +15,7 @@
 #include "gl.cuh"
 #include "kernels.h"
 #include "poseidon_rc.inc"
+#include <cstdlib>
 
 using gl::u64;
 using gl::u32;
@@ -167,16 +168,22 @@ __device__ __forceinline__ u64 acc32(u32 x, u64 c) {   // c + x (zero-extended),
     asm("v_mad_u64_u32 %[r], vcc, %[x], 1, %[c]" : [r] "=v"(r) : [x] "v"(x), [c] "v"(c) : "vcc");
     return r;
 }
-template <unsigned K>
-__device__ __forceinline__ u64 shl_plus(u64 a, u64 sum_lo, u64 sum_hi) {
-    const u64 A = K ? mad64(gl::lo32(a), 1u << K, sum_lo) : acc32(gl::lo32(a), sum_lo);
-    const u64 B = K ? mad64(gl::hi32(a), 1u << K, sum_hi) : acc32(gl::hi32(a), sum_hi);
+// A + B * 2^32 -> weak residue, for A < 2^62 and B < 2^62 with A + (B >> 32) * EPS < 2^63 (no carry):
+//   B * 2^32 = B_hi * 2^64 + B_lo * 2^32 == B_hi * EPS + B_lo * 2^32;  T = A + B_hi * EPS;  result = T + (B_lo << 32): one add on
+//   the high word, "+EPS" on its carry (after a wrap the value is < 2^63, so the correction cannot carry again).
+__device__ __forceinline__ u64 combine_split(u64 A, u64 B) {
     u64 T;
     asm("v_mad_u64_u32 %[t], vcc, %[b], -1, %[a]" : [t] "=v"(T) : [b] "v"(gl::hi32(B)), [a] "v"(A) : "vcc");
     u32 c, hi, e;
     hi = __builtin_addc(gl::hi32(T), gl::lo32(B), 0u, &c);
     e = c ? 0xFFFFFFFFu : 0u;
     return gl::pack(gl::lo32(T), hi) + (u64)e;
+}
+template <unsigned K>
+__device__ __forceinline__ u64 shl_plus(u64 a, u64 sum_lo, u64 sum_hi) {
+    const u64 A = K ? mad64(gl::lo32(a), 1u << K, sum_lo) : acc32(gl::lo32(a), sum_lo);
+    const u64 B = K ? mad64(gl::hi32(a), 1u << K, sum_hi) : acc32(gl::hi32(a), sum_hi);
+    return combine_split(A, B);
 }
 
 // state in: any u64 words; state out: weak words (canonicalise what leaves the sponge with gl::canon)
@@ -324,6 +331,70 @@ __global__ void __launch_bounds__(256) poseidon2_nodes_kernel(const u64 *childre
     d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small node layers: ONE permutation spread over 16 lanes (lane l holds state word l, lanes 12..15 idle).
+// A permutation is a dependent chain of ~14 k instructions, so a layer with fewer nodes than the chip has lanes takes
+// ~45 us however small it is — and the top ~13 layers of every tree (and every layer of the small FRI oracles) are such
+// layers: 25-35 % of a 2^14..2^16-row proof and a fixed cost per proof that sharding over GPUs does not shrink.  Spread
+// over lanes, the twelve S-boxes of a full round run side by side and both linear layers become the same routine — a
+// 12-term dot product of the state (exchanged through LDS) with the lane's matrix row — which cuts the chain to ~4 k
+// instructions.  Same arithmetic (weak residues, exact mod p), same digests.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mad_vv(u32 x, u32 y, u64 c) {   // x*y + c, no carry out (callers bound the sums)
+    u64 r;
+    asm("v_mad_u64_u32 %[r], vcc, %[x], %[y], %[c]" : [r] "=v"(r) : [x] "v"(x), [y] "v"(y), [c] "v"(c) : "vcc");
+    return r;
+}
+// sum_k coef[k] * x[k] for coefficients < 2^15: low and high words accumulate apart (each sum < 12 * 2^47 < 2^51)
+__device__ __forceinline__ u64 lane_matvec(const u64 *x, const u32 (&coef)[12]) {
+    u64 a0 = 0, a1 = 0, b0 = 0, b1 = 0;        // two chains per word to halve the dependent length
+#pragma unroll
+    for (int k = 0; k < 12; k += 2) {
+        ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(x + k);
+        a0 = mad_vv(gl::lo32(v.x), coef[k], a0);
+        b0 = mad_vv(gl::hi32(v.x), coef[k], b0);
+        a1 = mad_vv(gl::lo32(v.y), coef[k + 1], a1);
+        b1 = mad_vv(gl::hi32(v.y), coef[k + 1], b1);
+    }
+    return combine_split(a0 + a1, b0 + b1);
+}
+
+constexpr int BJ_LANEPAR_GROUPS = 16;          // permutations per 256-lane workgroup
+__global__ void __launch_bounds__(256)
+poseidon2_nodes_lanepar_kernel(const u64 *children, u64 *parents, size_t num_parents) {
+    __shared__ u64 xchg[2][BJ_LANEPAR_GROUPS][16];
+    const unsigned g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const size_t node = (size_t)blockIdx.x * BJ_LANEPAR_GROUPS + g;
+    const bool live = node < num_parents;
+    // this lane's rows of the external matrix circ(2*M4, M4, M4) and of the internal matrix 1 + diag(2^SH)
+    constexpr u32 M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+    constexpr u32 SH[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
+    u32 ext[12], inl[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        ext[k] = l < 12 ? M4[l & 3][k & 3] * (((unsigned)k >> 2) == (l >> 2) ? 2u : 1u) : 0u;
+        inl[k] = l < 12 ? 1u + ((unsigned)k == l ? (1u << SH[l < 12 ? l : 0]) : 0u) : 0u;
+    }
+    // round constants: a full round adds RC[12r + l] to word l, a partial round RC[12r] to word 0
+    u64 rc[30];
+#pragma unroll
+    for (int r = 0; r < 30; r++) rc[r] = POSEIDON_RC[12 * r + ((r < 4 || r >= 26) && l < 12 ? l : 0)];
+    u64 s = (live && l < 8) ? children[8 * node + l] : 0;
+    xchg[0][g][l] = s;
+    __syncthreads();
+    s = lane_matvec(xchg[0][g], ext);
+#pragma unroll
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        const u64 t = pow7w(addw_rc(s, rc[r]));
+        if (full || l == 0) s = t;
+        xchg[(r + 1) & 1][g][l] = s;
+        __syncthreads();
+        s = full ? lane_matvec(xchg[(r + 1) & 1][g], ext) : lane_matvec(xchg[(r + 1) & 1][g], inl);
+    }
+    if (live && l < 4) parents[4 * node + l] = gl::canon(s);
+}
+
 __global__ void poseidon2_permute_states_kernel(u64 *states, size_t n_states) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
@@ -347,6 +418,13 @@ void launch_poseidon2_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsig
     hipLaunchKernelGGL(poseidon2_leaves_chunked_kernel, dim3((unsigned)((num_leaves + tpb - 1) / tpb)), dim3(tpb), 0,
                        s, d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests);
 }
+static size_t nodes_lanepar_max() {   // layers up to this many parents use the lane-parallel kernel (BJ_NODES_LANEPAR_MAX=0: never)
+    static const size_t v = [] {
+        const char *e = getenv("BJ_NODES_LANEPAR_MAX");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
+    }();
+    return v;
+}
 // tree layout: layer 0 = num_leaves digests, then num_leaves/2, ... down to cap_size (inclusive), back to back
 void launch_poseidon2_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s) {
     u64 *prev = d_tree;
@@ -355,8 +433,11 @@ void launch_poseidon2_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_siz
         u64 *next = prev + 4 * len;
         size_t nl = len / 2;
         unsigned tpb = 256;
-        hipLaunchKernelGGL(poseidon2_nodes_kernel, dim3((unsigned)((nl + tpb - 1) / tpb)), dim3(tpb), 0, s, prev, next,
-                           nl);
+        if (nl <= nodes_lanepar_max())   // latency-bound layer: one permutation per 16 lanes
+            hipLaunchKernelGGL(poseidon2_nodes_lanepar_kernel, dim3((unsigned)((nl + BJ_LANEPAR_GROUPS - 1) / BJ_LANEPAR_GROUPS)),
+                               dim3(tpb), 0, s, prev, next, nl);
+        else
+            hipLaunchKernelGGL(poseidon2_nodes_kernel, dim3((unsigned)((nl + tpb - 1) / tpb)), dim3(tpb), 0, s, prev, next, nl);
         prev = next;
         len = nl;
     }
