@@ -93,6 +93,26 @@ void tmp_free(bj_ctx *ctx, void *p, bool from_arena) {
     if (p && !from_arena) (void)hipFree(p);
 }
 
+constexpr size_t RING_BYTES = (size_t)1 << 20, RING_MAX_BLOCK = (size_t)128 << 10;
+int h2d_async(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (int rc = bind(ctx)) return rc;
+    if (!bytes) return BJ_OK;
+    if (!d_dst || !h_src) return fail(ctx, BJ_ERR_INVALID_ARG, "h2d_async: null pointer");
+    if (bytes > RING_MAX_BLOCK) return bj_memcpy_h2d(ctx, d_dst, h_src, bytes);
+    if (!ctx->h_ring) BJ_HIP(ctx, hipHostMalloc((void **)&ctx->h_ring, RING_BYTES, hipHostMallocDefault));
+    const size_t slot = (bytes + 63) & ~(size_t)63;
+    if (ctx->ring_off + slot > RING_BYTES) ctx->ring_off = 0;
+    if (ctx->ring_inflight + slot > RING_BYTES) {   // the ring wrapped onto copies that may not have run yet
+        BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ring_inflight = 0;
+    }
+    std::memcpy(ctx->h_ring + ctx->ring_off, h_src, bytes);
+    BJ_HIP(ctx, hipMemcpyAsync(d_dst, ctx->h_ring + ctx->ring_off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ctx->ring_off += slot;
+    ctx->ring_inflight += slot;
+    return BJ_OK;
+}
+
 u64 *arena_alloc(bj_ctx *ctx, size_t elems) {
     size_t start = (ctx->arena_off + 63) & ~(size_t)63;   // 512-byte alignment
     if (start + elems > ctx->arena_elems) return nullptr;
@@ -159,6 +179,7 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     if (ctx->d_ptrs) (void)hipFree((void *)ctx->d_ptrs);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -166,6 +187,11 @@ void bj_ctx_destroy(bj_ctx *ctx) {
 
 int bj_ctx_set_stream(bj_ctx *ctx, void *hip_stream) {
     if (!ctx) return BJ_ERR_INVALID_ARG;
+    if (ctx->ring_inflight) {   // staged copies are ordered on the old stream
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->ring_inflight = 0;
+    }
     ctx->stream = (hipStream_t)hip_stream;
     return BJ_OK;
 }
@@ -206,6 +232,7 @@ int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!h_dst || !d_src) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_memcpy_d2h: null pointer");
     BJ_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ring_inflight = 0;
     return BJ_OK;
 }
 
@@ -444,9 +471,7 @@ int bj_merkle_tree_build_ptrs(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, un
         BJ_HIP(ctx, hipMalloc((void **)&ctx->d_ptrs, cap * sizeof(u64 *)));
         ctx->d_ptrs_cap = cap;
     }
-    BJ_HIP(ctx, hipMemcpyAsync((void *)ctx->d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *), hipMemcpyHostToDevice,
-                               ctx->stream));
-    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // caller's pointer array may be transient
+    if (int rc = bj::h2d_async(ctx, (void *)ctx->d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *))) return rc;  // staged: the caller's array may be transient
     bj::launch_tree_leaves(ctx->hasher, nullptr, 0, ctx->d_ptrs, n_cols, num_leaves, d_tree, ctx->stream);
     bj::launch_tree_node_layers(ctx->hasher, d_tree, num_leaves, cap_size, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);

@@ -27,11 +27,17 @@ struct bj_ctx {
     size_t arena_elems = 0, arena_off = 0;
     int hasher = BJ_HASHER_POSEIDON2;   // tree hasher of the bj_merkle_tree_* calls (bj_ctx_set_tree_hasher / bj_prove)
     bool in_proof = false;       // bj_prove_dev is running: temporaries come out of the arena instead of hipMalloc
+    // pinned staging ring for the small host->device blocks between kernels (challenges, pointer tables, query indices):
+    // a copy out of pageable memory costs a blocking staging pass plus a stream synchronisation, ~35 us of idle GPU each
+    unsigned char *h_ring = nullptr;
+    size_t ring_off = 0, ring_inflight = 0;
 };
 
 namespace bj {
 int fail(bj_ctx *ctx, int code, const char *fmt, ...);
 int bind(bj_ctx *ctx);
+// host block -> device, ordered on ctx->stream like a kernel launch; returns without waiting (h_src may be reused at once)
+int h2d_async(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
 int arena_reset(bj_ctx *ctx, size_t need_elems);

@@ -33,6 +33,11 @@ __host__ __device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi <
 
 // a, b in [0,p) -> (a + b) mod p
 __host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    u64 s = a + b;                                    // host: 64-bit words
+    if (s < a) return s + 0xFFFFFFFFULL;              // wrapped: a + b - 2^64 + EPS = a + b - p
+    return s >= P ? s - P : s;
+#endif
     u32 c1, c2, c3, c4;
     u32 s0 = __builtin_addc(lo32(a), lo32(b), 0u, &c1);
     u32 s1 = __builtin_addc(hi32(a), hi32(b), c1, &c2);
@@ -43,6 +48,9 @@ __host__ __device__ __forceinline__ u64 add(u64 a, u64 b) {
 }
 // a, b in [0,p) -> (a - b) mod p
 __host__ __device__ __forceinline__ u64 sub(u64 a, u64 b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return a >= b ? a - b : a - b - 0xFFFFFFFFULL;   // host: borrowed 2^64 = p + EPS
+#endif
     u32 b1, b2, b3, b4;
     u32 d0 = __builtin_subc(lo32(a), lo32(b), 0u, &b1);
     u32 d1 = __builtin_subc(hi32(a), hi32(b), b1, &b2);
@@ -56,6 +64,15 @@ __host__ __device__ __forceinline__ u64 dbl(u64 a) { return add(a, a); }
 
 // (hi_hi : hi_lo : lo) = 128-bit value -> canonical residue, using 2^64 = 2^32 - 1 and 2^96 = -1 (mod p)
 __host__ __device__ __forceinline__ u64 reduce_limbs(u32 hi_hi, u32 hi_lo, u64 lo) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host: the same identities on 64-bit words (the limb chains below are written for the GPU's 32-bit VALU)
+    u64 t = lo - hi_hi;
+    if (lo < hi_hi) t -= 0xFFFFFFFFULL;              // borrowed 2^64 = p + EPS: add p back
+    const u64 m = (u64)hi_lo * 0xFFFFFFFFULL;
+    u64 r = t + m;
+    if (r < m) r += 0xFFFFFFFFULL;                   // wrapped: 2^64 = EPS (mod p); r < 2^64 - 2^33 then, no second wrap
+    return r >= P ? r - P : r;
+#else
     u32 b1, b2, b3, b4;
     // t0 = lo - hi_hi  (+p on borrow), in [0, 2^64)
     u32 d0 = __builtin_subc(lo32(lo), hi_hi, 0u, &b1);
@@ -92,6 +109,7 @@ __host__ __device__ __forceinline__ u64 reduce_limbs(u32 hi_hi, u32 hi_lo, u64 l
     u32 q0 = __builtin_addc(r0, 0xFFFFFFFFu, 0u, &c3);
     u32 q1 = __builtin_addc(r1, 0u, c3, &c4);
     return (c2 | c4) ? pack(q0, q1) : pack(r0, r1);
+#endif
 #endif
 }
 __host__ __device__ __forceinline__ u64 reduce128(u64 hi, u64 lo) { return reduce_limbs(hi32(hi), lo32(hi), lo); }

@@ -72,19 +72,27 @@ inline void poseidon1_permutation(u64 *s) {
         const bool full = r < 4 || r >= 26;
         for (int k = 0; k < 12; k++) s[k] = gl::add(s[k], RC[12 * r + k]);
         for (int k = 0; k < (full ? 12 : 1); k++) s[k] = pow7(s[k]);
-        u64 out[12];
-        for (int row = 0; row < 12; row++) {
-            u64 lo = 0, hi = 0;   // 128-bit accumulator; the sum stays below 2^81
-            for (int col = 0; col < 12; col++) {
-                const unsigned e = EXPS[(col + 12 - row) % 12];
-                const u64 add_lo = s[col] << e, add_hi = e ? s[col] >> (64 - e) : 0;
-                const u64 t = lo + add_lo;
-                hi += add_hi + (t < lo ? 1 : 0);
-                lo = t;
-            }
-            out[row] = gl::add(gl::canon(lo), gl::mul(hi, 0xFFFFFFFFULL));   // 2^64 = 2^32 - 1
+        // out[row] = sum_col s[col] << EXPS[(col - row) mod 12] = sum_d s[(row + d) mod 12] << EXPS[d]: for a fixed d
+        // the twelve rows read a rotated copy of the state and shift by one constant, so the loops over rows vectorise.
+        // Low and high words accumulate apart (each sum < 12 * 2^48), no 128-bit arithmetic.
+        u64 lo2[24], hi2[24], acc_lo[12] = {0}, acc_hi[12] = {0};
+        for (int k = 0; k < 12; k++) {
+            lo2[k] = lo2[k + 12] = s[k] & 0xFFFFFFFFULL;
+            hi2[k] = hi2[k + 12] = s[k] >> 32;
         }
-        for (int k = 0; k < 12; k++) s[k] = out[k];
+        for (int d = 0; d < 12; d++) {
+            const unsigned e = EXPS[d];
+            for (int row = 0; row < 12; row++) {
+                acc_lo[row] += lo2[row + d] << e;
+                acc_hi[row] += hi2[row + d] << e;
+            }
+        }
+        for (int row = 0; row < 12; row++) {
+            // acc_lo + acc_hi * 2^32 = acc_lo + (hi part of acc_hi) * 2^64 + (lo part of acc_hi) * 2^32
+            const unsigned __int128 t = (unsigned __int128)acc_lo[row] + ((unsigned __int128)(acc_hi[row] & 0xFFFFFFFFULL) << 32) +
+                                        (unsigned __int128)(acc_hi[row] >> 32) * 0xFFFFFFFFULL;
+            s[row] = gl::reduce128((u64)(t >> 64), (u64)t);
+        }
     }
 }
 

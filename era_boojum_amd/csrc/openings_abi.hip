@@ -74,8 +74,7 @@ int bj_barycentric_eval_batch(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, un
     const u64 **d_ptrs = (const u64 **)args.d;
     u64 *d_partials = (u64 *)(d_ptrs + n_cols);
     u64 *d_out = d_partials + (size_t)n_cols * nb * 2;
-    BJ_HIP(ctx, hipMemcpyAsync((void *)d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
-    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = bj::h2d_async(ctx, (void *)d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *))) return rc;
     bj::launch_barycentric_eval(d_ptrs, n_cols, n, d_w0, d_w1, d_partials, d_out, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     BJ_HIP(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_cols * 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -117,9 +116,8 @@ int combine_monomials(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64
     if (int rc = args.alloc(ctx, n_cols * sizeof(u64 *) + coefs.size() * sizeof(u64))) return rc;
     const u64 **d_ptrs = (const u64 **)args.d;
     u64 *d_coefs = (u64 *)(d_ptrs + n_cols);
-    BJ_HIP(ctx, hipMemcpyAsync((void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
-    BJ_HIP(ctx, hipMemcpyAsync(d_coefs, coefs.data(), coefs.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = bj::h2d_async(ctx, (void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *))) return rc;
+    if (int rc = bj::h2d_async(ctx, d_coefs, coefs.data(), coefs.size() * sizeof(u64))) return rc;
     bj::launch_linear_combination(d_ptrs, d_coefs, n_cols, n, d_out0, d_out1, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     if (!args.from_arena) BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -162,9 +160,8 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
     if (int rc = args.alloc(ctx, n_cols * sizeof(u64 *) + coefs.size() * sizeof(u64))) return rc;
     const u64 **d_ptrs = (const u64 **)args.d;
     u64 *d_coefs = (u64 *)(d_ptrs + n_cols);
-    BJ_HIP(ctx, hipMemcpyAsync((void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *), hipMemcpyHostToDevice, ctx->stream));
-    BJ_HIP(ctx, hipMemcpyAsync(d_coefs, coefs.data(), coefs.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = bj::h2d_async(ctx, (void *)d_ptrs, ptrs.data(), n_cols * sizeof(u64 *))) return rc;
+    if (int rc = bj::h2d_async(ctx, d_coefs, coefs.data(), coefs.size() * sizeof(u64))) return rc;
     bj::launch_deep_accumulate(d_ptrs, d_coefs, n_cols, N_local, I0, ctx->tw_fwd, C.c0, C.c1,
                                gl::canon(at2[0]), gl::canon(at2[1]), d_dst_c0, d_dst_c1, accumulate, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);

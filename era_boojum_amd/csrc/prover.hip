@@ -486,7 +486,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     }
     ArenaBuf d_alphas, T;
     if ((rc = d_alphas.alloc(ctx, alphas.size()))) return rc;
-    if ((rc = bj_memcpy_h2d(ctx, d_alphas.p, alphas.data(), alphas.size() * 8))) return rc;
+    if ((rc = bj::h2d_async(ctx, d_alphas.p, alphas.data(), alphas.size() * 8))) return rc;
     if ((rc = T.alloc(ctx, 2 * Q))) return rc;
     ArenaBuf Tl;   // this rank's evaluations [2][Qe] (T itself when nothing has to be gathered)
     if (q_local)
@@ -607,7 +607,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
                 if (r) return r;
             }
             u64 *d_part = ctx->d_small + 64 + 64 * 32, *d_all = d_part + 2048;   // the 4096-u64 gather area of the context
-            if ((r = bj_memcpy_h2d(ctx, d_part, mine.data(), 2 * per * 8))) return r;
+            if ((r = bj::h2d_async(ctx, d_part, mine.data(), 2 * per * 8))) return r;
             if ((r = bj::all_gather(ctx, sh, d_part, d_all, 2 * per))) return r;
             std::vector<u64> all(2 * per * sh.world);
             if ((r = bj_memcpy_d2h(ctx, all.data(), d_all, all.size() * 8))) return r;
@@ -774,7 +774,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         const u64 none = ~(u64)0, batch = (u64)1 << 24;
         u64 found = none;
         for (u64 base = 0; found == none; base += batch) {   // batches in order + minimum inside a batch = the smallest nonce,
-            if ((rc = bj_memcpy_h2d(ctx, d_res.p, &none, 8))) return rc;   // i.e. what the reference's serial search returns
+            if ((rc = bj::h2d_async(ctx, d_res.p, &none, 8))) return rc;   // i.e. what the reference's serial search returns
             bj::launch_blake2s_pow(seed, new_pow, base, batch, d_res.p, st);
             BJ_CHECK_LAUNCH(ctx);
             if ((rc = bj_memcpy_d2h(ctx, &found, d_res.p, 8))) return rc;
@@ -806,7 +806,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     {
         std::vector<u64> loc(num_queries);
         for (size_t i = 0; i < num_queries; i++) loc[i] = idxs[i] % N;
-        if ((rc = bj_memcpy_h2d(ctx, d_idx.p, loc.data(), num_queries * 8))) return rc;
+        if ((rc = bj::h2d_async(ctx, d_idx.p, loc.data(), num_queries * 8))) return rc;
     }
     const size_t G = per_query * num_queries;
     std::vector<u64> gathered(G * W);   // [rank][...]; query qi reads the block of rank idxs[qi] / N
@@ -849,7 +849,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             for (size_t qi = 0; qi < num_queries; qi++) li[qi] = ((idxs[qi] >> shift) >> o.log_e) % o.num_leaves;
             const unsigned shift0 = shift;
             shift += o.log_e;
-            if ((rc = bj_memcpy_h2d(ctx, d_li.p, li.data(), num_queries * 8))) return rc;
+            if ((rc = bj::h2d_async(ctx, d_li.p, li.data(), num_queries * 8))) return rc;
             const size_t E2 = (size_t)2 << o.log_e;
             bj::launch_gather_fri_leaves(o.d_c0, o.d_c1, o.log_e, d_li.p, (unsigned)num_queries, d_fo.p, st);
             bj::launch_merkle_paths(o.d_tree, o.num_leaves, fri_depth[i], d_li.p, (unsigned)num_queries,
