@@ -230,6 +230,14 @@ int bj_memcpy_d2h(bj_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (int rc = bind(ctx)) return rc;
     if (!bytes) return BJ_OK;
     if (!h_dst || !d_src) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_memcpy_d2h: null pointer");
+    if (bytes <= bj::RING_MAX_BLOCK) {   // small block: land in pinned memory (a pageable destination costs a staging pass in the runtime)
+        if (!ctx->h_ring) BJ_HIP(ctx, hipHostMalloc((void **)&ctx->h_ring, bj::RING_BYTES, hipHostMallocDefault));
+        BJ_HIP(ctx, hipMemcpyAsync(ctx->h_ring, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));   // runs after every staged upload
+        BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(h_dst, ctx->h_ring, bytes);
+        ctx->ring_off = ctx->ring_inflight = 0;
+        return BJ_OK;
+    }
     BJ_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->ring_inflight = 0;

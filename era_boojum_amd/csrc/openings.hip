@@ -207,22 +207,48 @@ void launch_barycentric_eval(const u64 *const *d_col_ptrs, unsigned n_cols, size
 // MONOMIAL forms: sum_k c_k f_k is a polynomial of degree < n, so it is combined once over n coefficients (1/lde_factor of
 // the LDE-domain traffic) and extended to the FRI domain by one two-column LDE; exact arithmetic, identical values.
 // ---------------------------------------------------------------------------------------------------------
-static constexpr int LC_PTS = 4;
+// PTS points per lane, CU columns in flight.  With few points (a 2^14-row proof has 64 wavefronts of them) the kernel is one
+// long chain of dependent loads — column pointer, then value — per column: the small-n variant keeps 8 columns in flight
+// and one point per lane (234 -> ~40 us at 2^14); the large-n one is throughput-bound and keeps 4 points per lane.
+template <int PTS, int CU>
 __global__ void __launch_bounds__(256)
 linear_combination_kernel(const u64 *const *cols, const u64 *coefs /*[n_cols][2]*/, unsigned n_cols, size_t n, u64 *out0,
                           u64 *out1) {
-    const size_t base = (size_t)blockIdx.x * (256 * LC_PTS) + threadIdx.x;
-    Acc160 s0[LC_PTS], s1[LC_PTS];
+    const size_t base = (size_t)blockIdx.x * (256 * PTS) + threadIdx.x;
+    Acc160 s0[PTS], s1[PTS];
 #pragma unroll
-    for (int k = 0; k < LC_PTS; k++) {
+    for (int k = 0; k < PTS; k++) {
         s0[k].clear();
         s1[k].clear();
     }
-    for (unsigned c = 0; c < n_cols; c++) {
+    unsigned c = 0;
+    for (; c + CU <= n_cols; c += CU) {
+        const u64 *f[CU];
+        u64 v[CU][PTS];
+#pragma unroll
+        for (int j = 0; j < CU; j++) f[j] = cols[c + j];
+#pragma unroll
+        for (int j = 0; j < CU; j++)
+#pragma unroll
+            for (int k = 0; k < PTS; k++) {
+                const size_t i = base + (size_t)k * 256;
+                v[j][k] = i < n ? f[j][i] : 0;
+            }
+#pragma unroll
+        for (int j = 0; j < CU; j++) {
+            const u64 a = coefs[2 * (c + j)], b = coefs[2 * (c + j) + 1];
+#pragma unroll
+            for (int k = 0; k < PTS; k++) {
+                s0[k].fma(v[j][k], a);
+                s1[k].fma(v[j][k], b);
+            }
+        }
+    }
+    for (; c < n_cols; c++) {
         const u64 *f = cols[c];
         const u64 a = coefs[2 * c], b = coefs[2 * c + 1];
 #pragma unroll
-        for (int k = 0; k < LC_PTS; k++) {
+        for (int k = 0; k < PTS; k++) {
             const size_t i = base + (size_t)k * 256;
             const u64 v = i < n ? f[i] : 0;
             s0[k].fma(v, a);
@@ -230,7 +256,7 @@ linear_combination_kernel(const u64 *const *cols, const u64 *coefs /*[n_cols][2]
         }
     }
 #pragma unroll
-    for (int k = 0; k < LC_PTS; k++) {
+    for (int k = 0; k < PTS; k++) {
         const size_t i = base + (size_t)k * 256;
         if (i < n) {
             out0[i] = s0[k].reduce();
@@ -240,8 +266,12 @@ linear_combination_kernel(const u64 *const *cols, const u64 *coefs /*[n_cols][2]
 }
 void launch_linear_combination(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t n, u64 *d_out0,
                                u64 *d_out1, hipStream_t s) {
-    hipLaunchKernelGGL(linear_combination_kernel, dim3((unsigned)((n + 256 * LC_PTS - 1) / (256 * LC_PTS))), dim3(256), 0, s,
-                       d_col_ptrs, d_coefs, n_cols, n, d_out0, d_out1);
+    if (n <= ((size_t)1 << 18))
+        hipLaunchKernelGGL((linear_combination_kernel<1, 8>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_col_ptrs,
+                           d_coefs, n_cols, n, d_out0, d_out1);
+    else
+        hipLaunchKernelGGL((linear_combination_kernel<4, 1>), dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, d_col_ptrs,
+                           d_coefs, n_cols, n, d_out0, d_out1);
 }
 
 // ---------------------------------------------------------------------------------------------------------

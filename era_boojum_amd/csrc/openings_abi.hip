@@ -77,9 +77,7 @@ int bj_barycentric_eval_batch(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, un
     if (int rc = bj::h2d_async(ctx, (void *)d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *))) return rc;
     bj::launch_barycentric_eval(d_ptrs, n_cols, n, d_w0, d_w1, d_partials, d_out, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
-    BJ_HIP(ctx, hipMemcpyAsync(h_out, d_out, (size_t)n_cols * 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return BJ_OK;
+    return bj_memcpy_d2h(ctx, h_out, d_out, (size_t)n_cols * 2 * sizeof(u64));
 }
 
 int bj_deep_quotient_accumulate(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1,

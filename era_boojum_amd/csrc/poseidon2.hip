@@ -360,39 +360,81 @@ __device__ __forceinline__ u64 lane_matvec(const u64 *x, const u32 (&coef)[12]) 
 }
 
 constexpr int BJ_LANEPAR_GROUPS = 16;          // permutations per 256-lane workgroup
+// this lane's rows of the external matrix circ(2*M4, M4, M4) and of the internal matrix 1 + diag(2^SH), and its round
+// constants: a full round adds RC[12r + l] to word l, a partial round RC[12r] to word 0
+struct LaneRows {
+    u32 ext[12], inl[12];
+    u64 rc[30];
+    __device__ __forceinline__ void init(unsigned l) {
+        constexpr u32 M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+        constexpr u32 SH[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            ext[k] = l < 12 ? M4[l & 3][k & 3] * (((unsigned)k >> 2) == (l >> 2) ? 2u : 1u) : 0u;
+            inl[k] = l < 12 ? 1u + ((unsigned)k == l ? (1u << SH[l < 12 ? l : 0]) : 0u) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 30; r++) rc[r] = POSEIDON_RC[12 * r + ((r < 4 || r >= 26) && l < 12 ? l : 0)];
+    }
+};
+// the permutation on a state spread over the lanes of group g (word l in lane l); every lane of the workgroup must call it
+__device__ __forceinline__ u64 lanepar_permutation(u64 s, u64 (&xchg)[2][BJ_LANEPAR_GROUPS][16], unsigned g, unsigned l,
+                                                   const LaneRows &rows) {
+    xchg[0][g][l] = s;
+    __syncthreads();
+    s = lane_matvec(xchg[0][g], rows.ext);
+#pragma unroll
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        const u64 t = pow7w(addw_rc(s, rows.rc[r]));
+        if (full || l == 0) s = t;
+        xchg[(r + 1) & 1][g][l] = s;
+        __syncthreads();
+        s = full ? lane_matvec(xchg[(r + 1) & 1][g], rows.ext) : lane_matvec(xchg[(r + 1) & 1][g], rows.inl);
+    }
+    return s;
+}
+
 __global__ void __launch_bounds__(256)
 poseidon2_nodes_lanepar_kernel(const u64 *children, u64 *parents, size_t num_parents) {
     __shared__ u64 xchg[2][BJ_LANEPAR_GROUPS][16];
     const unsigned g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const size_t node = (size_t)blockIdx.x * BJ_LANEPAR_GROUPS + g;
     const bool live = node < num_parents;
-    // this lane's rows of the external matrix circ(2*M4, M4, M4) and of the internal matrix 1 + diag(2^SH)
-    constexpr u32 M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
-    constexpr u32 SH[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
-    u32 ext[12], inl[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-        ext[k] = l < 12 ? M4[l & 3][k & 3] * (((unsigned)k >> 2) == (l >> 2) ? 2u : 1u) : 0u;
-        inl[k] = l < 12 ? 1u + ((unsigned)k == l ? (1u << SH[l < 12 ? l : 0]) : 0u) : 0u;
-    }
-    // round constants: a full round adds RC[12r + l] to word l, a partial round RC[12r] to word 0
-    u64 rc[30];
-#pragma unroll
-    for (int r = 0; r < 30; r++) rc[r] = POSEIDON_RC[12 * r + ((r < 4 || r >= 26) && l < 12 ? l : 0)];
+    LaneRows rows;
+    rows.init(l);
     u64 s = (live && l < 8) ? children[8 * node + l] : 0;
-    xchg[0][g][l] = s;
-    __syncthreads();
-    s = lane_matvec(xchg[0][g], ext);
-#pragma unroll
-    for (int r = 0; r < 30; r++) {
-        const bool full = r < 4 || r >= 26;
-        const u64 t = pow7w(addw_rc(s, rc[r]));
-        if (full || l == 0) s = t;
-        xchg[(r + 1) & 1][g][l] = s;
-        __syncthreads();
-        s = full ? lane_matvec(xchg[(r + 1) & 1][g], ext) : lane_matvec(xchg[(r + 1) & 1][g], inl);
-    }
+    s = lanepar_permutation(s, xchg, g, l, rows);
     if (live && l < 4) parents[4 * node + l] = gl::canon(s);
+}
+
+// the chunked leaf sponge of the small FRI oracles, one leaf per 16 lanes: lanes 0..7 overwrite the rate part with the
+// next eight elements (zeros past the end), lanes 8..11 carry the capacity
+__global__ void __launch_bounds__(256)
+poseidon2_leaves_chunked_lanepar_kernel(const u64 *src0, const u64 *src1, unsigned n_srcs, unsigned log_e, size_t num_leaves,
+                                        u64 *digests) {
+    __shared__ u64 xchg[2][BJ_LANEPAR_GROUPS][16];
+    const unsigned g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const size_t j = (size_t)blockIdx.x * BJ_LANEPAR_GROUPS + g;
+    const bool live = j < num_leaves;
+    LaneRows rows;
+    rows.init(l);
+    const unsigned E = 1u << log_e, total = n_srcs * E;
+    u64 s = 0;
+    for (unsigned t = 0; t < total; t += 8) {
+        if (l < 8) {
+            const unsigned idx = t + l;
+            u64 v = 0;
+            if (live && idx < total) {
+                const u64 *p = (idx >> log_e) == 0 ? src0 : src1;
+                v = p[j * E + (idx & (E - 1))];
+            }
+            s = v;
+        }
+        s = lanepar_permutation(s, xchg, g, l, rows);
+        __syncthreads();   // the exchange buffers are reused by the next block of the sponge
+    }
+    if (live && l < 4) digests[4 * j + l] = gl::canon(s);
 }
 
 __global__ void poseidon2_permute_states_kernel(u64 *states, size_t n_states) {
@@ -406,6 +448,13 @@ __global__ void poseidon2_permute_states_kernel(u64 *states, size_t n_states) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = gl::canon(s[k]);
 }
 
+static size_t nodes_lanepar_max() {   // layers up to this many parents use the lane-parallel kernel (BJ_NODES_LANEPAR_MAX=0: never)
+    static const size_t v = [] {
+        const char *e = getenv("BJ_NODES_LANEPAR_MAX");
+        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
+    }();
+    return v;
+}
 void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
                              size_t num_leaves, u64 *d_digests, hipStream_t s) {
     unsigned tpb = 256;
@@ -415,15 +464,12 @@ void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *co
 void launch_poseidon2_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsigned n_srcs, unsigned log_e,
                                      size_t num_leaves, u64 *d_digests, hipStream_t s) {
     unsigned tpb = 256;
-    hipLaunchKernelGGL(poseidon2_leaves_chunked_kernel, dim3((unsigned)((num_leaves + tpb - 1) / tpb)), dim3(tpb), 0,
-                       s, d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests);
-}
-static size_t nodes_lanepar_max() {   // layers up to this many parents use the lane-parallel kernel (BJ_NODES_LANEPAR_MAX=0: never)
-    static const size_t v = [] {
-        const char *e = getenv("BJ_NODES_LANEPAR_MAX");
-        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
-    }();
-    return v;
+    if (num_leaves <= nodes_lanepar_max())   // latency-bound: one leaf per 16 lanes
+        hipLaunchKernelGGL(poseidon2_leaves_chunked_lanepar_kernel, dim3((unsigned)((num_leaves + BJ_LANEPAR_GROUPS - 1) / BJ_LANEPAR_GROUPS)),
+                           dim3(tpb), 0, s, d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests);
+    else
+        hipLaunchKernelGGL(poseidon2_leaves_chunked_kernel, dim3((unsigned)((num_leaves + tpb - 1) / tpb)), dim3(tpb), 0,
+                           s, d_src0, d_src1, n_srcs, log_e, num_leaves, d_digests);
 }
 // tree layout: layer 0 = num_leaves digests, then num_leaves/2, ... down to cap_size (inclusive), back to back
 void launch_poseidon2_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s) {
