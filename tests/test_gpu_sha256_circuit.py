@@ -32,16 +32,17 @@ def test_hip_proof_of_real_sha256_equals_oracle_proof():
     gsetup.close()
 
 
-@pytest.mark.parametrize("transcript", ["poseidon2", "poseidon"])
+@pytest.mark.parametrize("transcript", ["poseidon2", "poseidon", "blake2s"])
 def test_hip_proof_of_the_8_kib_bench_circuit_verifies(transcript):
     """`prove_sha256(8 * (1 << 10))` with the bench's parameters: LDE 8, cap 16, security 100, no PoW
-    (sha256/mod.rs:294, 309-316); "poseidon" is the bench script's transcript."""
+    (sha256/mod.rs:294, 309-316); "poseidon" is the recursive-mode bench script's transcript, "blake2s" (tree hasher and
+    transcript) is `run_sha256_prover_non_recursive` = BASELINE config 1 (sha256/mod.rs:265-270)."""
     c = S.sha256_circuit(S.bench_message(8 << 10))
     assert c.log_n == 16
     gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript=transcript)
     buf, _ = gsetup.prove()
     pg = proof_format.parse(buf, security_level=100)
-    kind = {"poseidon2": 1, "poseidon": 2}[transcript]
+    kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3}[transcript]
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, transcript_kind=kind)
     # a witness with one wrong bit of the message is rejected by the prover's own satisfiability check
     bad = c.variables.copy()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Full-prover timing on one GPU: SHA-shaped synthetic circuit, bj_prove_dev with the witness resident in HBM.
-    python tools/prove_bench.py --log-n 16 [--reps 3] [--verify]"""
+"""Full-prover timing on one GPU, bj_prove_dev with the witness resident in HBM.
+    python tools/prove_bench.py --log-n 16 [--reps 3] [--verify]              random circuit of the SHA bench's geometry
+    python tools/prove_bench.py --message-bytes 8192 --transcript blake2s    the reference's own test: SHA-256 of 8 KiB
+                                                                              (2^16 rows), non-recursive configuration"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,10 +19,16 @@ def main():
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
     ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--message-bytes", type=int, default=0, help="prove the real SHA-256 circuit of this many random bytes")
     ap.add_argument("--transcript", default="poseidon2", choices=["poseidon2", "poseidon", "blake2s", "keccak256"])
     a = ap.parse_args()
     t0 = time.time()
-    c = S.sha_shaped_circuit(a.log_n, seed=42, table_bits=4 if a.log_n >= 14 else 2)
+    if a.message_bytes:
+        from era_boojum_amd import sha256_circuit as SHA
+        c = SHA.sha256_circuit(SHA.bench_message(a.message_bytes))
+        a.log_n = c.log_n
+    else:
+        c = S.sha_shaped_circuit(a.log_n, seed=42, table_bits=4 if a.log_n >= 14 else 2)
     t_gen = time.time() - t0
     ctx = E.Context(0)
     t0 = time.time()
