@@ -391,7 +391,8 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
                     + (size_t)nS2 * Ln + tree_elems                                                // s2_lde, s2_tree
                     + 2 * Q + (sh.world > 1 ? 2 * Ln * (sh.world + 1) : 0) + (size_t)2 * q * N + tree_elems + 4 * n + 4 * N                       // T (+ gather staging), q_lde, q_tree, w, deep
                     + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
-                    + 4 * N + (N * sh.world) / 2;                                                  // FRI layers + trees, DEEP argument blocks
+                    + 4 * N + (N * sh.world) / 2                                                   // FRI layers + trees, DEEP argument blocks
+                    + (sh.world > 1 ? 10 * n : 0);                                                 // sharded DEEP numerators: slices + gather staging
         if ((rc = bj::arena_reset(ctx, need))) return rc;
     }
     struct InProof {   // temporaries of the ABI calls below come out of the arena while this is alive
@@ -686,8 +687,9 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     // Every opening set goes the same way: the numerator sum_k ch_k f_k is a polynomial of degree < n, so it is combined on
     // the MONOMIAL forms (n coefficients per column instead of the fri_lde_factor * n values of the FRI domain), extended by
     // one two-column LDE and divided by (x - at) pointwise.  Exact arithmetic: the same values as combining on the LDE.
-    ArenaBuf num_mono, num_lde;
+    ArenaBuf num_mono, num_lde, num_slice;
     if ((rc = num_mono.alloc(ctx, 2 * n))) return rc;
+    if (sh.world > 1 && (rc = num_slice.alloc(ctx, 2 * n / sh.world + 16))) return rc;
     if ((rc = num_lde.alloc(ctx, 2 * N))) return rc;
     auto deep_set = [&](const std::vector<Src> &ls, const std::vector<Src> &ms, const u64 *vals, const u64 *at, int accumulate) -> int {
         const u64 *ch = chs.data() + 2 * choff;
@@ -708,7 +710,19 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             p0.push_back(m.c0);
             p1.push_back(m.c1);
         }
-        int r = bj::combine_monomials(ctx, p0.data(), p1.data(), ms.size(), ch, n, num_mono.p, num_mono.p + n);
+        int r;
+        if (sh.world > 1 && n % sh.world == 0 && n / sh.world >= 256) {
+            // the monomials are replicated: every rank combines its slice of the coefficient range, one all-gather of the
+            // two result columns rebuilds the numerator everywhere (the combination is the replicated part of DEEP)
+            const size_t per = n / sh.world, off = (size_t)sh.rank * per;
+            for (auto &q0 : p0) q0 += off;
+            for (auto &q1 : p1)
+                if (q1) q1 += off;
+            r = bj::combine_monomials(ctx, p0.data(), p1.data(), ms.size(), ch, per, num_slice.p, num_slice.p + per);
+            if (!r) r = bj::all_gather_columns(ctx, sh, num_slice.p, num_mono.p, 2, per);
+        } else {
+            r = bj::combine_monomials(ctx, p0.data(), p1.data(), ms.size(), ch, n, num_mono.p, num_mono.p + n);
+        }
         if (r) return r;
         if (sh.world > 1)
             r = bj_lde_cosets_batch(ctx, num_mono.p, n, num_lde.p, log_n, 2, S->log_L, S->c0, S->cl);
