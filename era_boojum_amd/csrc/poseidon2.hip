@@ -241,20 +241,12 @@ poseidon2_leaves_kernel(const u64 *base, size_t col_stride, const u64 *const *co
     u64 s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0;
-    unsigned c = 0;
-    for (; c + 8 <= n_cols; c += 8) {
+    // ONE call site of the permutation: with a second copy for the zero-padded tail block the kernel is 72 KB of code,
+    // more than the 64 KB instruction cache two CUs share; the tail's zeros are selected by wave-uniform conditions
+    for (unsigned c = 0; c < n_cols; c += 8) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const u64 *p = col_ptrs ? col_ptrs[c + k] : base + (size_t)(c + k) * col_stride;
-            s[k] = p[I];
-        }
-        poseidon2_permutation(s);
-    }
-    if (c < n_cols) {
-        unsigned rem = n_cols - c;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((unsigned)k < rem) {
+            if (c + k < n_cols) {
                 const u64 *p = col_ptrs ? col_ptrs[c + k] : base + (size_t)(c + k) * col_stride;
                 s[k] = p[I];
             } else {
@@ -280,36 +272,16 @@ poseidon2_leaves_chunked_kernel(const u64 *src0, const u64 *src1, unsigned n_src
     u64 s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0;
-    unsigned filled = 0;
-    for (unsigned t = 0; t < total; t++) {
-        unsigned src = t >> log_e, off = t & (E - 1);
-        const u64 *p = src == 0 ? src0 : src1;
-        u64 v = p[j * E + off];
-        // filled is wave-uniform; write through a switch to keep the state in registers
-        switch (filled) {
-            case 0: s[0] = v; break;
-            case 1: s[1] = v; break;
-            case 2: s[2] = v; break;
-            case 3: s[3] = v; break;
-            case 4: s[4] = v; break;
-            case 5: s[5] = v; break;
-            case 6: s[6] = v; break;
-            default: s[7] = v; break;
-        }
-        if (++filled == 8) {
-            poseidon2_permutation(s);
-            filled = 0;
-        }
-    }
-    if (filled) {
-        switch (filled) {  // zero-pad the rate part
-            case 1: s[1] = 0; [[fallthrough]];
-            case 2: s[2] = 0; [[fallthrough]];
-            case 3: s[3] = 0; [[fallthrough]];
-            case 4: s[4] = 0; [[fallthrough]];
-            case 5: s[5] = 0; [[fallthrough]];
-            case 6: s[6] = 0; [[fallthrough]];
-            default: s[7] = 0;
+    for (unsigned t = 0; t < total; t += 8) {   // one call site of the permutation (instruction-cache footprint, see above)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned idx = t + k;             // wave-uniform
+            u64 v = 0;
+            if (idx < total) {
+                const u64 *p = (idx >> log_e) == 0 ? src0 : src1;
+                v = p[j * E + (idx & (E - 1))];
+            }
+            s[k] = v;
         }
         poseidon2_permutation(s);
     }
