@@ -157,3 +157,27 @@ def test_proof_of_work(pow_bits, transcript, kind):
     bad["pow_challenge"] = pg["pow_challenge"] + 1
     assert not OV.verify(vk, bad, transcript_kind=kind)
     gsetup.close()
+
+
+def test_repeated_proofs_are_identical_and_do_not_leak_device_memory():
+    """Serving shape: one setup, many proofs.  Every proof of the same witness is the same bytes (no state leaks between
+    proofs through the arena, the staging ring or the transcript), a failed proof in between does not poison the next
+    one, and device memory stops growing after the first proof (workspace comes from the reused arena)."""
+    import torch
+    c = S.sha_shaped_circuit(10, seed=77, table_bits=2)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    first, _ = gsetup.prove()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    bad = c.variables.copy()
+    rows = np.nonzero(c.constants[0] == 1)[0]
+    bad[3, rows[0]] = (int(bad[3, rows[0]]) + 1) % E.P
+    for i in range(40):
+        if i == 17:
+            with pytest.raises(E.BoojumHipError, match="not satisfied"):
+                gsetup.prove(variables=bad)
+        buf, _ = gsetup.prove()
+        assert np.array_equal(buf, first), i
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
+    gsetup.close()
