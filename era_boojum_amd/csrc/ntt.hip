@@ -16,6 +16,8 @@
 // multiplying the round-r twiddle by shift^(n/2^(r+1)) (the factor shift^(i mod n/2^(r+1)) commutes through the
 // butterfly), so the kernel takes a per-round scale table instead.  Same residues, one HBM pass fewer.
 #include "gl.cuh"
+#include <cstdint>
+#include <cstdlib>
 #include "kernels.h"
 #include <cstdlib>
 
@@ -135,7 +137,7 @@ void launch_round_scales(u64 *d_out, const u64 *h_shifts, unsigned n_cosets, uns
 // (T[g] * sc[r], g < 2^r) and are staged in LDS by the first lanes.  No tile, no barrier in the data path: every access
 // is a fully coalesced 512-byte wave access.  Replaces the generic LDS pass for this case (4x faster at 2^22).
 // ---------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, int V>
 __global__ void __launch_bounds__(256) ntt_first_rounds_kernel(PassArgs a, unsigned n_cosets) {
     constexpr int E = 1 << R;
     __shared__ u64 tws[64 * (E - 1)];                    // [coset][2^R - 1]: round r, group g at (1 << r) - 1 + g
@@ -150,21 +152,37 @@ __global__ void __launch_bounds__(256) ntt_first_rounds_kernel(PassArgs a, unsig
         tws[t] = v;
     }
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // V adjacent indices per lane: 16-byte accesses (1 KB per wave instruction) when the slice allows it
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (i >= quarter) return;
     const unsigned col = blockIdx.y;
     const u64 *src = a.in + (size_t)col * a.in_col_stride + i;
     u64 *dst = a.out + (size_t)col * a.out_col_stride + i;
-    u64 in[E];
+    auto load = [](const u64 *p, u64 (&o)[V]) {
+        if (V == 2) {
+            const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(p);
+            o[0] = gl::canon(q.x);
+            o[V - 1] = gl::canon(q.y);
+        } else {
+            o[0] = gl::canon(p[0]);
+        }
+    };
+    u64 in[E][V];
     if (a.in_coset_stride == 0) {
 #pragma unroll
-        for (int m = 0; m < E; m++) in[m] = gl::canon(src[(size_t)m * quarter]);
+        for (int m = 0; m < E; m++) load(src + (size_t)m * quarter, in[m]);
     }
     for (unsigned c = 0; c < n_cosets; c++) {
-        u64 x[E];
+        u64 x[E][V];
 #pragma unroll
-        for (int m = 0; m < E; m++)
-            x[m] = a.in_coset_stride == 0 ? in[m] : gl::canon(src[(size_t)c * a.in_coset_stride + (size_t)m * quarter]);
+        for (int m = 0; m < E; m++) {
+            if (a.in_coset_stride == 0) {
+#pragma unroll
+                for (int v = 0; v < V; v++) x[m][v] = in[m][v];
+            } else {
+                load(src + (size_t)c * a.in_coset_stride + (size_t)m * quarter, x[m]);
+            }
+        }
         const u64 *tw = tws + c * (E - 1);
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -175,15 +193,24 @@ __global__ void __launch_bounds__(256) ntt_first_rounds_kernel(PassArgs a, unsig
 #pragma unroll
                 for (int j = 0; j < half; j++) {
                     const int iu = g * 2 * half + j, iv = iu + half;
-                    u64 u = x[iu];
-                    u64 v = (g == 0 && !a.round_scale) ? x[iv] : gl::mul(x[iv], w);   // T[0] = 1
-                    x[iu] = gl::add(u, v);
-                    x[iv] = gl::sub(u, v);
+#pragma unroll
+                    for (int v = 0; v < V; v++) {
+                        u64 u = x[iu][v];
+                        u64 t = (g == 0 && !a.round_scale) ? x[iv][v] : gl::mul(x[iv][v], w);   // T[0] = 1
+                        x[iu][v] = gl::add(u, t);
+                        x[iv][v] = gl::sub(u, t);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int m = 0; m < E; m++) dst[(size_t)c * n + (size_t)m * quarter] = x[m];
+        for (int m = 0; m < E; m++) {
+            u64 *o = dst + (size_t)c * n + (size_t)m * quarter;
+            if (V == 2)
+                *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2(x[m][0], x[m][V - 1]);
+            else
+                o[0] = x[m][0];
+        }
     }
 }
 
@@ -192,13 +219,23 @@ static void launch_first_rounds(const u64 *src, u64 *d_out, const u64 *d_tw, con
                                 size_t src_coset_stride, size_t out_col_stride, hipStream_t s) {
     PassArgs a{src, d_out, d_tw, d_round_scale, log_n, 0, R, 0, src_col_stride, src_coset_stride, out_col_stride};
     const size_t quarter = ((size_t)1 << log_n) >> R;
-    dim3 grid((unsigned)((quarter + 255) / 256), n_cols, 1);
-    if (R == 1)
-        hipLaunchKernelGGL(ntt_first_rounds_kernel<1>, grid, dim3(256), 0, s, a, n_cosets);
+    // two indices per lane need 16-byte aligned columns and an even slice
+    const bool wide = quarter % 512 == 0 && src_col_stride % 2 == 0 && src_coset_stride % 2 == 0 && out_col_stride % 2 == 0 &&
+                      ((uintptr_t)src % 16) == 0 && ((uintptr_t)d_out % 16) == 0 && !getenv("BJ_NTT_FIRST_NARROW");
+    dim3 grid((unsigned)((quarter / (wide ? 2 : 1) + 255) / 256), n_cols, 1);
+    if (wide) {
+        if (R == 1)
+            hipLaunchKernelGGL((ntt_first_rounds_kernel<1, 2>), grid, dim3(256), 0, s, a, n_cosets);
+        else if (R == 2)
+            hipLaunchKernelGGL((ntt_first_rounds_kernel<2, 2>), grid, dim3(256), 0, s, a, n_cosets);
+        else
+            hipLaunchKernelGGL((ntt_first_rounds_kernel<3, 2>), grid, dim3(256), 0, s, a, n_cosets);
+    } else if (R == 1)
+        hipLaunchKernelGGL((ntt_first_rounds_kernel<1, 1>), grid, dim3(256), 0, s, a, n_cosets);
     else if (R == 2)
-        hipLaunchKernelGGL(ntt_first_rounds_kernel<2>, grid, dim3(256), 0, s, a, n_cosets);
+        hipLaunchKernelGGL((ntt_first_rounds_kernel<2, 1>), grid, dim3(256), 0, s, a, n_cosets);
     else
-        hipLaunchKernelGGL(ntt_first_rounds_kernel<3>, grid, dim3(256), 0, s, a, n_cosets);
+        hipLaunchKernelGGL((ntt_first_rounds_kernel<3, 1>), grid, dim3(256), 0, s, a, n_cosets);
 }
 
 // Plan: last pass local with up to LOCAL_MAX rounds; earlier rounds in strided passes of <= STRIDED_MAX rounds.
