@@ -234,6 +234,7 @@ def main():
                                          "+ python orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (args.cpu_log_n, t_cpu)}
     if rank == 0:
         print(json.dumps(out))
+    barrier()           # rank 0 may still have been verifying / timing the CPU baseline: leave the group together
     setup.close()
     if dist is not None:
         dist.destroy_process_group()
