@@ -23,7 +23,11 @@ def main():
     torch.cuda.set_device(dev)
     backend = "nccl" if ndev >= world else "gloo"
     dist.init_process_group(backend, rank=rank, world_size=world)
-    circuit = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2)
+    if log_n == 0:      # the real SHA-256 circuit of a 100-byte message (2^14 rows)
+        from era_boojum_amd import sha256_circuit as SHA
+        circuit = SHA.sha256_circuit(SHA.bench_message(100, seed=7))
+    else:
+        circuit = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2)
     ctx = E.Context(dev)
     comm = E.TorchComm(ctx)
     setup = E.ProverSetup(ctx, circuit, fri, cap, sec, comm=comm)
