@@ -346,12 +346,45 @@ __global__ void bitrev_scale_kernel(const u64 *in, u64 *out, unsigned log_n, siz
     if (step != 1) v = gl::mul(v, gl::pow(step, i));
     dst[i] = v;
 }
+// Tiled variant for log_n >= 10: index i = [h : 5 bits][mid][l : 5 bits] and bitrev(i) = [rev(l)][rev(mid)][rev(h)], so for a
+// fixed mid the 32 x 32 elements {(h, l)} are read as 32 runs of 32 consecutive words (row r = rev(l), column c = rev(h))
+// and written as 32 runs of 32 consecutive words (row h, column l): both sides of the permutation are 256-byte runs, the
+// transposition happens in LDS (row stride 33: conflict-free).  The gather above reads one word per 128-byte line.
+__global__ void __launch_bounds__(256)
+bitrev_scale_tiled_kernel(const u64 *in, u64 *out, unsigned log_n, size_t in_col_stride, size_t out_col_stride, u64 scale,
+                          u64 step) {
+    __shared__ u64 tile[32][33];
+    const unsigned mid_bits = log_n - 10;
+    const u32 mid = blockIdx.x, rmid = gl::bitrev32(mid, mid_bits);
+    const u64 *src = in + (size_t)blockIdx.y * in_col_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_col_stride;
+    const unsigned c = threadIdx.x & 31, r0 = threadIdx.x >> 5;       // 8 rows per sweep
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned r = r0 + 8 * k;
+        tile[r][c] = src[((size_t)r << (log_n - 5)) | ((size_t)rmid << 5) | c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned h = r0 + 8 * k, l = c;
+        const size_t i = ((size_t)h << (log_n - 5)) | ((size_t)mid << 5) | l;
+        u64 v = gl::canon(tile[gl::bitrev32(l, 5)][gl::bitrev32(h, 5)]);
+        if (scale != 1) v = gl::mul(v, scale);
+        if (step != 1) v = gl::mul(v, gl::pow(step, i));
+        dst[i] = v;
+    }
+}
 void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n_cols, size_t in_col_stride,
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s) {
     size_t n = (size_t)1 << log_n;
     unsigned tpb = 256;
-    hipLaunchKernelGGL(bitrev_scale_kernel, dim3((unsigned)((n + tpb - 1) / tpb), n_cols), dim3(tpb), 0, s, d_in,
-                       d_out, log_n, in_col_stride, out_col_stride, scale, step);
+    if (log_n >= 10 && !getenv("BJ_BITREV_GATHER"))
+        hipLaunchKernelGGL(bitrev_scale_tiled_kernel, dim3(1u << (log_n - 10), n_cols), dim3(256), 0, s, d_in, d_out, log_n,
+                           in_col_stride, out_col_stride, scale, step);
+    else
+        hipLaunchKernelGGL(bitrev_scale_kernel, dim3((unsigned)((n + tpb - 1) / tpb), n_cols), dim3(tpb), 0, s, d_in,
+                           d_out, log_n, in_col_stride, out_col_stride, scale, step);
 }
 
 __global__ void canonicalize_kernel(u64 *a, size_t n) {
