@@ -74,7 +74,37 @@ class GateProgramBuilder:
         self.writes.append((v.kind, v.index))
 
     def build(self):
-        return GateProgram(self.relations, self.values, self.writes, self.n_tmp)
+        """Temporaries are renamed onto as few slots as a linear scan needs (a slot is free again after the last relation
+        that reads it; what the writes name stays live): the interpreter has BJ_GATE_PROGRAM_MAX_TEMPORARIES of them, a
+        straight trace of a 12 x 12 matrix gate alone would use ~290."""
+        last_use = {}
+        for i, (op, dst, a, b) in enumerate(self.relations):
+            for k, ix in (a, b):
+                if k == IDX_TEMPORARY:
+                    last_use[ix] = i
+        for k, ix in self.writes:
+            if k == IDX_TEMPORARY:
+                last_use[ix] = len(self.relations)
+        slot_of, free, n_slots, relations = {}, [], 0, []
+
+        def rename(ref):
+            k, ix = ref
+            return (k, slot_of[ix]) if k == IDX_TEMPORARY else ref
+        for i, (op, dst, a, b) in enumerate(self.relations):
+            ra, rb = rename(a), rename(b)
+            for k, ix in {a, b}:                                # operands read for the last time here free their slot:
+                if k == IDX_TEMPORARY and last_use[ix] == i:   # the result may take it over (the interpreter reads first)
+                    free.append(slot_of[ix])
+            if dst not in last_use:                             # a result nobody reads (dead code of a trace)
+                last_use[dst] = i
+            slot = free.pop() if free else n_slots
+            n_slots = max(n_slots, slot + 1)
+            slot_of[dst] = slot
+            if last_use[dst] == i:
+                free.append(slot)
+            relations.append((op, slot, ra, rb))
+        writes = [rename(w) for w in self.writes]
+        return GateProgram(relations, self.values, writes, n_slots)
 
 
 class GateProgram:
@@ -206,4 +236,118 @@ def u8x4_fma_program():
     u = u + (a[3] * bb[2] + a[2] * bb[3]) * sh(1)
     u = u + (a[3] * bb[3]) * sh(2)
     b.push(u)
+    return b.build()
+
+
+# ---- the remaining evaluators over general-purpose columns (src/cs/gates/*.rs), written once with the tracer ----
+def conditional_swap_program(n=1):
+    """ConditionalSwapGate<N> (conditional_swap.rs:96-140): selector, then (a, b, result_a, result_b) per pair."""
+    b = GateProgramBuilder()
+    sel = b.var(0)
+    for i in range(n):
+        a, bb, ra, rb = (b.var(4 * i + k) for k in (1, 2, 3, 4))
+        b.push(bb * sel + (1 - sel) * a - ra)
+        b.push(a * sel + (1 - sel) * bb - rb)
+    return b.build()
+
+
+def quadratic_combination_program(n=4):
+    """QuadraticCombinationGate<N> (quadratic_combination.rs:85-117): sum a_i * b_i = 0."""
+    b = GateProgramBuilder()
+    acc = b.var(0) * b.var(1)
+    for i in range(1, n):
+        acc = acc + b.var(2 * i) * b.var(2 * i + 1)
+    b.push(acc)
+    return b.build()
+
+
+def reduction_by_powers_program(n=4):
+    """ReductionByPowersGate<N> (reduction_by_powers_gate.rs:96-135): sum var_i * c^i = result, c row-shared."""
+    b = GateProgramBuilder()
+    c = b.const_poly(0)
+    acc, power = b.var(0) * 1, None
+    for i in range(1, n):
+        power = c if power is None else power * c
+        acc = acc + b.var(i) * power
+    b.push(acc - b.var(n))
+    return b.build()
+
+
+def simple_non_linearity_program(n=7):
+    """SimpleNonlinearityGate<N> (simple_non_linearity_with_constant.rs:96-125): (x + c)^N = y."""
+    b = GateProgramBuilder()
+    t = b.var(0) + b.const_poly(0)
+    acc, base, e = None, t, n
+    while e:                                   # small_pow: square and multiply
+        if e & 1:
+            acc = base if acc is None else acc * base
+        e >>= 1
+        if e:
+            base = base.square()
+    b.push(acc - b.var(1))
+    return b.build()
+
+
+def u32_add_program():
+    """U32AddGate (u32_add.rs:85-125)."""
+    b = GateProgramBuilder()
+    a, bb, cin, c, cout = (b.var(i) for i in range(5))
+    b.push(a + bb + cin - c - b.value(1 << 32) * cout)
+    b.push(cout * cout - cout)
+    return b.build()
+
+
+def u32_sub_program():
+    """U32SubGate (u32_sub.rs:85-125): a - b - borrow_in - c + 2^32 * borrow_out = 0."""
+    b = GateProgramBuilder()
+    a, bb, bin_, c, bout = (b.var(i) for i in range(5))
+    b.push(a - bb - bin_ - c + b.value(1 << 32) * bout)
+    b.push(bout * bout - bout)
+    return b.build()
+
+
+def u32_tri_add_carry_as_chunk_program():
+    """U32TriAddCarryAsChunkGate (u32_tri_add_carry_as_chunk.rs:100-190): three 4x8-bit operands, 8-bit result limbs, carry chunk."""
+    b = GateProgramBuilder()
+    sh = [1, 1 << 8, 1 << 16, 1 << 24]
+    acc = None
+    for op in range(3):
+        for k in range(4):
+            t = b.var(4 * op + k) * sh[k]
+            acc = t if acc is None else acc + t
+    acc = acc - b.var(12)
+    for k in range(1, 4):
+        acc = acc - b.var(12 + k) * sh[k]
+    b.push(acc - b.var(16) * (1 << 32))
+    return b.build()
+
+
+def fma_in_extension_program():
+    """FmaGateInExtensionWithoutConstant (fma_gate_in_extension_without_constant.rs:110-190): q * a * b + l * c = d over
+    F_p[u]/(u^2 - 7), all of a, b, c, d, q, l as (c0, c1) pairs; q, l row-shared constants."""
+    b = GateProgramBuilder()
+    a0, a1, b0, b1, c0, c1, d0, d1 = (b.var(i) for i in range(8))
+    q0, q1, l0, l1 = (b.const_poly(i) for i in range(4))
+    nr = b.value(7)
+    lin0 = c0 * l0 + (c1 * l1) * nr
+    lin1 = c0 * l1 + c1 * l0
+    in0 = a0 * b0 + (a1 * b1) * nr
+    in1 = a0 * b1 + a1 * b0
+    f0 = in0 * q0 + (in1 * q1) * nr
+    f1 = in0 * q1 + in1 * q0
+    b.push(f0 + lin0 - d0)
+    b.push(f1 + lin1 - d1)
+    return b.build()
+
+
+def matrix_multiplication_program(matrix):
+    """MatrixMultiplicationGate<N> (matrix_multiplication_gate.rs:110-140): result = M * input, M a global constant."""
+    n = len(matrix)
+    b = GateProgramBuilder()
+    for r in range(n):
+        acc = None
+        for c in range(n):
+            t = b.var(c) * int(matrix[r][c])
+            acc = t if acc is None else acc + t
+        b.push(acc - b.var(n + r))
     return b.build()

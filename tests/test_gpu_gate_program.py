@@ -130,3 +130,35 @@ def test_circuit_with_more_gate_types_proves_and_verifies():
     with pytest.raises(E.BoojumHipError, match="not satisfied"):
         gsetup.prove(variables=bad)
     gsetup.close()
+
+
+MORE = [  # evaluators the golden proof's circuit does not contain: program, principal width, row constants, repetitions
+    (GP.conditional_swap_program(2), 9, 0, 2),
+    (GP.quadratic_combination_program(4), 8, 0, 3),
+    (GP.reduction_by_powers_program(4), 5, 1, 2),
+    (GP.simple_non_linearity_program(7), 2, 1, 4),
+    (GP.u32_add_program(), 5, 0, 3),
+    (GP.u32_sub_program(), 5, 0, 3),
+    (GP.u32_tri_add_carry_as_chunk_program(), 17, 0, 2),
+    (GP.fma_in_extension_program(), 8, 4, 2),
+    (GP.matrix_multiplication_program([[(7 * r + 3 * c + 1) % 23 + 1 for c in range(12)] for r in range(12)]), 24, 0, 2),
+]
+
+
+@pytest.mark.parametrize("case", range(len(MORE)))
+def test_interpreter_runs_the_remaining_evaluators(case):
+    """The other gates of src/cs/gates over general-purpose columns (formulas pinned against independent restatements in
+    tests/test_gate_programs.py): the interpreter kernel computes what the op list says, with renamed temporary slots."""
+    prog, width, n_const, reps = MORE[case]
+    n_points = 600
+    rng = np.random.default_rng(100 + case)
+    var = rand_gl(rng, (width * reps, n_points), noncanonical=True)
+    con = rand_gl(rng, (max(1, n_const), n_points), noncanonical=True)
+    d_var, d_con = DevBuf(var), DevBuf(con)
+    d_out = DevBuf(nelems=reps * prog.num_terms * n_points)
+    ctx().gate_program_eval(prog, d_var.ptr, n_points, d_con.ptr, n_points, reps, width, 0, n_points, d_out.ptr)
+    got = d_out.get((reps, prog.num_terms, n_points))
+    for i in range(0, n_points, 53):
+        for r in range(reps):
+            want = prog.evaluate([int(x) for x in var[r * width:(r + 1) * width, i]], [int(x) for x in con[:, i]])
+            assert [int(x) for x in got[r, :, i]] == want, (case, i, r)
