@@ -2,7 +2,7 @@
 #pragma once
 #include "ctx.h"
 
-#define BJ_GATE_PROGRAM_MAX_TEMPORARIES 96
+#define BJ_GATE_PROGRAM_MAX_TEMPORARIES 160
 
 namespace bj {
 struct DevRelation {

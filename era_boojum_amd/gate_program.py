@@ -351,3 +351,76 @@ def matrix_multiplication_program(matrix):
             acc = t if acc is None else acc + t
         b.push(acc - b.var(n + r))
     return b.build()
+
+
+def poseidon2_round_constants():
+    """The 360 round constants (30 rounds x 12) from the generated data table the kernels are built with
+    (csrc/poseidon_rc.inc <- src/implementations/poseidon_goldilocks_params.rs:14-105)."""
+    import os
+    import re
+    txt = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "poseidon_rc.inc")).read()
+    vals = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]+)ULL", txt)]
+    assert len(vals) == 360
+    return [vals[12 * r: 12 * r + 12] for r in range(30)]
+
+
+def poseidon2_flattened_program():
+    """Poseidon2FlattenedGate<8, 12, 4> without witness columns (src/cs/gates/poseidon2.rs:165-410): the permutation over
+    130 variables — 12 inputs, 12 outputs, and a fresh variable for every S-box input from the second full round on
+    ("degree reset") — 118 relations.  ~3.4 k recorded operations on ~150 live slots."""
+    rc = poseidon2_round_constants()
+    m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
+    shifts = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]
+    b = GateProgramBuilder()
+
+    def ext(st):
+        blk = []
+        for k in range(3):
+            x = st[4 * k: 4 * k + 4]
+            blk.append([sum((x[j] * m4[i][j] for j in range(1, 4)), x[0] * m4[i][0]) for i in range(4)])
+        sums = [blk[0][i] + blk[1][i] + blk[2][i] for i in range(4)]
+        return [blk[k][i] + sums[i] for k in range(3) for i in range(4)]
+
+    def inner(st):
+        total = st[0]
+        for v in st[1:]:
+            total = total + v
+        return [st[i] * (1 << shifts[i]) + total for i in range(12)]
+
+    def pow7(x):
+        x2 = x.square()
+        return x2.square() * (x2 * x)
+
+    state = [b.var(i) for i in range(12)]
+    output = [b.var(12 + i) for i in range(12)]
+    nxt = 24
+    for rnd in range(4):
+        if rnd != 0:
+            for i in range(12):
+                v = b.var(nxt)
+                nxt += 1
+                b.push(state[i] - v)
+                state[i] = v
+        else:
+            state = ext(state)
+        state = [pow7(s + rc[rnd][i]) for i, s in enumerate(state)]
+        state = ext(state)
+    for rnd in range(22):
+        state[0] = state[0] + rc[4 + rnd][0]
+        v = b.var(nxt)
+        nxt += 1
+        b.push(state[0] - v)
+        state[0] = pow7(v)
+        state = inner(state)
+    for k in range(4):
+        for i in range(12):
+            v = b.var(nxt)
+            nxt += 1
+            b.push(state[i] - v)
+            state[i] = v
+        state = [pow7(s + rc[26 + k][i]) for i, s in enumerate(state)]
+        state = ext(state)
+    for s_, o in zip(state, output):
+        b.push(o - s_)
+    assert nxt == 130 and len(b.writes) == 118
+    return b.build()

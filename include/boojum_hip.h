@@ -279,7 +279,7 @@ typedef struct bj_gate_program {
     uint32_t num_values;
     const bj_gate_index *writes; /* num_terms entries */
     uint32_t num_writes;
-    uint32_t num_temporaries; /* <= 96 */
+    uint32_t num_temporaries; /* <= 160; era_boojum_amd/gate_program.py renames a trace onto the slots it needs */
 } bj_gate_program;
 
 typedef struct bj_gate_desc {

@@ -56,7 +56,7 @@ CASES = [  # program, formula, variables, constants, a satisfying assignment (or
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_traced_program_equals_the_reference_formula(case):
     prog, formula, nv, nc, sat = CASES[case]
-    assert prog.num_temporaries <= 96                      # BJ_GATE_PROGRAM_MAX_TEMPORARIES
+    assert prog.num_temporaries <= 160                     # BJ_GATE_PROGRAM_MAX_TEMPORARIES
     for _ in range(20):
         v, c = rv(nv), rv(nc)
         assert prog.evaluate(v, c) == formula(v, c)
@@ -87,3 +87,14 @@ def test_slot_renaming_keeps_the_semantics_and_shrinks_the_register_file():
     for i in range(200):
         acc = (acc * v[i % 6] + v[(i + 1) % 6]) % P
     assert prog.evaluate(v, []) == [acc % P, (v[2] * v[3] - acc) % P]
+
+
+def test_poseidon2_flattened_gate_equals_the_golden_pinned_evaluator():
+    """The 118-relation gate of the recursion circuits (poseidon2.rs:165-410) as a traced op list against
+    oracle/gates.py::ev_poseidon2_flattened, whose formulas the reference's own proof pins (tests/test_oracle_fixture.py)."""
+    from oracle import gates as OG
+    prog = G.poseidon2_flattened_program()
+    assert prog.num_terms == 118 and prog.num_temporaries <= 160 and len(prog.relations) < 3000
+    for _ in range(3):
+        v = rv(130)
+        assert prog.evaluate(v, []) == [t[0] for t in OG.ev_poseidon2_flattened([(x, 0) for x in v], [])]

@@ -162,3 +162,20 @@ def test_interpreter_runs_the_remaining_evaluators(case):
         for r in range(reps):
             want = prog.evaluate([int(x) for x in var[r * width:(r + 1) * width, i]], [int(x) for x in con[:, i]])
             assert [int(x) for x in got[r, :, i]] == want, (case, i, r)
+
+
+def test_poseidon2_flattened_gate_through_the_interpreter():
+    """The largest evaluator of the reference (118 terms over 130 variables, 2.4 k recorded operations, 122 live slots)
+    through the op-list interpreter against the golden-pinned oracle evaluator."""
+    prog = GP.poseidon2_flattened_program()
+    n_points = 300
+    rng = np.random.default_rng(5)
+    var = rand_gl(rng, (130, n_points), noncanonical=True)
+    con = rand_gl(rng, (1, n_points))
+    d_var, d_con = DevBuf(var), DevBuf(con)
+    d_out = DevBuf(nelems=prog.num_terms * n_points)
+    ctx().gate_program_eval(prog, d_var.ptr, n_points, d_con.ptr, n_points, 1, 130, 0, n_points, d_out.ptr)
+    got = d_out.get((1, prog.num_terms, n_points))
+    for i in (0, 1, 150, n_points - 1):
+        want = [t[0] for t in OG.ev_poseidon2_flattened([(int(x) % P, 0) for x in var[:, i]], [])]
+        assert [int(x) for x in got[0, :, i]] == want, i
