@@ -431,7 +431,8 @@ class _Circuit(C.Structure):
                 ("num_constant_cols", C.c_uint), ("lookup_width", C.c_uint), ("lookup_reps", C.c_uint),
                 ("table_id_col", C.c_uint), ("quotient_degree", C.c_uint), ("num_gates", C.c_uint),
                 ("gates", C.POINTER(_GateDesc)), ("non_residues", C.POINTER(C.c_uint64)), ("num_public_inputs", C.c_uint),
-                ("public_input_cols", C.POINTER(C.c_uint)), ("public_input_rows", C.POINTER(C.c_uint))]
+                ("public_input_cols", C.POINTER(C.c_uint)), ("public_input_rows", C.POINTER(C.c_uint)),
+                ("num_specialized_gates", C.c_uint), ("specialized_gates", C.POINTER(_GateDesc))]
 
 
 class _ProofConfig(C.Structure):
@@ -526,12 +527,18 @@ class ProverSetup:
             if prog is not None:
                 gates[i].kind = 5
                 gates[i].program = C.cast(C.pointer(prog.struct), C.c_void_p)
+        spec_list = list(getattr(c, "specialized_gates", []) or [])
+        spec = (_GateDesc * max(1, len(spec_list)))()
+        for i, g in enumerate(spec_list):                # gates over specialized columns: op lists, no selector
+            spec[i].kind, spec[i].path_len = 5, 0
+            spec[i].num_repetitions, spec[i].var_stride, spec[i].const_stride, spec[i].num_terms = g.reps, g.var_stride, 0, g.num_terms
+            spec[i].program = C.cast(C.pointer(g.program.struct), C.c_void_p)
         nr = np.array(c.non_residues, dtype=np.uint64)
         cols = (C.c_uint * max(1, len(c.public_inputs)))(*[p[0] for p in c.public_inputs])
         rows = (C.c_uint * max(1, len(c.public_inputs)))(*[p[1] for p in c.public_inputs])
         cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, 0, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
                       c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
-                      cols, rows)
+                      cols, rows, len(spec_list), spec if spec_list else None)
         self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3, "keccak256": 4}[transcript]
         self.hasher_kind = {"blake2s": 2, "keccak256": 3}.get(transcript, 1)      # Transcript::CompatibleCap = TreeHasher::Output
         cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind, self.hasher_kind)

@@ -61,6 +61,12 @@ struct bj_setup {
     std::vector<int> gates_flat;   // 12 ints per gate
     std::vector<bj::DevProgram> programs;   // per gate; empty (block == nullptr) unless kind == BJ_GATE_PROGRAM
     unsigned n_gates = 0;
+    struct SpecGate {                        // a gate over specialized columns: op list, no selector, own columns
+        bj::DevProgram program;
+        unsigned reps = 0, width = 0, terms = 0, first_col = 0;
+    };
+    std::vector<SpecGate> spec;
+    unsigned n_spec_terms = 0;
     std::vector<u64> non_residues;
     std::vector<unsigned> pub_cols, pub_rows;
     // proof config
@@ -187,6 +193,7 @@ void bj_setup_destroy(bj_setup *s) {
     if (s->d_tree) (void)hipFree(s->d_tree);
     if (s->d_non_res) (void)hipFree(s->d_non_res);
     for (auto &p : s->programs) p.release();
+    for (auto &g : s->spec) g.program.release();
     delete s;
 }
 
@@ -276,6 +283,38 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
                      (int)G.num_terms, 0, 0, 0, 0, 0, 0};
         for (unsigned b = 0; b < G.path_len; b++) f[6 + b] = G.path[b] ? 1 : 0;
         s->gates_flat.insert(s->gates_flat.end(), f, f + 12);
+    }
+    {   // gates over specialized columns
+        unsigned col = c->num_gp_vars + c->lookup_width * c->lookup_reps;
+        s->spec.resize(c->num_specialized_gates);
+        for (unsigned g = 0; g < c->num_specialized_gates; g++) {
+            const bj_gate_desc &G = c->specialized_gates[g];
+            bool ok = c->specialized_gates && G.kind == BJ_GATE_PROGRAM && G.program && G.path_len == 0 && G.num_repetitions &&
+                      G.var_stride && G.program->num_writes == G.num_terms;
+            for (uint32_t i = 0; ok && i < G.program->num_relations; i++) {
+                const bj_gate_relation &R = G.program->relations[i];
+                const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
+                if (R.a.kind == BJ_IDX_CONSTANT_POLY || (binary && R.b.kind == BJ_IDX_CONSTANT_POLY)) ok = false;
+            }
+            if (!ok) {
+                bj_setup_destroy(s);
+                return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: specialized gate %u must be an op list without a "
+                                "selector path that reads no constant column", g);
+            }
+            bj_setup::SpecGate &sg = s->spec[g];
+            if (int prc = sg.program.upload(ctx, G.program)) {
+                bj_setup_destroy(s);
+                return prc;
+            }
+            sg.reps = G.num_repetitions; sg.width = G.var_stride; sg.terms = G.num_terms; sg.first_col = col;
+            col += sg.reps * sg.width;
+            s->n_spec_terms += sg.reps * sg.terms;
+        }
+        if (col != c->num_vars) {
+            bj_setup_destroy(s);
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: %u variable columns declared, geometry + lookups + "
+                            "specialized gates make %u", c->num_vars, col);
+        }
     }
     s->non_residues.assign(c->non_residues, c->non_residues + c->num_vars);
     for (unsigned i = 0; i < c->num_public_inputs; i++) {
@@ -475,7 +514,8 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     const unsigned n_lookup_terms = has_lookup ? S->lookup_reps + 1 : 0;
     unsigned n_gate_terms = 0;
     for (unsigned g = 0; g < S->n_gates; g++) n_gate_terms += (unsigned)(S->gates_flat[12 * g + 2] * S->gates_flat[12 * g + 5]);
-    const unsigned total_terms = n_lookup_terms + n_gate_terms + 1 + n_chunks;
+    const unsigned n_spec_terms = S->n_spec_terms;   // lookup | specialized | general | L1 | copy-permutation (prover.rs:599-625)
+    const unsigned total_terms = n_lookup_terms + n_spec_terms + n_gate_terms + 1 + n_chunks;
     std::vector<u64> alphas(2 * total_terms);
     {
         gl::e2 a = e2c(alpha), cur{1, 0};
@@ -494,7 +534,8 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         Tl.p = T.p;
     else if ((rc = Tl.alloc(ctx, 2 * Ln))) return rc;
     u64 *t0 = Tl.p, *t1 = Tl.p + (q_local ? Q : Ln);
-    const u64 *a_lookup = d_alphas.p, *a_gates = d_alphas.p + 2 * n_lookup_terms, *a_l1 = a_gates + 2 * n_gate_terms;
+    const u64 *a_lookup = d_alphas.p, *a_spec = d_alphas.p + 2 * n_lookup_terms, *a_gates = a_spec + 2 * n_spec_terms,
+              *a_l1 = a_gates + 2 * n_gate_terms;
     const u64 *d_sig_lde = S->d_lde, *d_con_lde = S->d_lde + (size_t)V * Ln, *d_tab_lde = S->d_lde + (size_t)(V + nC) * Ln;
     if (Qe) {
         bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Qe, t0, t1, st);
@@ -509,6 +550,13 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
             }
             aoff += (unsigned)(f[2] * f[5]);
         }
+        unsigned soff = 0;   // gates over specialized columns: every row, no selector
+        const unsigned char no_path[8] = {0};
+        for (const auto &sg : S->spec) {
+            bj::launch_gate_program(sg.program, wit_lde.p + (size_t)sg.first_col * Ln, Ln, d_con_lde, Ln, 0, no_path, sg.reps,
+                                    sg.width, 0, a_spec + 2 * (size_t)soff, Qe, t0, t1, nullptr, st);
+            soff += sg.reps * sg.terms;
+        }
     }
     if (has_lookup && Qe) {
         const u64 *dA = s2_lde.p + (size_t)(2 + 2 * n_part) * Ln, *dB = dA + (size_t)2 * S->lookup_reps * Ln;
@@ -518,7 +566,7 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     }
     if (Qe)
         bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_L, ctx->tw_fwd,
-                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_gate_terms), a_l1 + 2, Qe, I0, t0, t1, st);
+                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_spec_terms + n_gate_terms), a_l1 + 2, Qe, I0, t0, t1, st);
     BJ_CHECK_LAUNCH(ctx);
     u64 q_shift = gl::GEN;   // coset the gathered evaluations live on
     if (q_local) {

@@ -142,6 +142,35 @@ class GateProgram:
         return [get(w) for w in self.writes]
 
 
+def _evaluate_columns(self, var_cols, con_cols):
+    """The same semantics over whole columns (numpy uint64, era_boojum_amd.field_np): returns one array per term."""
+    import numpy as np
+    from . import field_np as F
+    tmp = {}
+    n = len(var_cols[0]) if len(var_cols) else len(con_cols[0])
+
+    def get(ix):
+        k, i = ix
+        if k == IDX_VARIABLE: return F.canon(np.asarray(var_cols[i], dtype=np.uint64))
+        if k == IDX_CONSTANT_POLY: return F.canon(np.asarray(con_cols[i], dtype=np.uint64))
+        if k == IDX_TEMPORARY: return tmp[i]
+        return np.full(n, self.values[i] % P, dtype=np.uint64)
+    for op, dst, a, b in self.relations:
+        x = get(a)
+        if op == OP_ADD: r = F.add(x, get(b))
+        elif op == OP_DOUBLE: r = F.add(x, x)
+        elif op == OP_SUB: r = F.sub(x, get(b))
+        elif op == OP_NEGATE: r = F.sub(np.zeros(n, dtype=np.uint64), x)
+        elif op == OP_MUL: r = F.mul(x, get(b))
+        elif op == OP_SQUARE: r = F.mul(x, x)
+        else: r = np.array([pow(int(v), P - 2, P) for v in x], dtype=np.uint64)
+        tmp[dst] = r
+    return [get(w) for w in self.writes]
+
+
+GateProgram.evaluate_columns = _evaluate_columns
+
+
 # ---- the evaluators of the SHA bench as op lists (the same formulas quotient.hip hard-codes), and a few more gates ----
 def fma_program():
     b = GateProgramBuilder()

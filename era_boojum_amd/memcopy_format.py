@@ -185,7 +185,7 @@ def multiplicity_column(multiplicities, n):
 
 
 def circuit_from_dumps(setup_base, witness_vec, variables_hint, gates, num_gp_vars, lookup_width=0, lookup_reps=0,
-                       geometry_constant_cols=4, max_allowed_constraint_degree=4):
+                       geometry_constant_cols=4, max_allowed_constraint_degree=4, specialized_gates=()):
     """The prover's inputs from the three dumps a Rust host produces for `prove_cpu_basic` (SetupBaseStorage, WitnessVec,
     DenseVariablesCopyHint) + what is code on the Rust side (the gate list in configuration order, the geometry)."""
     sig, const, tabs, idxes, tree = read_setup_base(setup_base, gates)
@@ -194,7 +194,7 @@ def circuit_from_dumps(setup_base, witness_vec, variables_hint, gates, num_gp_va
     V, n = sig.shape
     if hint.shape != (V, n):
         raise ValueError("the copy hint is %s, the setup has %d columns of %d rows" % (hint.shape, V, n))
-    if V != num_gp_vars + lookup_width * lookup_reps:
+    if V != num_gp_vars + lookup_width * lookup_reps + sum(g.reps * g.var_stride for g in specialized_gates):
         raise ValueError("column count does not match the geometry")
     variables = variables_from_witness_vec(vals, hint)
     max_deg, _ = _stats(tree, 0)
@@ -215,4 +215,4 @@ def circuit_from_dumps(setup_base, witness_vec, variables_hint, gates, num_gp_va
     return Circuit(n.bit_length() - 1, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, const.shape[0],
                    consts_for_gates, table_id_col, q, variables, multiplicities, sig, const, tabs, non_residues(V, n), pubs,
                    total_len, selector_tree=tree, max_allowed_constraint_degree=max_allowed_constraint_degree,
-                   geometry_constant_cols=geometry_constant_cols)
+                   geometry_constant_cols=geometry_constant_cols, specialized_gates=list(specialized_gates))

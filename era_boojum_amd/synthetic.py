@@ -191,20 +191,27 @@ class Circuit:
     selector_tree: object = None    # ('gate', GateDesc) | ('fork', left, right); left = constant, right = 1 - constant
     max_allowed_constraint_degree: int = 4
     geometry_constant_cols: int = 4    # CSGeometry::num_constant_columns (the rest of num_constants_for_gates are selector extras)
+    specialized_gates: list = field(default_factory=list)   # GateDesc with .program: gates over their own columns after the lookup ones
 
     @property
     def n(self):
         return 1 << self.log_n
 
     @property
+    def num_specialized_vars(self):
+        return sum(g.reps * g.var_stride for g in self.specialized_gates)
+
+    @property
     def num_vars(self):
-        return self.num_gp_vars + self.num_lookup_vars
+        return self.num_gp_vars + self.num_lookup_vars + self.num_specialized_vars
 
 
 def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
-                       lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False):
+                       lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False, boolean_columns=0):
     """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
-    (ConstantsAllocator, FMA, Reduction); the rest are Nop rows."""
+    (ConstantsAllocator, FMA, Reduction); the rest are Nop rows.  boolean_columns > 0 adds a BooleanConstraintGate placed
+    over that many specialized columns (GatePlacementStrategy::UseSpecializedColumns, boolean_allocator.rs): every row of
+    those columns holds a bit, some of them linked to a copy of themselves in another boolean column."""
     n = 1 << log_n
     rng = np.random.default_rng(seed)
     rand_f = lambda shape: rng.integers(0, P, size=shape, dtype=np.uint64)
@@ -217,7 +224,7 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         q *= 2
     table_id_col = consts_for_gates
     Kc = consts_for_gates + 1
-    V = num_gp_vars + lookup_width * lookup_reps
+    V = num_gp_vars + lookup_width * lookup_reps + boolean_columns
     variables = np.zeros((V, n), dtype=np.uint64)
     constants = np.zeros((Kc, n), dtype=np.uint64)
     swaps = []   # copy cycles of length 2: (col_a, col_b, row slice) — sigma exchanges the two cells' identities
@@ -311,6 +318,17 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         for j in range(lookup_width):
             variables[num_gp_vars + rep * lookup_width + j] = small[j][pick]
         mult += np.bincount(pick, minlength=n).astype(np.uint64)
+    specialized = []
+    if boolean_columns:
+        from .gate_program import boolean_program
+        first = num_gp_vars + lookup_width * lookup_reps
+        bits = rng.integers(0, 2, size=(boolean_columns, n)).astype(np.uint64)
+        if boolean_columns >= 2:                       # column 1 repeats column 0 on the first half: copy constraints
+            bits[1, : n // 2] = bits[0, : n // 2]
+            swaps.append((first, first + 1, slice(0, n // 2)))
+        variables[first:] = bits
+        specialized.append(GateDesc(GATE_PROGRAM, "BooleanConstraintGate", 2, 0, 1, boolean_columns, 1, 0, 1, False,
+                                    program=boolean_program()))
     # --- sigma = id o link,  id(c, r) = k_c * omega^r; linked cells (the FMA chains) exchange identities
     ks = non_residues(V, n)
     om = F.powers(F.omega(log_n), n)
@@ -326,7 +344,8 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         pubs.append((col, row, int(variables[col, row])))
     return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
                    table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len,
-                   selector_tree=getattr(place_selectors, "last_tree", None), geometry_constant_cols=num_constant_cols)
+                   selector_tree=getattr(place_selectors, "last_tree", None), geometry_constant_cols=num_constant_cols,
+                   specialized_gates=specialized)
 
 
 def check_satisfied(c: Circuit):
@@ -357,6 +376,12 @@ def check_satisfied(c: Circuit):
             for r in range(g.reps):
                 assert not F.sub(var[r * g.var_stride], consts[d + r * g.const_stride])[m].any(), "ConstAlloc unsatisfied"
     assert sum(m.sum() for m in sel_rows.values()) == n, "selector paths must partition the rows"
+    col = c.num_gp_vars + c.num_lookup_vars
+    for g in c.specialized_gates:                       # every row, no selector
+        for r in range(g.reps):
+            for t in g.program.evaluate_columns(var[col + r * g.var_stride: col + (r + 1) * g.var_stride], []):
+                assert not t.any(), "%s over specialized columns unsatisfied" % g.name
+        col += g.reps * g.var_stride
     # copy constraints: sigma(c, r) = id(c', r')  =>  var[c, r] == var[c', r']
     ks = np.array(c.non_residues, dtype=np.uint64)
     om = F.powers(F.omega(c.log_n), n)

@@ -302,7 +302,8 @@ int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint
 
 typedef struct bj_circuit {
     unsigned log_n;              /* trace length 2^log_n */
-    unsigned num_vars;           /* all variable columns: general purpose first, then the specialized lookup columns */
+    unsigned num_vars;           /* all variable columns: general purpose first, then the specialized lookup columns, then the
+                                  * columns of the gates over specialized columns */
     unsigned num_gp_vars;        /* CSGeometry::num_columns_under_copy_permutation */
     unsigned num_witness_cols;   /* must be 0 */
     unsigned num_constant_cols;  /* selector/gate constants + (lookups) the table-id column */
@@ -316,6 +317,14 @@ typedef struct bj_circuit {
     unsigned num_public_inputs;
     const unsigned *public_input_cols; /* vk.fixed_parameters.public_inputs_locations */
     const unsigned *public_input_rows;
+    /* Gates placed with GatePlacementStrategy::UseSpecializedColumns (gate.rs; evaluator.rs:190-236, prover.rs:635-800):
+     * no selector, applied on every row to their own variable columns, which follow the lookup columns in declaration
+     * order (num_repetitions * var_stride columns each; num_vars counts them).  Each is an op list (kind BJ_GATE_PROGRAM,
+     * path_len 0) that reads no constant column — e.g. BooleanConstraintGate, the usual one.  Their quotient terms sit
+     * between the lookup terms and the general-purpose gates' terms in the order of the alpha powers (prover.rs:599-625).
+     * 0 / NULL when there are none. */
+    unsigned num_specialized_gates;
+    const bj_gate_desc *specialized_gates;
 } bj_circuit;
 
 typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */

@@ -182,6 +182,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     # ---- round 3: quotient (prover.rs:560-1495)
     alpha = t.challenge_ext()
     n_lookup_terms = c.lookup_reps + 1 if has_lookup else 0
+    assert not getattr(c, "specialized_gates", None), "the oracle prover has no gates over specialized columns (checked by the verifier restatement and the golden-pinned identity instead)"
     n_gate_terms = sum(g.reps * g.num_terms for g in c.gates)
     n_chunks = (V + q - 1) // q
     total_terms = n_lookup_terms + n_gate_terms + 1 + n_chunks          # prover.rs:599-606 (1 + 1 + n_partials)

@@ -22,6 +22,7 @@ class VerificationKey:
         self.lookup_reps, self.lookup_width = c.lookup_reps, c.lookup_width
         self.table_id_col = c.table_id_col
         self.gates = c.gates
+        self.specialized_gates = list(getattr(c, "specialized_gates", []) or [])   # (evaluator_data.rs:190-236)
         self.quotient_degree = c.quotient_degree
         self.non_residues = list(c.non_residues)
         self.public_input_locations = [(col, row) for (col, row, _) in c.public_inputs]
@@ -119,12 +120,14 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
     z_at_zo = vzo[0]
     # ---- challenges for the quotient terms (prover.rs:599-625 / verifier.rs:1000-1060)
     n_gate_terms = sum(g.reps * g.num_terms for g in vk.gates)
-    total_terms = n_lookup_terms + n_gate_terms + 1 + n_chunks
+    n_spec_terms = sum(g.reps * g.num_terms for g in vk.specialized_gates)
+    total_terms = n_lookup_terms + n_spec_terms + n_gate_terms + 1 + n_chunks      # lookup | specialized | general | L1 | chunks
     alphas = [(1, 0)]
     while len(alphas) < total_terms:
         alphas.append(emul(alphas[-1], alpha))
-    a_lookup, a_gates = alphas[:n_lookup_terms], alphas[n_lookup_terms:n_lookup_terms + n_gate_terms]
-    a_rest = alphas[n_lookup_terms + n_gate_terms:]
+    a_lookup, a_spec = alphas[:n_lookup_terms], alphas[n_lookup_terms:n_lookup_terms + n_spec_terms]
+    a_gates = alphas[n_lookup_terms + n_spec_terms:n_lookup_terms + n_spec_terms + n_gate_terms]
+    a_rest = alphas[n_lookup_terms + n_spec_terms + n_gate_terms:]
     one = (1, 0)
     T = (0, 0)
     if has_lookup:
@@ -147,6 +150,18 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
         for j in range(vk.lookup_width + 1):
             d = eadd(d, emul(gp[j], tab_z[j]))
         T = eadd(T, emul(esub(emul(B_z[0], d), mult_z[0]), a_lookup[vk.lookup_reps]))
+    # gates over specialized columns: no selector, their own variable columns after the lookup ones (verifier.rs:1560-1638)
+    from oracle.gates import EVALUATORS
+    col, off = vk.num_gp_vars + vk.lookup_reps * vk.lookup_width, 0
+    for g in vk.specialized_gates:
+        width, fn = EVALUATORS[g.name][0], EVALUATORS[g.name][5]
+        for r in range(g.reps):
+            for term in fn(var_z[col + r * g.var_stride: col + r * g.var_stride + width], []):
+                T = eadd(T, emul(term, a_spec[off]))
+                off += 1
+        col += g.reps * g.var_stride
+    if off != n_spec_terms or col != vk.num_vars:
+        return fail("specialized gate bookkeeping")
     # gates (verifier.rs:1640-1720)
     off = 0
     for sel, terms in _gate_terms_at(vk, var_z, con_z):

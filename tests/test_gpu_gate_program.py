@@ -179,3 +179,50 @@ def test_poseidon2_flattened_gate_through_the_interpreter():
     for i in (0, 1, 150, n_points - 1):
         want = [t[0] for t in OG.ev_poseidon2_flattened([(int(x) % P, 0) for x in var[:, i]], [])]
         assert [int(x) for x in got[0, :, i]] == want, i
+
+
+def test_gate_over_specialized_columns():
+    """BooleanConstraintGate placed with UseSpecializedColumns (three repetitions over their own columns after the lookup
+    ones, no selector, terms between the lookup and the general-purpose terms in the alpha order — the placement the golden
+    proof's circuit uses): the HIP proof is accepted by the verifier restatement AND satisfies the golden-pinned quotient
+    identity code, which handles specialized gates exactly as it does for the reference's own proof; a non-bit is reported."""
+    import json
+    import oracle as O
+    from oracle import golden_quotient as GQ
+    from oracle import verifier as OV
+    from era_boojum_amd import wire_format as W
+    c = S.sha_shaped_circuit(10, seed=21, table_bits=2, boolean_columns=3)
+    assert c.num_vars == 60 + 32 + 3 and S.check_satisfied(c)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=30)
+    assert len(pg["values_at_z"]) > 2 * 95
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, gsetup.cap(), 8, 16)))
+    t = O.Transcript()
+    t.absorb_cap(gsetup.cap())
+    t.absorb(pg["public_inputs"])
+    t.absorb_cap(np.array(pg["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(pg["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(pg["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), [g.name for g in c.gates], [("BooleanConstraintGate", 3)],
+                                    c.non_residues, dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma,
+                                                         alpha=alpha, z=z), pg["values_at_z"], pg["values_at_z_omega"][0])
+    assert lhs == rhs
+    # without the specialized gate in the verifier's configuration the same proof is rejected (the alpha order shifts)
+    c_no = S.sha_shaped_circuit(10, seed=21, table_bits=2, boolean_columns=3)
+    vk_no = OV.VerificationKey(c_no, gsetup.cap(), 8, 16)
+    vk_no.specialized_gates = []
+    assert not OV.verify(vk_no, pg)
+    bad = c.variables.copy()
+    bad[c.num_vars - 2, 77] = 2
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        gsetup.prove(variables=bad)
+    gsetup.close()
+    # a specialized gate that reads a constant column is refused
+    c.specialized_gates[0].program = GP.constants_allocator_program()
+    with pytest.raises(E.BoojumHipError, match="constant"):
+        E.ProverSetup(ctx(), c, 8, 16, 30)
