@@ -210,7 +210,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     if (!c || !cfg || !h_sigmas || !h_constants) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: null argument");
     if (c->log_n < 1 || c->log_n > 26) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: log_n out of range");
     if (c->num_witness_cols != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: witness columns are not supported");
-    if (c->num_gates == 0 || c->num_gates > 8 || !c->gates) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: 1..8 gates expected");
+    if (c->num_gates == 0 || c->num_gates > 16 || !c->gates) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: 1..16 gates expected");
     if (!bj::is_pow2(c->quotient_degree) || !bj::is_pow2(cfg->fri_lde_factor) || cfg->fri_lde_factor < 2 ||
         !bj::is_pow2(cfg->cap_size))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: quotient degree / fri_lde_factor / cap must be powers of two");
@@ -260,6 +260,10 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     s->lookup_w = c->lookup_width; s->lookup_reps = c->lookup_reps; s->table_id_col = c->table_id_col;
     s->q = c->quotient_degree;
     s->n_gates = c->num_gates;
+    if (c->num_gates > 16) {
+        bj_setup_destroy(s);
+        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: %u gate types over general-purpose columns (at most 16)", c->num_gates);
+    }
     for (unsigned g = 0; g < c->num_gates; g++) {
         const bj_gate_desc &G = c->gates[g];
         if (G.kind < 1 || G.kind > BJ_GATE_PROGRAM || G.path_len > 6 || (G.kind == BJ_GATE_PROGRAM && !G.program) ||

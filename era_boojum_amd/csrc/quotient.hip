@@ -64,8 +64,9 @@ struct GateDev {
     int kind, path_len, reps, var_stride, const_stride, num_terms;
     int path[6];
 };
+constexpr int BJ_MAX_GATES = 16;   // evaluators over general-purpose columns per circuit (the golden proof's circuit has 11)
 struct GateSet {
-    GateDev g[8];
+    GateDev g[BJ_MAX_GATES];
     int n_gates;
 };
 
@@ -251,7 +252,7 @@ void launch_quotient_gates(const u64 *d_vars, size_t var_stride, const u64 *d_co
                            size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s) {
     GateSet gs;
     gs.n_gates = (int)n_gates;
-    for (unsigned g = 0; g < n_gates && g < 8; g++) {
+    for (unsigned g = 0; g < n_gates && g < (unsigned)BJ_MAX_GATES; g++) {
         const int *f = h_gates_flat + 12 * g;
         gs.g[g] = GateDev{f[0], f[1], f[2], f[3], f[4], f[5], {f[6], f[7], f[8], f[9], f[10], f[11]}};
     }

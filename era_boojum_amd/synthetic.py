@@ -68,6 +68,35 @@ def extended_gates(num_gp_vars=60, num_constant_cols=4):
     return g[:3] + extra + g[3:]
 
 
+def recursion_gates(num_gp_vars=130, num_constant_cols=8):
+    """The evaluators over general-purpose columns of the golden proof's inner circuit (a recursion-layer circuit: 130
+    general-purpose columns, 8 x 3 lookup columns, one boolean specialized column = the 155 variable columns of vk.json), in
+    its evaluator order; everything but the SHA bench's four hand-written ones is an op list."""
+    from . import gate_program as GP
+    v = num_gp_vars
+    return [
+        GateDesc(GATE_CONSTANT_ALLOCATOR, "ConstantsAllocatorGate", 1, num_constant_cols, 1, min(num_constant_cols, v), 1, 1, 1, True),
+        GateDesc(GATE_PROGRAM, "U8x4FMAGate", 2, 0, 26, v // 26, 26, 0, 2, True, program=GP.u8x4_fma_program()),
+        GateDesc(GATE_PROGRAM, "Poseidon2FlattenedGate", 7, 0, 130, 1, 130, 0, 118, True, program=GP.poseidon2_flattened_program()),
+        GateDesc(GATE_PROGRAM, "DotProductGate<4>", 2, 0, 9, v // 9, 9, 0, 1, True, program=GP.dot_product4_program()),
+        GateDesc(GATE_PROGRAM, "ZeroCheckGate", 2, 0, 3, v // 3, 3, 0, 2, True, program=GP.zero_check_program()),
+        GateDesc(GATE_FMA, "FmaGateInBaseFieldWithoutConstant", 3, 2, 4, v // 4, 4, 0, 1, True),
+        GateDesc(GATE_PROGRAM, "UIntXAddGate", 2, 1, 5, v // 5, 5, 0, 2, True, program=GP.uintx_add_program()),
+        GateDesc(GATE_PROGRAM, "SelectionGate", 2, 0, 4, v // 4, 4, 0, 1, True, program=GP.selection_program()),
+        GateDesc(GATE_PROGRAM, "ParallelSelectionGate<4>", 2, 0, 13, v // 13, 13, 0, 4, True, program=GP.parallel_selection4_program()),
+        GateDesc(GATE_REDUCTION4, "ReductionGate<4>", 2, 4, 5, v // 5, 5, 0, 1, True),
+        GateDesc(GATE_NOP, "NopGate", 0, 0, 0, 1, 0, 0, 0, True),
+    ]
+
+
+def recursion_like_circuit(log_n, seed=1, table_bits=2):
+    """Random satisfiable circuit with the geometry and the gate set of the golden proof's inner circuit: 130 + 24 + 1
+    variable columns, width-3 lookups, the Poseidon2 flattened gate (118 terms over 130 variables per row), quotient degree 8."""
+    return sha_shaped_circuit(log_n, seed=seed, table_bits=table_bits, num_gp_vars=130, num_constant_cols=8, lookup_width=3,
+                              lookup_reps=8, num_public_inputs=2, boolean_columns=1, gates=recursion_gates(130, 8),
+                              mix=(0.04, 0.08, 0.12, 0.08, 0.08, 0.12, 0.08, 0.08, 0.08, 0.12), max_allowed_constraint_degree=8)
+
+
 # ---- selector placement: restatement of TreeNode::try_add_gate / try_find_placement_for_degree (setup.rs:1346-1572) ----
 def _stats(node, depth):
     if node[0] == "gate":
@@ -207,7 +236,8 @@ class Circuit:
 
 
 def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
-                       lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False, boolean_columns=0):
+                       lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False, boolean_columns=0, gates=None,
+                       max_allowed_constraint_degree=4):
     """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
     (ConstantsAllocator, FMA, Reduction); the rest are Nop rows.  boolean_columns > 0 adds a BooleanConstraintGate placed
     over that many specialized columns (GatePlacementStrategy::UseSpecializedColumns, boolean_allocator.rs): every row of
@@ -215,8 +245,10 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     n = 1 << log_n
     rng = np.random.default_rng(seed)
     rand_f = lambda shape: rng.integers(0, P, size=shape, dtype=np.uint64)
-    gates = extended_gates(num_gp_vars, num_constant_cols) if extended else sha_bench_gates(num_gp_vars, num_constant_cols)
-    if extended:   # rows: the bench mix squeezed into 60 %, 10 % for each op-list gate, Nop for the rest
+    custom = gates is not None          # a caller-supplied gate list: `mix` gives one fraction per gate in front of the last one
+    if not custom:
+        gates = extended_gates(num_gp_vars, num_constant_cols) if extended else sha_bench_gates(num_gp_vars, num_constant_cols)
+    if extended and not custom:   # rows: the bench mix squeezed into 60 %, 10 % for each op-list gate, Nop for the rest
         mix = tuple(0.6 * m for m in mix[:3]) + (0.1, 0.1, 0.1)
     max_deg, consts_for_gates = place_selectors(gates, num_constant_cols)
     q = 1
@@ -285,6 +317,68 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
                 tot = a + b + cin
                 variables[base, rows], variables[base + 1, rows], variables[base + 2, rows] = a, b, cin
                 variables[base + 3, rows], variables[base + 4, rows] = tot & np.uint64(0xFFFFFFFF), tot >> np.uint64(32)
+        elif g.name == "DotProductGate<4>":
+            for r in range(g.reps):
+                base = r * g.var_stride
+                v = [rand_f(m) for _ in range(8)]
+                for i in range(8):
+                    variables[base + i, rows] = v[i]
+                variables[base + 8, rows] = F.add(F.fma2(v[0], v[1], v[2], v[3]), F.fma2(v[4], v[5], v[6], v[7]))
+        elif g.name == "ParallelSelectionGate<4>":
+            for r in range(g.reps):
+                base = r * g.var_stride
+                sel = rng.integers(0, 2, size=m).astype(np.uint64)
+                variables[base, rows] = sel
+                for i in range(4):
+                    a, b = rand_f(m), rand_f(m)
+                    variables[base + 3 * i + 1, rows], variables[base + 3 * i + 2, rows] = a, b
+                    variables[base + 3 * i + 3, rows] = np.where(sel == 1, a, b)
+        elif g.name == "U8x4FMAGate":                       # a * b + c + carry = low + 2^32 * high on 8-bit limbs (u32_fma.rs)
+            for r in range(g.reps):
+                base = r * g.var_stride
+                a, b, cc, ci = (rng.integers(0, 1 << 32, size=m, dtype=np.uint64) for _ in range(4))
+                total = a * b + cc + ci                     # < 2^64
+                low, high = total & np.uint64(0xFFFFFFFF), total >> np.uint64(32)
+                limbs = lambda x: [(x >> np.uint64(8 * i)) & np.uint64(255) for i in range(4)]
+                al, bl = limbs(a), limbs(b)
+                cols = al + bl + limbs(cc) + limbs(ci) + limbs(low) + limbs(high)
+                # the two product-carry variables: what remains of the low relation after its 32 low bits
+                t = (cc + ci + al[0] * bl[0] + ((al[1] * bl[0] + al[0] * bl[1]) << np.uint64(8))
+                     + ((al[2] * bl[0] + al[1] * bl[1] + al[0] * bl[2]) << np.uint64(16))
+                     + ((al[3] * bl[0] + al[2] * bl[1] + al[1] * bl[2] + al[0] * bl[3]) << np.uint64(24)))
+                carry = (t - low) >> np.uint64(32)
+                cols += [carry & np.uint64(255), carry >> np.uint64(8)]
+                for i, col in enumerate(cols):
+                    variables[base + i, rows] = col
+        elif g.name == "Poseidon2FlattenedGate":           # one permutation per row: inputs, outputs, the S-box inputs in between
+            from .gate_program import poseidon2_round_constants
+            rc = poseidon2_round_constants()
+            m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
+            shifts = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]
+
+            def ext(st):
+                blk = [[sum(m4[i][j] * st[4 * k + j] for j in range(4)) % P for i in range(4)] for k in range(3)]
+                sums = [(blk[0][i] + blk[1][i] + blk[2][i]) % P for i in range(4)]
+                return [(blk[k][i] + sums[i]) % P for k in range(3) for i in range(4)]
+            for row in range(lo, hi):
+                st = [int(x) for x in rng.integers(0, P, size=12, dtype=np.uint64)]
+                cells = list(st) + [0] * 12
+                st = ext(st)
+                for rnd in range(4):
+                    if rnd:
+                        cells += st
+                    st = ext([pow((x + rc[rnd][i]) % P, 7, P) for i, x in enumerate(st)])
+                for rnd in range(22):
+                    st[0] = (st[0] + rc[4 + rnd][0]) % P
+                    cells.append(st[0])
+                    st[0] = pow(st[0], 7, P)
+                    tot = sum(st) % P
+                    st = [(st[i] * (1 << shifts[i]) + tot) % P for i in range(12)]
+                for k in range(4):
+                    cells += st
+                    st = ext([pow((x + rc[26 + k][i]) % P, 7, P) for i, x in enumerate(st)])
+                cells[12:24] = st
+                variables[:130, row] = np.array(cells, dtype=np.uint64)
         elif g.kind == GATE_REDUCTION4:
             cs = [rand_f(m) for _ in range(4)]
             for i in range(4):
@@ -345,7 +439,7 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
                    table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len,
                    selector_tree=getattr(place_selectors, "last_tree", None), geometry_constant_cols=num_constant_cols,
-                   specialized_gates=specialized)
+                   specialized_gates=specialized, max_allowed_constraint_degree=max_allowed_constraint_degree)
 
 
 def check_satisfied(c: Circuit):
@@ -375,6 +469,13 @@ def check_satisfied(c: Circuit):
         elif g.kind == GATE_CONSTANT_ALLOCATOR:
             for r in range(g.reps):
                 assert not F.sub(var[r * g.var_stride], consts[d + r * g.const_stride])[m].any(), "ConstAlloc unsatisfied"
+        elif g.kind == GATE_PROGRAM and m.any():      # op-list gates: the program itself on the gate's rows
+            rows = np.flatnonzero(m)
+            for r in range(g.reps):
+                vcols = [var[r * g.var_stride + k][rows] for k in range(g.principal_width)]
+                ccols = [consts[k][rows] for k in range(d + r * g.const_stride, consts.shape[0])]
+                for t in g.program.evaluate_columns(vcols, ccols):
+                    assert not t.any(), "%s unsatisfied" % g.name
     assert sum(m.sum() for m in sel_rows.values()) == n, "selector paths must partition the rows"
     col = c.num_gp_vars + c.num_lookup_vars
     for g in c.specialized_gates:                       # every row, no selector

@@ -311,7 +311,7 @@ typedef struct bj_circuit {
     unsigned lookup_reps;        /* num_repetitions; 0 = no lookup argument */
     unsigned table_id_col;       /* vk.fixed_parameters.table_ids_column_idxes[0] */
     unsigned quotient_degree;    /* vk.fixed_parameters.quotient_degree (power of two) */
-    unsigned num_gates;          /* evaluators over general purpose columns, in evaluator order (<= 8) */
+    unsigned num_gates;          /* evaluators over general purpose columns, in evaluator order (<= 16) */
     const bj_gate_desc *gates;
     const uint64_t *non_residues;     /* num_vars entries: non_residues_for_copy_permutation (copy_permutation.rs:512-523) */
     unsigned num_public_inputs;

@@ -226,3 +226,48 @@ def test_gate_over_specialized_columns():
     c.specialized_gates[0].program = GP.constants_allocator_program()
     with pytest.raises(E.BoojumHipError, match="constant"):
         E.ProverSetup(ctx(), c, 8, 16, 30)
+
+
+@pytest.mark.parametrize("fri_lde,cap", [(2, 32), (8, 16)])
+def test_circuit_of_the_golden_proofs_class_proves_and_verifies(fri_lde, cap):
+    """Geometry and gate set of the golden proof's inner circuit (a recursion-layer circuit): 130 general-purpose + 8 x 3
+    lookup + 1 boolean specialized column = 155 variable columns, eleven evaluators over general-purpose columns incl. the
+    118-term Poseidon2 flattened gate, quotient degree 8 — with the golden proof's own FRI parameters (LDE factor 2, cap 32)
+    and with the bench's.  The proof is accepted by the verifier restatement and satisfies the quotient identity code that
+    the reference's own proof pins, fed with the VerificationKey JSON this repository emits."""
+    import json
+    import oracle as O
+    from oracle import golden_quotient as GQ
+    from oracle import verifier as OV
+    from era_boojum_amd import wire_format as W
+    c = S.recursion_like_circuit(10, seed=4)
+    assert (c.num_vars, c.quotient_degree, len(c.gates)) == (155, 8, 11) and S.check_satisfied(c)
+    gsetup = E.ProverSetup(ctx(), c, fri_lde, cap, 40)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=40)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), fri_lde, cap), pg, verbose=True)
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, gsetup.cap(), fri_lde, cap)))
+    t = O.Transcript()
+    t.absorb_cap(gsetup.cap())
+    t.absorb(pg["public_inputs"])
+    t.absorb_cap(np.array(pg["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(pg["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(pg["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), [g.name for g in c.gates], [("BooleanConstraintGate", 1)],
+                                    c.non_residues, dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma,
+                                                         alpha=alpha, z=z), pg["values_at_z"], pg["values_at_z_omega"][0])
+    assert lhs == rhs
+    # one wrong S-box input inside a Poseidon2 row
+    g = c.gates[2]
+    m = np.ones(c.n, dtype=bool)
+    for i, bit in enumerate(g.path):
+        m &= c.constants[i] == (1 if bit else 0)
+    bad = c.variables.copy()
+    row = int(np.flatnonzero(m)[3])
+    bad[77, row] = (int(bad[77, row]) + 1) % P
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        gsetup.prove(variables=bad)
+    gsetup.close()
