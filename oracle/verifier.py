@@ -30,6 +30,49 @@ class VerificationKey:
         self.fri_lde_factor, self.cap_size = fri_lde_factor, cap_size
 
 
+class _Gate:
+    pass
+
+
+def vk_from_reference_geometry(geometry, setup_cap, general_gates, specialized_gates, non_residues, fri_lde_factor, cap_size):
+    """A VerificationKey for verify() out of the reference's own layout (vk.fixed_parameters as cut into the golden fixture):
+    evaluator names in gate_idx order, [(name, repetitions)] for the gates over specialized columns; paths from the
+    `selectors_placement` tree (left = the constant)."""
+    from oracle.gates import EVALUATORS
+    from oracle.golden_quotient import _paths
+    vk = VerificationKey.__new__(VerificationKey)
+    n = geometry["domain_size"]
+    lk = geometry["lookup"].get("UseSpecializedColumnsWithTableIdAsConstant") if isinstance(geometry["lookup"], dict) else None
+    w, reps = (lk["width"], lk["num_repetitions"]) if lk else (0, 0)
+    vgp = geometry["num_variable_columns"]
+    paths = {}
+    _paths(geometry["selectors_placement"], [], paths)
+    vk.gates, vk.specialized_gates = [], []
+    for idx, name in enumerate(general_gates):
+        width, reps_fn, n_shared, cstride, n_terms, _ = EVALUATORS[name]
+        g = _Gate()
+        g.name, g.kind, g.path, g.num_terms = name, 0, list(paths.get(idx, [])), n_terms
+        g.reps, g.var_stride, g.const_stride = reps_fn(vgp, geometry["num_constant_columns"]), width, cstride
+        vk.gates.append(g)
+    for name, r in specialized_gates:
+        g = _Gate()
+        g.name, g.kind, g.path, g.reps = name, 0, [], r
+        g.var_stride, g.const_stride, g.num_terms = EVALUATORS[name][0], 0, EVALUATORS[name][4]
+        vk.specialized_gates.append(g)
+    vk.log_n, vk.n = n.bit_length() - 1, n
+    vk.num_gp_vars = vgp
+    vk.num_vars = vgp + w * reps + sum(g.reps * g.var_stride for g in vk.specialized_gates)
+    vk.num_constant_cols = geometry["num_constant_columns"] + geometry["extra_constant_polys_for_selectors"] + len(geometry["table_ids_column_idxes"])
+    vk.lookup_reps, vk.lookup_width = reps, w
+    vk.table_id_col = geometry["table_ids_column_idxes"][0] if lk else 0
+    vk.quotient_degree = geometry["quotient_degree"]
+    vk.non_residues = list(non_residues)
+    vk.public_input_locations = [tuple(x) for x in geometry["public_inputs_locations"]]
+    vk.setup_cap = np.array(setup_cap, dtype=np.uint64)
+    vk.fri_lde_factor, vk.cap_size = fri_lde_factor, cap_size
+    return vk
+
+
 def _gate_terms_at(vk, var, con):
     """[(selector, [terms...])] with var/con = F_p^2 values of the variable / constant polys at z."""
     out = []
@@ -62,7 +105,9 @@ def _gate_terms_at(vk, var, con):
     return out
 
 
-def verify(vk, proof, verbose=False, transcript_kind=1):
+def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
+    """partial_queries: the proof carries only the FIRST k of the query openings (the golden fixture keeps 6 of 100);
+    indices are drawn in order, so the first k can be checked on their own."""
     def fail(msg):
         if verbose:
             print("verify:", msg)
@@ -212,7 +257,8 @@ def verify(vk, proof, verbose=False, transcript_kind=1):
         if not pow_ok(pow_seed(t), new_pow, nonce):
             return fail("invalid proof of work")
         t.absorb([nonce & 0xFFFFFFFF, nonce >> 32])
-    if len(proof["queries_per_fri_repetition"]) != num_queries:
+    if len(proof["queries_per_fri_repetition"]) != num_queries and not (
+            partial_queries and 0 < len(proof["queries_per_fri_repetition"]) < num_queries):
         return fail("unexpected number of queries")
     om = O.omega(log_n)
     pub_tuples = []

@@ -287,3 +287,53 @@ def test_golden_pinned_identity_accepts_our_proofs():
                                     dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
                                     proof["values_at_z"], proof["values_at_z_omega"][0])
     assert lhs == rhs
+
+
+def _golden_proof_dict(fx):
+    return {"proof_config": fx["proof_config"], "public_inputs": fx["public_inputs"],
+            "witness_oracle_cap": fx["witness_oracle_cap"], "stage_2_oracle_cap": fx["stage_2_oracle_cap"],
+            "quotient_oracle_cap": fx["quotient_oracle_cap"], "values_at_z": fx["values_at_z"],
+            "values_at_z_omega": fx["values_at_z_omega"], "values_at_0": fx["values_at_0"],
+            "fri_base_oracle_cap": fx["fri_base_oracle_cap"], "fri_intermediate_oracles_caps": fx["fri_intermediate_oracles_caps"],
+            "final_fri_monomials": fx["final_fri_monomials"], "pow_challenge": fx["pow_challenge"],
+            "queries_per_fri_repetition": fx["queries"]}
+
+
+def test_whole_proof_verifier_accepts_the_golden_proof(fixture_json):
+    """oracle/verifier.py::verify — the very function that accepts the proofs of the oracle prover and of the HIP prover —
+    run on the reference's own proof.json / vk.json (the six query openings the fixture keeps): transcript, opening
+    counts and order, lookup sumcheck, quotient identity over twelve evaluator types, DEEP over all four point sets incl.
+    the public inputs, Merkle paths of the four base oracles, the FRI chain down to the final monomials.  One function,
+    pinned end to end by reference-produced data; every tampered part below is rejected."""
+    import copy
+    from oracle import verifier as OV
+    from era_boojum_amd.synthetic import non_residues
+    fx = fixture_json
+    cfg = fx["proof_config"]
+    vk = OV.vk_from_reference_geometry(fx["geometry"], fx["setup_merkle_tree_cap"], GOLDEN_GENERAL_GATES,
+                                       [("BooleanConstraintGate", 1)], non_residues(155, fx["geometry"]["domain_size"]),
+                                       cfg["fri_lde_factor"], cfg["merkle_tree_cap_size"])
+    assert (vk.num_vars, vk.num_constant_cols, vk.lookup_width, vk.lookup_reps, vk.quotient_degree) == (155, 8, 3, 8, 8)
+    proof = _golden_proof_dict(fx)
+    assert OV.verify(vk, proof, verbose=True, partial_queries=True)
+    assert not OV.verify(vk, proof), "all 100 queries are required without partial_queries"
+
+    def tampered(edit):
+        p = copy.deepcopy(proof)
+        edit(p)
+        return OV.verify(vk, p, partial_queries=True)
+    def bump(lst, i, j=None):
+        if j is None:
+            lst[i] = (lst[i] + 1) % P
+        else:
+            lst[i][j] = (lst[i][j] + 1) % P
+    assert not tampered(lambda p: bump(p["values_at_z"], 200, 0))                                  # quotient identity
+    assert not tampered(lambda p: bump(p["values_at_0"], 3, 1))                                    # lookup sumcheck
+    assert not tampered(lambda p: bump(p["public_inputs"], 1))                                     # transcript + DEEP
+    assert not tampered(lambda p: bump(p["queries_per_fri_repetition"][2]["witness_query"]["leaf_elements"], 40))   # Merkle leaf
+    assert not tampered(lambda p: bump(p["queries_per_fri_repetition"][4]["fri_queries"][3]["proof"][0], 2))        # FRI path
+    assert not tampered(lambda p: bump(p["final_fri_monomials"][1], 5))                            # final monomials
+    assert not tampered(lambda p: bump(p["quotient_oracle_cap"][7], 0))                            # a cap
+    vk2 = copy.copy(vk)
+    vk2.specialized_gates = []
+    assert not OV.verify(vk2, proof, partial_queries=True)                                         # the boolean gate matters
