@@ -46,6 +46,9 @@ void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, c
                          u64 *d_out, hipStream_t s);
 void launch_gather_fri_leaves(const u64 *d_c0, const u64 *d_c1, unsigned log_e, const u64 *d_leaf_idx, unsigned n_idx,
                               u64 *d_out, hipStream_t s);
+void launch_quotient_poseidon2_flattened(const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                                         unsigned path_len, const unsigned char *path, const u64 *d_alphas, size_t Q,
+                                         u64 *d_out0, u64 *d_out1, hipStream_t s);
 int combine_monomials(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
                       const uint64_t *h_challenges, size_t n, uint64_t *d_out0, uint64_t *d_out1);
 int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const uint64_t *const *h_src_c1, size_t n_src,
@@ -266,8 +269,10 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     }
     for (unsigned g = 0; g < c->num_gates; g++) {
         const bj_gate_desc &G = c->gates[g];
-        if (G.kind < 1 || G.kind > BJ_GATE_PROGRAM || G.path_len > 6 || (G.kind == BJ_GATE_PROGRAM && !G.program) ||
-            (G.kind != BJ_GATE_PROGRAM && G.kind != BJ_GATE_NOP && G.num_terms != 1)) {
+        const bool p2 = G.kind == BJ_GATE_POSEIDON2_FLATTENED;
+        if (G.kind < 1 || G.kind > BJ_GATE_POSEIDON2_FLATTENED || G.path_len > 6 || (G.kind == BJ_GATE_PROGRAM && !G.program) ||
+            (p2 && (G.num_terms != 118 || G.num_repetitions != 1 || c->num_gp_vars < 130)) ||
+            (G.kind != BJ_GATE_PROGRAM && G.kind != BJ_GATE_NOP && !p2 && G.num_terms != 1)) {
             bj_setup_destroy(s);
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad gate descriptor %u", g);
         }
@@ -546,6 +551,12 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         unsigned aoff = 0;   // op-list gates (seam S3) add their contribution on top, with their own slice of alpha powers
         for (unsigned g = 0; g < S->n_gates; g++) {
             const int *f = S->gates_flat.data() + 12 * g;
+            if (f[0] == BJ_GATE_POSEIDON2_FLATTENED) {
+                unsigned char path[8] = {0};
+                for (int b = 0; b < f[1]; b++) path[b] = (unsigned char)f[6 + b];
+                bj::launch_quotient_poseidon2_flattened(wit_lde.p, Ln, d_con_lde, Ln, (unsigned)f[1], path, a_gates + 2 * (size_t)aoff,
+                                                        Qe, t0, t1, st);
+            }
             if (f[0] == BJ_GATE_PROGRAM) {
                 unsigned char path[8] = {0};
                 for (int b = 0; b < f[1]; b++) path[b] = (unsigned char)f[6 + b];

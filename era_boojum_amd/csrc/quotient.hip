@@ -81,7 +81,7 @@ quotient_gates_kernel(const u64 *vars, size_t var_stride, const u64 *consts, siz
     for (int gi = 0; gi < gs.n_gates; gi++) {
         const GateDev &G = gs.g[gi];
         if (G.num_terms == 0) continue;
-        if (G.kind == 5) {   // op-list gate (seam S3): evaluated by gate_program_kernel, only its alpha powers are skipped here
+        if (G.kind >= 5) {   // op-list gate (seam S3) or the Poseidon2 flattened gate: evaluated by their own kernels, only the alpha powers are skipped here
             aoff += G.reps * G.num_terms;
             continue;
         }

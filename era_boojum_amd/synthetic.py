@@ -24,6 +24,7 @@ from . import field_np as F
 P = F.P
 
 GATE_CONSTANT_ALLOCATOR, GATE_FMA, GATE_REDUCTION4, GATE_NOP = 1, 2, 3, 4
+GATE_POSEIDON2_FLATTENED = 6   # the hand-written evaluator of Poseidon2FlattenedGate (csrc/gate_poseidon2.hip)
 GATE_PROGRAM = 5     # evaluated from an op list (seam S3): GateDesc.program is an era_boojum_amd.gate_program.GateProgram
 
 
@@ -68,7 +69,7 @@ def extended_gates(num_gp_vars=60, num_constant_cols=4):
     return g[:3] + extra + g[3:]
 
 
-def recursion_gates(num_gp_vars=130, num_constant_cols=8):
+def recursion_gates(num_gp_vars=130, num_constant_cols=8, poseidon2_as_op_list=False):
     """The evaluators over general-purpose columns of the golden proof's inner circuit (a recursion-layer circuit: 130
     general-purpose columns, 8 x 3 lookup columns, one boolean specialized column = the 155 variable columns of vk.json), in
     its evaluator order; everything but the SHA bench's four hand-written ones is an op list."""
@@ -77,7 +78,8 @@ def recursion_gates(num_gp_vars=130, num_constant_cols=8):
     return [
         GateDesc(GATE_CONSTANT_ALLOCATOR, "ConstantsAllocatorGate", 1, num_constant_cols, 1, min(num_constant_cols, v), 1, 1, 1, True),
         GateDesc(GATE_PROGRAM, "U8x4FMAGate", 2, 0, 26, v // 26, 26, 0, 2, True, program=GP.u8x4_fma_program()),
-        GateDesc(GATE_PROGRAM, "Poseidon2FlattenedGate", 7, 0, 130, 1, 130, 0, 118, True, program=GP.poseidon2_flattened_program()),
+        (GateDesc(GATE_PROGRAM, "Poseidon2FlattenedGate", 7, 0, 130, 1, 130, 0, 118, True, program=GP.poseidon2_flattened_program())
+         if poseidon2_as_op_list else GateDesc(GATE_POSEIDON2_FLATTENED, "Poseidon2FlattenedGate", 7, 0, 130, 1, 130, 0, 118, True)),
         GateDesc(GATE_PROGRAM, "DotProductGate<4>", 2, 0, 9, v // 9, 9, 0, 1, True, program=GP.dot_product4_program()),
         GateDesc(GATE_PROGRAM, "ZeroCheckGate", 2, 0, 3, v // 3, 3, 0, 2, True, program=GP.zero_check_program()),
         GateDesc(GATE_FMA, "FmaGateInBaseFieldWithoutConstant", 3, 2, 4, v // 4, 4, 0, 1, True),
@@ -89,11 +91,11 @@ def recursion_gates(num_gp_vars=130, num_constant_cols=8):
     ]
 
 
-def recursion_like_circuit(log_n, seed=1, table_bits=2):
+def recursion_like_circuit(log_n, seed=1, table_bits=2, poseidon2_as_op_list=False):
     """Random satisfiable circuit with the geometry and the gate set of the golden proof's inner circuit: 130 + 24 + 1
     variable columns, width-3 lookups, the Poseidon2 flattened gate (118 terms over 130 variables per row), quotient degree 8."""
     return sha_shaped_circuit(log_n, seed=seed, table_bits=table_bits, num_gp_vars=130, num_constant_cols=8, lookup_width=3,
-                              lookup_reps=8, num_public_inputs=2, boolean_columns=1, gates=recursion_gates(130, 8),
+                              lookup_reps=8, num_public_inputs=2, boolean_columns=1, gates=recursion_gates(130, 8, poseidon2_as_op_list),
                               mix=(0.04, 0.08, 0.12, 0.08, 0.08, 0.12, 0.08, 0.08, 0.08, 0.12), max_allowed_constraint_degree=8)
 
 
@@ -469,12 +471,16 @@ def check_satisfied(c: Circuit):
         elif g.kind == GATE_CONSTANT_ALLOCATOR:
             for r in range(g.reps):
                 assert not F.sub(var[r * g.var_stride], consts[d + r * g.const_stride])[m].any(), "ConstAlloc unsatisfied"
-        elif g.kind == GATE_PROGRAM and m.any():      # op-list gates: the program itself on the gate's rows
+        elif g.kind in (GATE_PROGRAM, GATE_POSEIDON2_FLATTENED) and m.any():      # op-list gates: the program itself on the gate's rows
             rows = np.flatnonzero(m)
+            prog = g.program
+            if prog is None:
+                from .gate_program import poseidon2_flattened_program
+                prog = poseidon2_flattened_program()
             for r in range(g.reps):
                 vcols = [var[r * g.var_stride + k][rows] for k in range(g.principal_width)]
                 ccols = [consts[k][rows] for k in range(d + r * g.const_stride, consts.shape[0])]
-                for t in g.program.evaluate_columns(vcols, ccols):
+                for t in prog.evaluate_columns(vcols, ccols):
                     assert not t.any(), "%s unsatisfied" % g.name
     assert sum(m.sum() for m in sel_rows.values()) == n, "selector paths must partition the rows"
     col = c.num_gp_vars + c.num_lookup_vars

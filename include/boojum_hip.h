@@ -249,7 +249,9 @@ typedef enum bj_gate_kind {
     BJ_GATE_FMA_NO_CONSTANT = 2,    /* q*a*b + l*c - d            src/cs/gates/fma_gate_without_constant.rs:96-126    */
     BJ_GATE_REDUCTION4 = 3,         /* sum_i c_i*v_i - r          src/cs/gates/reduction_gate.rs:103-126              */
     BJ_GATE_NOP = 4,                /* no terms                   src/cs/gates/nop_gate.rs:41                         */
-    BJ_GATE_PROGRAM = 5             /* any evaluator, given as the op list of seam S3 (bj_gate_program below)          */
+    BJ_GATE_PROGRAM = 5,            /* any evaluator, given as the op list of seam S3 (bj_gate_program below)          */
+    BJ_GATE_POSEIDON2_FLATTENED = 6 /* Poseidon2FlattenedGate<8,12,4>, 130 variables, 118 terms, one repetition per row:
+                                     * src/cs/gates/poseidon2.rs:165-410 (the gate of the recursion circuits), hand-written */
 } bj_gate_kind;
 
 /* Seam S3 — a gate as the reference's gpu_synthesizer describes it (GPUDataCapture::from_evaluator,

@@ -271,3 +271,16 @@ def test_circuit_of_the_golden_proofs_class_proves_and_verifies(fri_lde, cap):
     with pytest.raises(E.BoojumHipError, match="not satisfied"):
         gsetup.prove(variables=bad)
     gsetup.close()
+
+
+def test_hand_written_poseidon2_gate_gives_the_same_proof_as_its_op_list():
+    """BJ_GATE_POSEIDON2_FLATTENED (csrc/gate_poseidon2.hip) against the same gate through the op-list interpreter: the two
+    proofs of the same recursion-class circuit are identical bytes."""
+    a = S.recursion_like_circuit(10, seed=9)
+    b = S.recursion_like_circuit(10, seed=9, poseidon2_as_op_list=True)
+    assert [g.kind for g in a.gates][2] == 6 and [g.kind for g in b.gates][2] == 5 and np.array_equal(a.variables, b.variables)
+    sa, sb = E.ProverSetup(ctx(), a, 2, 32, 30), E.ProverSetup(ctx(), b, 2, 32, 30)
+    pa, _ = sa.prove()
+    pb, _ = sb.prove()
+    assert np.array_equal(pa, pb)
+    sa.close(); sb.close()
