@@ -358,29 +358,47 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
             m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
             shifts = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]
 
+            # all rows of the gate at once: the state is twelve arrays over the rows
+            cst = lambda v: np.uint64(int(v) % P)
+            fadd = lambda a, b: F.add(a, b)
+
+            def scaled_sum(cols, coefs):
+                acc = None
+                for a, k in zip(cols, coefs):
+                    t = a if k == 1 else F.mul(a, cst(k))
+                    acc = t if acc is None else F.add(acc, t)
+                return acc
+
             def ext(st):
-                blk = [[sum(m4[i][j] * st[4 * k + j] for j in range(4)) % P for i in range(4)] for k in range(3)]
-                sums = [(blk[0][i] + blk[1][i] + blk[2][i]) % P for i in range(4)]
-                return [(blk[k][i] + sums[i]) % P for k in range(3) for i in range(4)]
-            for row in range(lo, hi):
-                st = [int(x) for x in rng.integers(0, P, size=12, dtype=np.uint64)]
-                cells = list(st) + [0] * 12
-                st = ext(st)
-                for rnd in range(4):
-                    if rnd:
-                        cells += st
-                    st = ext([pow((x + rc[rnd][i]) % P, 7, P) for i, x in enumerate(st)])
-                for rnd in range(22):
-                    st[0] = (st[0] + rc[4 + rnd][0]) % P
-                    cells.append(st[0])
-                    st[0] = pow(st[0], 7, P)
-                    tot = sum(st) % P
-                    st = [(st[i] * (1 << shifts[i]) + tot) % P for i in range(12)]
-                for k in range(4):
+                blk = [[scaled_sum(st[4 * k: 4 * k + 4], m4[i]) for i in range(4)] for k in range(3)]
+                sums = [F.add(F.add(blk[0][i], blk[1][i]), blk[2][i]) for i in range(4)]
+                return [F.add(blk[k][i], sums[i]) for k in range(3) for i in range(4)]
+
+            def pow7(x):
+                x2 = F.mul(x, x)
+                return F.mul(F.mul(x2, x2), F.mul(x2, x))
+            st = [rand_f(m) for _ in range(12)]
+            cells = list(st) + [None] * 12
+            st = ext(st)
+            for rnd in range(4):
+                if rnd:
                     cells += st
-                    st = ext([pow((x + rc[26 + k][i]) % P, 7, P) for i, x in enumerate(st)])
-                cells[12:24] = st
-                variables[:130, row] = np.array(cells, dtype=np.uint64)
+                st = ext([pow7(F.add(x, np.full(m, cst(rc[rnd][i]), dtype=np.uint64))) for i, x in enumerate(st)])
+            for rnd in range(22):
+                st[0] = F.add(st[0], np.full(m, cst(rc[4 + rnd][0]), dtype=np.uint64))
+                cells.append(st[0])
+                st[0] = pow7(st[0])
+                tot = st[0]
+                for x in st[1:]:
+                    tot = F.add(tot, x)
+                st = [F.add(F.mul(st[i], cst(1 << shifts[i])), tot) for i in range(12)]
+            for k in range(4):
+                cells += st
+                st = ext([pow7(F.add(x, np.full(m, cst(rc[26 + k][i]), dtype=np.uint64))) for i, x in enumerate(st)])
+            cells[12:24] = st
+            assert len(cells) == 130
+            for k, col in enumerate(cells):
+                variables[k, rows] = col
         elif g.kind == GATE_REDUCTION4:
             cs = [rand_f(m) for _ in range(4)]
             for i in range(4):
