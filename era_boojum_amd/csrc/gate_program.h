@@ -13,7 +13,7 @@ struct DevProgram {
     gl::u64 *d_values = nullptr;
     DevRelation *d_rel = nullptr;
     uint32_t *d_writes = nullptr;
-    unsigned n_rel = 0, n_writes = 0;
+    unsigned n_rel = 0, n_writes = 0, n_tmp = 0;
     int upload(bj_ctx *ctx, const bj_gate_program *p);   // validates, packs and copies the program
     void release();
 };

@@ -65,10 +65,20 @@ struct ProgArgs {
     u64 *terms;          // raw terms (stand-alone mode)
 };
 
+// SLOTS > 0: the temporaries live in LDS as [slot][lane] (conflict-free, no HBM-backed scratch traffic: a private array
+// indexed by a run-time slot number goes to scratch memory, two loads and a store per recorded operation); after slot
+// renaming almost every evaluator needs <= 16 slots.  SLOTS == 0: the private array, for the few large programs.
+template <int SLOTS>
 __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
+    __shared__ u64 lds_tmp[SLOTS ? SLOTS : 1][256];
     const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= a.Q) return;
-    u64 tmp[MAX_TMP];
+    u64 priv[SLOTS ? 1 : MAX_TMP];
+    struct Tmp {     // tmp[idx] as an lvalue over either storage
+        u64 *p;
+        unsigned stride;
+        __device__ __forceinline__ u64 &operator[](u32 i) const { return p[(size_t)i * stride]; }
+    } tmp{SLOTS ? &lds_tmp[0][threadIdx.x] : priv, SLOTS ? 256u : 1u};
     auto fetch = [&](u32 packed, size_t vb, size_t cb) -> u64 {
         const u32 kind = packed >> 28, idx = packed & 0x0FFFFFFFu;
         switch (kind) {
@@ -151,6 +161,7 @@ int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     std::vector<u64> vals(p->num_values ? p->num_values : 1, 0);
     for (uint32_t i = 0; i < p->num_values; i++) vals[i] = gl::canon(p->values[i]);
     n_rel = p->num_relations;
+    n_tmp = p->num_temporaries;
     n_writes = p->num_writes;
     const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + wr.size() * 4 + 64;
     if (hipMalloc(&block, bytes) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "gate program: allocation failed");
@@ -180,7 +191,15 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
     a.reps = reps; a.rep_var_stride = rep_var_stride; a.rep_const_stride = rep_const_stride;
     a.alphas = d_alphas; a.Q = Q; a.out0 = d_out0; a.out1 = d_out1; a.terms = d_terms;
     if (!Q) return;
-    hipLaunchKernelGGL(gate_program_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
+    if (P.n_tmp <= 8)
+        hipLaunchKernelGGL(gate_program_kernel<8>, grid, block, 0, s, a);
+    else if (P.n_tmp <= 16)
+        hipLaunchKernelGGL(gate_program_kernel<16>, grid, block, 0, s, a);
+    else if (P.n_tmp <= 32)
+        hipLaunchKernelGGL(gate_program_kernel<32>, grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL(gate_program_kernel<0>, grid, block, 0, s, a);
 }
 
 }  // namespace bj
