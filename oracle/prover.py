@@ -82,6 +82,58 @@ def quotient(vars_q, consts_q, sigmas_q, z_q, partials_q, A_q, B_q, mult_q, tabl
     return out
 
 
+def _F():
+    from era_boojum_amd import field_np      # numpy Goldilocks vector arithmetic (host-side helper, not the HIP path)
+    return field_np
+
+
+def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec):
+    """sum over the op-list gates of selector * sum alpha * term on the quotient domain, from the programs' own semantics
+    (GateProgram.evaluate_columns: plain numpy field arithmetic).  General-purpose gates of kind >= 5 with their selector
+    path; gates over specialized columns without one, on their own columns after the lookup ones."""
+    F = _F()
+    Qn = vars_q.shape[1]
+    acc0, acc1 = np.zeros(Qn, dtype=np.uint64), np.zeros(Qn, dtype=np.uint64)
+
+    def program_of(g):
+        if getattr(g, "program", None) is not None:
+            return g.program
+        from era_boojum_amd.gate_program import poseidon2_flattened_program
+        assert g.name == "Poseidon2FlattenedGate"
+        return poseidon2_flattened_program()
+
+    def weighted(prog, vcols, ccols, alphas, aoff):
+        s0, s1 = np.zeros(Qn, dtype=np.uint64), np.zeros(Qn, dtype=np.uint64)
+        for term in prog.evaluate_columns(vcols, ccols):
+            a = alphas[aoff]
+            s0 = F.add(s0, F.mul(term, np.uint64(a[0])))
+            s1 = F.add(s1, F.mul(term, np.uint64(a[1])))
+            aoff += 1
+        return s0, s1, aoff
+    aoff = 0
+    for g in c.gates:
+        if g.kind < 5:
+            aoff += g.reps * g.num_terms
+            continue
+        prog, d = program_of(g), len(g.path)
+        sel = np.ones(Qn, dtype=np.uint64)
+        for b, bit in enumerate(g.path):
+            sel = F.mul(sel, con_q[b] if bit else F.sub(np.ones(Qn, dtype=np.uint64), con_q[b]))
+        for r in range(g.reps):
+            vcols = [vars_q[r * g.var_stride + k] for k in range(g.principal_width)]
+            ccols = [con_q[k] for k in range(d + r * g.const_stride, con_q.shape[0])]
+            s0, s1, aoff = weighted(prog, vcols, ccols, a_gates, aoff)
+            acc0, acc1 = F.add(acc0, F.mul(s0, sel)), F.add(acc1, F.mul(s1, sel))
+    col, aoff = c.num_gp_vars + c.lookup_reps * c.lookup_width, 0
+    for g in spec_gates:
+        for r in range(g.reps):
+            vcols = [vars_q[col + r * g.var_stride + k] for k in range(g.var_stride)]
+            s0, s1, aoff = weighted(g.program, vcols, [], a_spec, aoff)
+            acc0, acc1 = F.add(acc0, s0), F.add(acc1, s1)
+        col += g.reps * g.var_stride
+    return acc0, acc1
+
+
 def pow_seed(t):
     """256 / CHAR_BITS = 4 challenges, +1 because 4 is not a multiple of CHAR_BITS (prover.rs:2114-2119): 40 seed bytes."""
     return b"".join(int(t.challenge()).to_bytes(8, "little") for _ in range(5))
@@ -182,13 +234,17 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     # ---- round 3: quotient (prover.rs:560-1495)
     alpha = t.challenge_ext()
     n_lookup_terms = c.lookup_reps + 1 if has_lookup else 0
-    assert not getattr(c, "specialized_gates", None), "the oracle prover has no gates over specialized columns (checked by the verifier restatement and the golden-pinned identity instead)"
+    spec_gates = list(getattr(c, "specialized_gates", None) or [])
+    n_spec_terms = sum(g.reps * g.num_terms for g in spec_gates)
     n_gate_terms = sum(g.reps * g.num_terms for g in c.gates)
     n_chunks = (V + q - 1) // q
-    total_terms = n_lookup_terms + n_gate_terms + 1 + n_chunks          # prover.rs:599-606 (1 + 1 + n_partials)
-    alphas = [(1, 0)]
-    while len(alphas) < total_terms:
-        alphas.append(emul(alphas[-1], alpha))                          # materialize_powers_serial (utils.rs:31)
+    total_terms = n_lookup_terms + n_spec_terms + n_gate_terms + 1 + n_chunks   # lookup | specialized | general | L1 | chunks (prover.rs:599-625)
+    alphas_all = [(1, 0)]
+    while len(alphas_all) < total_terms:
+        alphas_all.append(emul(alphas_all[-1], alpha))                  # materialize_powers_serial (utils.rs:31)
+    a_spec = alphas_all[n_lookup_terms:n_lookup_terms + n_spec_terms]
+    a_gates = alphas_all[n_lookup_terms + n_spec_terms:n_lookup_terms + n_spec_terms + n_gate_terms]
+    alphas = alphas_all[:n_lookup_terms] + alphas_all[n_lookup_terms + n_spec_terms:]     # what the C quotient consumes
     sub = lambda lde: np.ascontiguousarray(lde[:, :q, :].reshape(lde.shape[0], Q))
     vars_q = sub(wit_lde[:V])
     mult_q = sub(wit_lde[V:V + 1]).reshape(-1) if has_lookup else np.zeros(0, dtype=np.uint64)
@@ -201,6 +257,14 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     B_q = s2_q[2 + 2 * n_partials + 2 * c.lookup_reps:] if has_lookup else np.zeros(0, dtype=np.uint64)
     T = quotient(vars_q, con_q, sig_q, np.ascontiguousarray(z_q), np.ascontiguousarray(part_q), np.ascontiguousarray(A_q),
                  np.ascontiguousarray(B_q), mult_q, tab_q, c, log_q, alphas, beta, gamma, lbeta, lgamma, threads)
+    if spec_gates or any(g.kind >= 5 for g in c.gates):
+        e0, e1 = _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec)
+        for cs in range(q):   # divide by x^n - 1, constant on a coset: x^n = (7 * w_{nL}^{bitrev_L(cs)})^n
+            xn = pow(7 * pow(O.omega(log_n + log_L), O.bitrev(cs, log_L), P) % P, n, P)
+            inv = np.uint64(O.inv((xn - 1) % P))
+            sl = slice(cs * n, (cs + 1) * n)
+            T[0][sl] = _F().add(T[0][sl], _F().mul(e0[sl], inv))
+            T[1][sl] = _F().add(T[1][sl], _F().mul(e1[sl], inv))
     # flatten_presumably_bitreversed == bit-reversal of the size-qn array; iNTT on coset g (prover.rs:1405-1422)
     qmono = O.ifft_batch(np.stack([O.bitreverse(T[0]), O.bitreverse(T[1])]), 7, threads)
     assert qmono[0][-1] == 0 and qmono[1][-1] == 0, "unsatisfied (prover.rs:1425-1438)"

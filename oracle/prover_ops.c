@@ -136,6 +136,10 @@ void orc_quotient(const uint64_t *vars, size_t V, const uint64_t *consts, size_t
         for (size_t g = 0; g < n_gates; g++) {
             const orc_gate *G = &gates[g];
             if (G->num_terms == 0) continue;
+            if (G->kind >= 5) {   /* op-list / Poseidon2 flattened gates: added by oracle/prover.py from the program's own semantics */
+                aoff += (size_t)G->reps * G->num_terms;
+                continue;
+            }
             gl_t sel = 1;
             for (int b = 0; b < G->path_len; b++) {
                 gl_t c = consts[(size_t)b * Q + I];

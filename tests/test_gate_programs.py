@@ -98,3 +98,22 @@ def test_poseidon2_flattened_gate_equals_the_golden_pinned_evaluator():
     for _ in range(3):
         v = rv(130)
         assert prog.evaluate(v, []) == [t[0] for t in OG.ev_poseidon2_flattened([(x, 0) for x in v], [])]
+
+
+def test_oracle_prover_handles_op_list_and_specialized_gates():
+    """The CPU oracle prover on a circuit of the golden proof's class (op-list gates, the Poseidon2 flattened gate, a
+    boolean specialized column): its proof is accepted by the verifier restatement, a broken Poseidon2 row is caught."""
+    import numpy as np
+    from era_boojum_amd import synthetic as S
+    from oracle import prover as OP, verifier as OV
+    c = S.recursion_like_circuit(8, seed=3)
+    st = OP.Setup(c, 2, 8, threads=4)
+    assert OV.verify(OV.VerificationKey(c, st.cap, 2, 8), OP.prove(c, st, 2, 8, security_level=20, threads=4))
+    g = c.gates[2]
+    m = np.ones(c.n, dtype=bool)
+    for i, bit in enumerate(g.path):
+        m &= c.constants[i] == (1 if bit else 0)
+    row = int(np.flatnonzero(m)[0])
+    c.variables[50, row] = (int(c.variables[50, row]) + 1) % P
+    with pytest.raises(AssertionError, match="unsatisfied"):
+        OP.prove(c, st, 2, 8, security_level=20, threads=4)

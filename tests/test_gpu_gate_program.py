@@ -284,3 +284,27 @@ def test_hand_written_poseidon2_gate_gives_the_same_proof_as_its_op_list():
     pb, _ = sb.prove()
     assert np.array_equal(pa, pb)
     sa.close(); sb.close()
+
+
+@pytest.mark.parametrize("make,fri_lde,cap", [
+    (lambda: S.recursion_like_circuit(9, seed=11), 2, 32),                                   # the golden proof's class and parameters
+    (lambda: S.recursion_like_circuit(8, seed=12, poseidon2_as_op_list=True), 8, 16),
+    (lambda: S.sha_shaped_circuit(9, seed=13, table_bits=2, extended=True), 8, 16),          # op-list gates with two terms / constants
+    (lambda: S.sha_shaped_circuit(9, seed=14, table_bits=2, boolean_columns=3), 4, 8),       # gates over specialized columns
+])
+def test_hip_proof_equals_oracle_proof_with_op_list_and_specialized_gates(make, fri_lde, cap):
+    """Identical proofs, not only accepted ones: the oracle prover adds op-list gates (general-purpose and specialized
+    placement) and the Poseidon2 flattened gate from the programs' numpy semantics; the HIP prover runs the interpreter
+    kernel / the hand-written evaluator.  Every cap, opening, FRI layer and query must agree."""
+    from test_gpu_prover import _compare
+    from oracle import verifier as OV
+    c = make()
+    osetup = OP.Setup(c, fri_lde, cap, threads=8)
+    po = OP.prove(c, osetup, fri_lde, cap, security_level=30, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, fri_lde, cap, 30)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=30)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), fri_lde, cap), pg)
+    gsetup.close()
