@@ -47,6 +47,7 @@ _SIGNATURES = {
     "bj_barycentric_eval_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_deep_quotient_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]),
+    "bj_gate_program_generated": (C.c_int, [C.c_void_p]),
     "bj_gate_program_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint,
                                        C.c_uint, C.c_size_t, C.c_void_p]),
     "bj_setup_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libboojum_hip.so")
-SOURCES = ["abi.hip", "ntt.hip", "ntt_r16.hip", "poseidon2.hip", "blake2s.hip", "keccak.hip", "fri.hip", "fri_prover.hip", "openings.hip", "openings_abi.hip", "stage2.hip", "quotient.hip", "gate_program.hip", "gate_poseidon2.hip", "prover.hip"]
+SOURCES = ["abi.hip", "ntt.hip", "ntt_r16.hip", "poseidon2.hip", "blake2s.hip", "keccak.hip", "fri.hip", "fri_prover.hip", "openings.hip", "openings_abi.hip", "stage2.hip", "quotient.hip", "gate_program.hip", "gate_aot.hip", "gate_poseidon2.hip", "prover.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -37,6 +37,8 @@ def _deps():
 
 def build(force=False, verbose=False):
     build_synth(force)
+    from . import gate_codegen          # csrc/gate_aot.hip: straight-line kernels generated from the known gate op lists
+    gate_codegen.write()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(p) for p in _deps()):
         return LIB
     objs = []

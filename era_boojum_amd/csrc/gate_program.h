@@ -14,6 +14,7 @@ struct DevProgram {
     DevRelation *d_rel = nullptr;
     uint32_t *d_writes = nullptr;
     unsigned n_rel = 0, n_writes = 0, n_tmp = 0;
+    uint64_t hash = 0;        // of the program's content: selects a generated kernel when one exists
     int upload(bj_ctx *ctx, const bj_gate_program *p);   // validates, packs and copies the program
     void release();
 };

@@ -5,6 +5,8 @@
 // temporaries live in a per-lane array.  Contribution to the quotient:  T += selector * sum_rep sum_t alpha * term.
 #include "ctx.h"
 #include "gate_program.h"
+#include "gate_program_dev.h"
+#include <cstdlib>
 
 using gl::u64;
 using gl::u32;
@@ -14,56 +16,7 @@ namespace bj {
 namespace {
 constexpr int MAX_TMP = BJ_GATE_PROGRAM_MAX_TEMPORARIES;
 
-struct Acc160g {   // same lazy accumulator as quotient.hip
-    u32 w[5];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int i = 0; i < 5; i++) w[i] = 0;
-    }
-    __device__ __forceinline__ void fma(u64 a, u64 b) {
-        u32 hh, hl;
-        u64 lo;
-        gl::mul_limbs(a, b, hh, hl, lo);
-        u32 c;
-        w[0] = __builtin_addc(w[0], gl::lo32(lo), 0u, &c);
-        w[1] = __builtin_addc(w[1], gl::hi32(lo), c, &c);
-        w[2] = __builtin_addc(w[2], hl, c, &c);
-        w[3] = __builtin_addc(w[3], hh, c, &c);
-        w[4] += c;
-    }
-    __device__ __forceinline__ u64 reduce() const {
-        u64 r = gl::reduce_limbs(w[3], w[2], gl::pack(w[0], w[1]));
-        return gl::sub(r, (u64)w[4] << 32);
-    }
-};
-
-__device__ inline u64 inv_pow(u64 x) {   // x^(p-2); inverse of 0 is 0 like the reference's batch inversion never sees
-    u64 r = 1, b = x;
-    u64 e = gl::P - 2;
-    for (int i = 0; i < 64; i++) {
-        if ((e >> i) & 1) r = gl::mul(r, b);
-        b = gl::sqr(b);
-    }
-    return r;
-}
-
-struct ProgArgs {
-    const u64 *vars;
-    size_t var_stride;
-    const u64 *consts;
-    size_t const_stride;
-    const DevRelation *rel;
-    const u64 *values;
-    const u32 *writes;   // kind << 28 | index
-    unsigned n_rel, n_writes;
-    unsigned path_len;
-    unsigned char path[8];
-    unsigned reps, rep_var_stride, rep_const_stride;
-    const u64 *alphas;   // [reps * n_writes][2] for this gate, or nullptr
-    size_t Q;
-    u64 *out0, *out1;    // accumulated into (quotient mode)
-    u64 *terms;          // raw terms (stand-alone mode)
-};
+using namespace gpdev;
 
 // SLOTS > 0: the temporaries live in LDS as [slot][lane] (conflict-free, no HBM-backed scratch traffic: a private array
 // indexed by a run-time slot number goes to scratch memory, two loads and a store per recorded operation); after slot
@@ -130,6 +83,31 @@ __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
 }
 }  // namespace
 
+// FNV-1a over the program as 32-bit words: the key of the generated kernels (era_boojum_amd/gate_codegen.py walks the same way)
+uint64_t gate_program_hash(const bj_gate_program *p) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    auto mix = [&](uint32_t w) {
+        for (int b = 0; b < 4; b++) {
+            h ^= (w >> (8 * b)) & 0xFFu;
+            h *= 0x100000001b3ULL;
+        }
+    };
+    for (uint32_t i = 0; i < p->num_relations; i++) {
+        const bj_gate_relation &R = p->relations[i];
+        const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
+        mix(R.op); mix(R.dst); mix(R.a.kind); mix(R.a.index);
+        mix(binary ? R.b.kind : 0u); mix(binary ? R.b.index : 0u);
+    }
+    mix(p->num_values);
+    for (uint32_t i = 0; i < p->num_values; i++) {
+        const u64 v = gl::canon(p->values[i]);
+        mix((uint32_t)v); mix((uint32_t)(v >> 32));
+    }
+    for (uint32_t t = 0; t < p->num_writes; t++) { mix(p->writes[t].kind); mix(p->writes[t].index); }
+    mix(p->num_temporaries);
+    return h;
+}
+
 int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     if (!p || !p->relations || !p->writes || p->num_writes == 0)
         return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: null / empty program");
@@ -162,6 +140,7 @@ int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     for (uint32_t i = 0; i < p->num_values; i++) vals[i] = gl::canon(p->values[i]);
     n_rel = p->num_relations;
     n_tmp = p->num_temporaries;
+    hash = gate_program_hash(p);
     n_writes = p->num_writes;
     const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + wr.size() * 4 + 64;
     if (hipMalloc(&block, bytes) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "gate program: allocation failed");
@@ -192,6 +171,8 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
     a.alphas = d_alphas; a.Q = Q; a.out0 = d_out0; a.out1 = d_out1; a.terms = d_terms;
     if (!Q) return;
     const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
+    static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr;
+    if (!no_aot && launch_gate_aot(P.hash, a, grid.x, s)) return;   // a generated straight-line kernel exists for this program
     if (P.n_tmp <= 8)
         hipLaunchKernelGGL(gate_program_kernel<8>, grid, block, 0, s, a);
     else if (P.n_tmp <= 16)
@@ -203,6 +184,11 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
 }
 
 }  // namespace bj
+
+extern "C" int bj_gate_program_generated(const bj_gate_program *program) {
+    if (!program || !program->relations || !program->writes) return 0;
+    return bj::gate_aot_known(bj::gate_program_hash(program)) ? 1 : 0;
+}
 
 extern "C" int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint64_t *d_vars, size_t var_stride,
                                     const uint64_t *d_consts, size_t const_stride, unsigned num_repetitions,

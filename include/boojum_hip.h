@@ -295,6 +295,10 @@ typedef struct bj_gate_desc {
     const bj_gate_program *program; /* BJ_GATE_PROGRAM only, NULL otherwise */
 } bj_gate_desc;
 
+/* 1 if the library carries a generated straight-line kernel for exactly this program (era_boojum_amd/gate_codegen.py emits one
+ * for every evaluator it knows, keyed by a hash of the op list), 0 if it will run in the interpreter.  Host-only, no GPU. */
+int bj_gate_program_generated(const bj_gate_program *program);
+
 /* Evaluate a gate program at n_points points (stand-alone, for parity tests of S3): d_terms[(rep*num_writes + t)*n_points + i]
  * = term t of repetition rep at point i.  d_vars / d_consts: columns with the given strides, constants WITHOUT a selector
  * prefix. */

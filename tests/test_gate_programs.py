@@ -117,3 +117,22 @@ def test_oracle_prover_handles_op_list_and_specialized_gates():
     c.variables[50, row] = (int(c.variables[50, row]) + 1) % P
     with pytest.raises(AssertionError, match="unsatisfied"):
         OP.prove(c, st, 2, 8, security_level=20, threads=4)
+
+
+def test_generated_kernels_cover_the_known_programs_and_the_committed_file_is_current():
+    """csrc/gate_aot.hip is what gate_codegen.generate() emits today, and the library recognises exactly the known programs by
+    their content hash (computed in python by gate_codegen.program_hash and in C++ by DevProgram::upload — the same walk)."""
+    import ctypes as C
+    import os
+    import era_boojum_amd as E
+    from era_boojum_amd import gate_codegen as GC
+    path = os.path.join(os.path.dirname(os.path.abspath(GC.__file__)), "csrc", "gate_aot.hip")
+    assert open(path).read() == GC.generate(), "run `python -m era_boojum_amd.gate_codegen` and rebuild"
+    lib = E.load_library()
+    for name, prog in GC.known_programs().items():
+        assert lib.bj_gate_program_generated(C.byref(prog.struct)) == 1, name
+    assert lib.bj_gate_program_generated(C.byref(G.matrix_multiplication_program(MATRIX).struct)) == 0     # host-chosen matrix
+    assert lib.bj_gate_program_generated(C.byref(G.poseidon2_flattened_program().struct)) == 0            # has its own kind
+    b = G.GateProgramBuilder()
+    b.push(b.var(0) * b.var(1) - b.var(2) + 5)
+    assert lib.bj_gate_program_generated(C.byref(b.build().struct)) == 0                                   # a host's own gate

@@ -308,3 +308,24 @@ def test_hip_proof_equals_oracle_proof_with_op_list_and_specialized_gates(make, 
     _compare(pg, po)
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), fri_lde, cap), pg)
     gsetup.close()
+
+
+def test_generated_kernels_and_interpreter_give_the_same_proof(tmp_path):
+    """The straight-line kernels generated from the op lists (csrc/gate_aot.hip, the default) against the interpreter
+    (BJ_GATE_NO_AOT=1, read once per process: a child process proves the same circuit) — identical proof bytes."""
+    import os
+    import subprocess
+    import sys
+    c = S.sha_shaped_circuit(9, seed=41, table_bits=2, extended=True)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    mine, _ = gsetup.prove()
+    gsetup.close()
+    out = os.path.join(str(tmp_path), "proof.npy")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; torch.cuda.init();"
+            "import era_boojum_amd as E; from era_boojum_amd import synthetic as S;"
+            "c = S.sha_shaped_circuit(9, seed=41, table_bits=2, extended=True); s = E.ProverSetup(E.Context(0), c, 8, 16, 30);"
+            "np.save(%r, s.prove()[0])") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                           os.path.dirname(os.path.abspath(__file__)), out)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BJ_GATE_NO_AOT="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(out), mine)
