@@ -32,6 +32,7 @@ _SIGNATURES = {
     "bj_trace_to_lde_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
     "bj_bitreverse_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t]),
     "bj_canonicalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bj_field_op_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_ntt_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64]),
     "bj_intt_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64]),
     "bj_merkle_tree_digests": (C.c_size_t, [C.c_size_t, C.c_size_t]),
@@ -228,6 +229,24 @@ class Context:
 
     def canonicalize(self, d, n):
         self._check(self._lib.bj_canonicalize(self._h, d, n))
+
+    FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_lazy": 3, "square": 4, "inverse": 5, "ext2_mul": 6}
+
+    def field_op(self, op, a, b=None):
+        """bj_field_op_batch on host arrays (uploads, runs, downloads): elementwise Goldilocks / F_p^2 operators."""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        n = a.size // 2 if op == "ext2_mul" else a.size
+        da = self.upload(a)
+        db = self.upload(np.ascontiguousarray(b, dtype=np.uint64)) if b is not None else None
+        do = self.malloc(a.nbytes)
+        try:
+            self._check(self._lib.bj_field_op_batch(self._h, self.FIELD_OPS[op], C.c_void_p(da), C.c_void_p(db) if db else None,
+                                                    C.c_void_p(do), n))
+            return self.d2h(do, a.shape)
+        finally:
+            for p in (da, db, do):
+                if p:
+                    self.free(p)
 
     # -- host convenience
     def ntt_forward_host(self, arr, coset=1):

@@ -35,6 +35,24 @@ def _deps():
     return out
 
 
+def build_variant(out_path, extra_flags):
+    """Tuning experiments: the same library built with extra -D flags into another file (BOOJUM_HIP_LIB selects it at load)."""
+    bdir = os.path.join(HERE, "build", "variant_" + os.path.basename(out_path))
+    os.makedirs(bdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([HIPCC] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj],
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path] + objs)
+    return out_path
+
+
 def build(force=False, verbose=False):
     build_synth(force)
     from . import gate_codegen          # csrc/gate_aot.hip: straight-line kernels generated from the known gate op lists
@@ -63,4 +81,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:      # python -m era_boojum_amd.build --variant out.so -DFOO -DBAR
+        i = sys.argv.index("--variant")
+        print(build_variant(os.path.abspath(sys.argv[i + 1]), sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -395,6 +395,17 @@ int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsi
     return BJ_OK;
 }
 
+int bj_field_op_batch(bj_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n) {
+    if (int rc = bind(ctx)) return rc;
+    if (n == 0) return BJ_OK;
+    if (op < BJ_FIELD_ADD || op > BJ_FIELD_EXT2_MUL) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_field_op_batch: unknown operator");
+    const bool unary = op == BJ_FIELD_SQUARE || op == BJ_FIELD_INVERSE;
+    if (!d_a || !d_out || (!unary && !d_b)) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_field_op_batch: null device pointer");
+    bj::launch_field_op(op, d_a, unary ? nullptr : d_b, d_out, n, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
 int bj_canonicalize(bj_ctx *ctx, uint64_t *d_data, size_t n) {
     if (int rc = bind(ctx)) return rc;
     if (n == 0) return BJ_OK;

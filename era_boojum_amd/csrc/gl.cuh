@@ -147,11 +147,69 @@ __host__ __device__ __forceinline__ void mul_limbs(u64 a, u64 b, u32 &hi_hi, u32
 #endif
 }
 
-__host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+// any u64 x any u64 -> "weak" residue (some u64 congruent to a*b mod p, not necessarily < p), 8 half-rate + 4 full-rate VALU
+// instructions (the limb-assembly + canonical reduction above is 14 + 3 and needs six carry links):
+//   T = a0*b0;  X = a1*b0 + (a0*b1 + T.hi)  [carry cm, weight 2^96];  H = a1*b1 + X.hi       -- every addition rides on a
+//   multiply-add, so   a*b = (T.lo | X.lo << 32) + H * 2^64 + cm * 2^96   exactly, with H < 2^64;
+//   2^64 = EPS, 2^96 = -1 (mod p):   a*b == lo + H.lo * EPS - (H.hi + cm)
+//   R = lo + H.lo*EPS mod 2^64 (carry c, ONE multiply-add);  D = R - H.hi - cm mod 2^64 (borrow b; cm enters as the borrow-in)
+//   result = D + c*EPS mod 2^64 (one more multiply-add on the 0/1 carry).  Why that is right:
+//     b = 0: c = 1 means R < 2^64 - 2^33 + 1, so D + EPS cannot wrap;
+//     b = 1: D >= 2^64 - 2^32 + 1 = p (H.hi + cm <= 2^32 - 1); with c = 1 the wrap of D + EPS cancels the borrow;
+//            with c = 0 the value is D - EPS (no second borrow as D >= p).  That last case needs R < 2^32: probability
+//            2^-32 per product, so it is a wave-uniform branch around three instructions, not predicated code.
+// Temporaries are fixed physical registers (clobbers): the sequence writes halves of 64-bit pairs, which operands allocated by
+// the compiler cannot express (no sub-register modifier for inline-asm operands on this target).  The s_nop covers the 2 wait
+// states gfx950 needs between a VALU write of an SGPR pair and a VALU read of it (the compiler cannot see inside the string).
+__device__ __forceinline__ u64 mul_weak(u64 a, u64 b) {
+    u64 out, cm, c;
+    asm("v_mad_u64_u32 v[48:49], vcc, %[a0], %[b0], 0\n\t"
+        "v_mov_b32 v51, 0\n\t"
+        "v_mov_b32 v50, v49\n\t"
+        "v_mad_u64_u32 v[50:51], vcc, %[a0], %[b1], v[50:51]\n\t"
+        "v_mad_u64_u32 v[50:51], %[cm], %[a1], %[b0], v[50:51]\n\t"
+        "v_mov_b32 v53, 0\n\t"
+        "v_mov_b32 v52, v51\n\t"
+        "v_mad_u64_u32 v[52:53], vcc, %[a1], %[b1], v[52:53]\n\t"
+        "v_mov_b32 v49, v50\n\t"
+        "v_mad_u64_u32 v[50:51], %[c], v52, -1, v[48:49]\n\t"
+        "v_subb_co_u32 v50, vcc, v50, v53, %[cm]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32 v52, 0, 1, %[c]\n\t"
+        "v_subb_co_u32 v51, vcc, v51, 0, vcc\n\t"
+        "s_cbranch_vccz .Lglmw%=\n\t"
+        "s_andn2_b64 vcc, vcc, %[c]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 v53, 0, -1, vcc\n\t"
+        "v_sub_co_u32 v50, vcc, v50, v53\n\t"
+        "s_nop 1\n\t"
+        "v_subbrev_co_u32 v51, vcc, 0, v51, vcc\n"
+        ".Lglmw%=:\n\t"
+        "v_mad_u64_u32 %[out], vcc, v52, -1, v[50:51]"
+        : [out] "=&v"(out), [cm] "=&s"(cm), [c] "=&s"(c)
+        : [a0] "v"(lo32(a)), [a1] "v"(hi32(a)), [b0] "v"(lo32(b)), [b1] "v"(hi32(b))
+        : "vcc", "v48", "v49", "v50", "v51", "v52", "v53");
+    return out;
+}
+#else
+__host__ __forceinline__ u64 mul_weak(u64 a, u64 b) {   // host pass of the kernels' translation units: any representative will do
     u32 hi_hi, hi_lo;
     u64 lo;
     mul_limbs(a, b, hi_hi, hi_lo, lo);
     return reduce_limbs(hi_hi, hi_lo, lo);
+}
+#endif
+
+__host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BJ_GL_MUL_LIMBS)
+    return canon(mul_weak(a, b));
+#else
+    u32 hi_hi, hi_lo;
+    u64 lo;
+    mul_limbs(a, b, hi_hi, hi_lo, lo);
+    return reduce_limbs(hi_hi, hi_lo, lo);
+#endif
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 

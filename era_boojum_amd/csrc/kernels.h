@@ -16,6 +16,7 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
 void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n_cols, size_t in_col_stride,
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s);
 void launch_canonicalize(u64 *d, size_t n, hipStream_t s);
+void launch_field_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n, hipStream_t s);
 
 // ntt_r16.hip (register-radix-16 passes)
 void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n,

@@ -399,4 +399,34 @@ void launch_canonicalize(u64 *d, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s, d, n);
 }
 
+// elementwise field operators on arbitrary u64 inputs (row a1/a2 of SURVEY §8 at operator level; field/goldilocks/mod.rs:188-255,
+// field/traits/field.rs:407-512); op: 0 add, 1 sub, 2 mul, 3 mul through the weak (lazy) product of the hash kernels,
+// 4 square, 5 inverse (0 -> 0), 6 F_p^2 multiplication on (a0,a1) x (b0,b1) with the second halves at +n
+__global__ void field_op_kernel(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == 6) {
+        gl::e2 x = {gl::canon(a[i]), gl::canon(a[n + i])}, y = {gl::canon(b[i]), gl::canon(b[n + i])};
+        gl::e2 r = gl::e2_mul(x, y);
+        out[i] = r.c0;
+        out[n + i] = r.c1;
+        return;
+    }
+    const u64 x = a[i], y = b ? b[i] : 0;
+    u64 r;
+    switch (op) {
+    case 0: r = gl::add(gl::canon(x), gl::canon(y)); break;
+    case 1: r = gl::sub(gl::canon(x), gl::canon(y)); break;
+    case 2: r = gl::mul(x, y); break;
+    case 3: r = gl::canon(gl::mul_weak(x, y)); break;
+    case 4: r = gl::sqr(x); break;
+    default: r = gl::inv(gl::canon(x)); break;
+    }
+    out[i] = r;
+}
+void launch_field_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, a, b, out, n);
+}
+
 }  // namespace bj

@@ -93,6 +93,9 @@ __device__ __forceinline__ u64 w3_reduce(W3 a) {
 //   c only: true value = R + 2^64 = R + EPS (R < 2^64 - 2^33, no second carry);  b only: R - EPS (R > 2^64 - 2^32);
 //   both: the wrap and the borrow cancel.  So W = R + (c ? EPS : 0) - (b ? EPS : 0) mod 2^64 in every case.
 __device__ __forceinline__ u64 mulw(u64 a, u64 b) {
+#if !defined(BJ_P2_MULW_LIMBS)
+    return gl::mul_weak(a, b);   // chained multiply-adds, 12 instructions (gl.cuh)
+#else
     u32 hh, hl, e;
     u64 lo;
     gl::mul_limbs(a, b, hh, hl, lo);
@@ -109,6 +112,7 @@ __device__ __forceinline__ u64 mulw(u64 a, u64 b) {
         : [r0] "v"(gl::lo32(r)), [r1] "v"(gl::hi32(r)), [hh] "v"(hh)
         : "vcc");
     return gl::pack(d0, d1) + (u64)e - (u64)f;
+#endif
 }
 // weak + canonical constant -> weak: "+EPS" on carry; the wrapped sum is < rc < p, so adding EPS cannot carry again
 __device__ __forceinline__ u64 addw_rc(u64 x, u64 rc) {

@@ -110,6 +110,14 @@ int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsi
 /* Reduce every element to its canonical residue (what the reference does on serialisation, goldilocks/mod.rs:98-107). */
 int bj_canonicalize(bj_ctx *ctx, uint64_t *d_data, size_t n);
 
+/* Elementwise field operators over n elements (n pairs for BJ_FIELD_EXT2_MUL, second halves at +n): GoldilocksField add / sub /
+ * mul / square / inverse (src/field/goldilocks/mod.rs:188-255, 294-360; inverse of 0 is 0 here, the reference returns None)
+ * and the F_p^2 product (src/field/traits/field.rs:407-426).  Inputs may be any u64, outputs are canonical.  BJ_FIELD_MUL_LAZY
+ * is the same product through the non-canonical ("weak") multiplication the hash / NTT kernels use internally. */
+enum { BJ_FIELD_ADD = 0, BJ_FIELD_SUB = 1, BJ_FIELD_MUL = 2, BJ_FIELD_MUL_LAZY = 3, BJ_FIELD_SQUARE = 4, BJ_FIELD_INVERSE = 5,
+       BJ_FIELD_EXT2_MUL = 6 };
+int bj_field_op_batch(bj_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
+
 /* Host-memory convenience for single-polynomial plumbing (what a Rust `impl PrimeFieldLikeVectorized` would call);
  * synchronous, includes the PCIe copies. */
 int bj_ntt_forward_host(bj_ctx *ctx, uint64_t *h_inout, unsigned log_n, unsigned n_cols, uint64_t coset);

@@ -1,0 +1,87 @@
+"""-m gpu parity, SURVEY §8 rows a1/a2 at operator level: bj_field_op_batch (GoldilocksField add / sub / mul / square / inverse,
+F_p^2 product; src/field/goldilocks/mod.rs:188-255, 294-360, src/field/traits/field.rs:407-512) against Python integers —
+including the operand pairs that take the rare (2^-32) branches of the device multiplication."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import ctx, rand_gl
+
+pytestmark = pytest.mark.gpu
+P = (1 << 64) - (1 << 32) + 1
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+SPECIALS = [0, 1, 2, 7, (1 << 16), (1 << 32) - 1, 1 << 32, (1 << 32) + 1, (1 << 48), (1 << 48) - 1, P - 2, P - 1, P, P + 1,
+            (1 << 64) - (1 << 32), (1 << 64) - 2, (1 << 64) - 1, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF,
+            0xFFFFFFFE00000001, 0x8000000080000000, 0x00000001FFFFFFFF]
+
+
+def _pairs():
+    rng = np.random.default_rng(5)
+    a = [x for x in SPECIALS for _ in SPECIALS]
+    b = [y for _ in SPECIALS for y in SPECIALS]
+    # a * b = k * 2^96 = -k: the reduction's subtraction borrows with no carry before it; powers of two in every position
+    for i in range(0, 64, 3):
+        for j in range(0, 64, 5):
+            for k in (1, 3, 0xFFFF):
+                a.append((1 << i) % (1 << 64))
+                b.append((k << j) % (1 << 64))
+    with open(os.path.join(HERE, "golden", "gl_mul_rare.json")) as f:
+        for v in json.load(f)["vectors"]:
+            a.append(v["a"])
+            b.append(v["b"])
+            assert v["a"] * v["b"] % P == v["product"]
+    ra = rand_gl(rng, (1 << 16,), noncanonical=True)
+    rb = rand_gl(rng, (1 << 16,), noncanonical=True)
+    a = np.concatenate([np.array(a, dtype=np.uint64), ra])
+    b = np.concatenate([np.array(b, dtype=np.uint64), rb])
+    return a, b
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "mul_lazy", "square"])
+def test_field_operator_matches_python_integers(op):
+    a, b = _pairs()
+    got = ctx().field_op(op, a, None if op == "square" else b)
+    fn = {"add": lambda x, y: (x + y) % P, "sub": lambda x, y: (x - y) % P, "mul": lambda x, y: x * y % P,
+          "mul_lazy": lambda x, y: x * y % P, "square": lambda x, y: x * x % P}[op]
+    want = np.array([fn(int(x), int(y)) for x, y in zip(a, b)], dtype=np.uint64)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "first mismatch at %d: a=%d b=%d got=%d want=%d" % (bad[0], a[bad[0]], b[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_rare_branch_vectors_on_a_lone_wave_and_on_a_full_grid():
+    """The wave-uniform rare branch must work whether one lane of one wave takes it or every lane does."""
+    with open(os.path.join(HERE, "golden", "gl_mul_rare.json")) as f:
+        vec = json.load(f)["vectors"]
+    for n in (1, 63, 64, 65, 1 << 14):
+        a = np.array([vec[i % len(vec)]["a"] for i in range(n)], dtype=np.uint64)
+        b = np.array([vec[i % len(vec)]["b"] for i in range(n)], dtype=np.uint64)
+        want = np.array([vec[i % len(vec)]["product"] for i in range(n)], dtype=np.uint64)
+        for op in ("mul", "mul_lazy"):
+            assert np.array_equal(ctx().field_op(op, a, b), want), (op, n)
+    # one rare pair inside an otherwise random wave
+    rng = np.random.default_rng(9)
+    a = rand_gl(rng, (4096,))
+    b = rand_gl(rng, (4096,))
+    for k, v in enumerate(vec):
+        a[37 + 64 * k] = v["a"]
+        b[37 + 64 * k] = v["b"]
+    want = np.array([int(x) * int(y) % P for x, y in zip(a, b)], dtype=np.uint64)
+    assert np.array_equal(ctx().field_op("mul", a, b), want)
+
+
+def test_inverse_and_extension_product():
+    rng = np.random.default_rng(6)
+    a = rand_gl(rng, (2048,), noncanonical=True)
+    a[:4] = [0, 1, P - 1, P]
+    got = ctx().field_op("inverse", a)
+    want = np.array([pow(int(x) % P, P - 2, P) for x in a], dtype=np.uint64)
+    assert np.array_equal(got, want)
+    x = rand_gl(rng, (2, 1024), noncanonical=True)
+    y = rand_gl(rng, (2, 1024), noncanonical=True)
+    got = ctx().field_op("ext2_mul", x, y)
+    w0 = [(int(p) * int(r) + 7 * int(q) * int(s)) % P for p, q, r, s in zip(x[0], x[1], y[0], y[1])]
+    w1 = [(int(p) * int(s) + int(q) * int(r)) % P for p, q, r, s in zip(x[0], x[1], y[0], y[1])]
+    assert np.array_equal(got, np.array([w0, w1], dtype=np.uint64))
