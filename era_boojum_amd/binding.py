@@ -48,6 +48,18 @@ _SIGNATURES = {
     "bj_barycentric_eval_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_deep_quotient_accumulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_int]),
+    "bj_copy_perm_stage2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint,
+                                      C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_lookup_polys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint,
+                                  C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_quotient_gates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p,
+                                    C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "bj_quotient_lookup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p]),
+    "bj_quotient_copy_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "bj_gate_program_generated": (C.c_int, [C.c_void_p]),
     "bj_gate_program_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint,
                                        C.c_uint, C.c_size_t, C.c_void_p]),
@@ -229,6 +241,44 @@ class Context:
 
     def canonicalize(self, d, n):
         self._check(self._lib.bj_canonicalize(self._h, d, n))
+
+    # -- seam S2: second round and quotient terms on device columns (pointers are device addresses, challenges (c0, c1) tuples)
+    @staticmethod
+    def _e2(x):
+        return np.array([int(x[0]), int(x[1])], dtype=np.uint64)
+
+    def copy_perm_stage2(self, d_vars, var_stride, d_sigmas, sig_stride, non_residues, num_vars, chunk, log_n, beta, gamma, d_z,
+                         d_partials):
+        nr = np.ascontiguousarray(non_residues, dtype=np.uint64)
+        self._check(self._lib.bj_copy_perm_stage2(self._h, d_vars, var_stride, d_sigmas, sig_stride, _np_ptr(nr), num_vars, chunk,
+                                                  log_n, _np_ptr(self._e2(beta)), _np_ptr(self._e2(gamma)), d_z, d_partials))
+
+    def lookup_polys(self, d_lvars, var_stride, d_table_id, d_tables, table_stride, d_mult, reps, width, log_n, beta, gamma, d_A, d_B):
+        self._check(self._lib.bj_lookup_polys(self._h, d_lvars, var_stride, d_table_id, d_tables, table_stride, d_mult, reps, width,
+                                              log_n, _np_ptr(self._e2(beta)), _np_ptr(self._e2(gamma)), d_A, d_B))
+
+    def quotient_gates(self, d_vars, var_stride, num_gp_vars, d_consts, const_stride, num_constant_cols, gates, alphas, num_points,
+                       d_out0, d_out1):
+        descs = gate_desc_array(gates)
+        al = np.ascontiguousarray(np.array(alphas, dtype=np.uint64).reshape(-1))
+        self._check(self._lib.bj_quotient_gates(self._h, d_vars, var_stride, num_gp_vars, d_consts, const_stride, num_constant_cols,
+                                                C.cast(descs, C.c_void_p), len(gates), _np_ptr(al) if al.size else None,
+                                                num_points, d_out0, d_out1))
+
+    def quotient_lookup(self, d_lvars, var_stride, d_table_id, d_tables, table_stride, d_mult, d_A, d_B, s2_stride, reps, width,
+                        beta, gamma, alphas, num_points, d_out0, d_out1):
+        al = np.ascontiguousarray(np.array(alphas, dtype=np.uint64).reshape(-1))
+        self._check(self._lib.bj_quotient_lookup(self._h, d_lvars, var_stride, d_table_id, d_tables, table_stride, d_mult, d_A, d_B,
+                                                 s2_stride, reps, width, _np_ptr(self._e2(beta)), _np_ptr(self._e2(gamma)),
+                                                 _np_ptr(al), num_points, d_out0, d_out1))
+
+    def quotient_copy_perm(self, d_vars, var_stride, d_sigmas, sig_stride, d_stage2, s2_stride, non_residues, num_vars, chunk, log_n,
+                           log_lde, beta, gamma, alphas, num_points, first_point, d_out0, d_out1):
+        nr = np.ascontiguousarray(non_residues, dtype=np.uint64)
+        al = np.ascontiguousarray(np.array(alphas, dtype=np.uint64).reshape(-1))
+        self._check(self._lib.bj_quotient_copy_perm(self._h, d_vars, var_stride, d_sigmas, sig_stride, d_stage2, s2_stride,
+                                                    _np_ptr(nr), num_vars, chunk, log_n, log_lde, _np_ptr(self._e2(beta)),
+                                                    _np_ptr(self._e2(gamma)), _np_ptr(al), num_points, first_point, d_out0, d_out1))
 
     FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_lazy": 3, "square": 4, "inverse": 5, "ext2_mul": 6}
 
@@ -444,6 +494,18 @@ class FriProof:
 class _GateDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("path_len", C.c_uint), ("path", C.c_ubyte * 8), ("num_repetitions", C.c_uint),
                 ("var_stride", C.c_uint), ("const_stride", C.c_uint), ("num_terms", C.c_uint), ("program", C.c_void_p)]
+
+
+def gate_desc_array(gates):
+    """bj_gate_desc[] for gates with the attributes of synthetic.Gate (kind, path, reps, var_stride, const_stride, num_terms)."""
+    arr = (_GateDesc * len(gates))()
+    for i, g in enumerate(gates):
+        arr[i].kind, arr[i].path_len = int(g.kind), len(g.path)
+        for b, bit in enumerate(g.path):
+            arr[i].path[b] = 1 if bit else 0
+        arr[i].num_repetitions, arr[i].var_stride, arr[i].const_stride = int(g.reps), int(g.var_stride), int(g.const_stride)
+        arr[i].num_terms, arr[i].program = int(g.num_terms), None
+    return arr
 
 
 class _Circuit(C.Structure):

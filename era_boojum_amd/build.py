@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libboojum_hip.so")
-SOURCES = ["abi.hip", "ntt.hip", "ntt_r16.hip", "poseidon2.hip", "blake2s.hip", "keccak.hip", "fri.hip", "fri_prover.hip", "openings.hip", "openings_abi.hip", "stage2.hip", "quotient.hip", "gate_program.hip", "gate_aot.hip", "gate_poseidon2.hip", "prover.hip"]
+SOURCES = ["abi.hip", "ntt.hip", "ntt_r16.hip", "poseidon2.hip", "blake2s.hip", "keccak.hip", "fri.hip", "fri_prover.hip", "openings.hip", "openings_abi.hip", "stage_ops_abi.hip", "stage2.hip", "quotient.hip", "gate_program.hip", "gate_aot.hip", "gate_poseidon2.hip", "prover.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

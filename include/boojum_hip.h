@@ -314,6 +314,46 @@ int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint
                          const uint64_t *d_consts, size_t const_stride, unsigned num_repetitions, unsigned rep_var_stride,
                          unsigned rep_const_stride, size_t n_points, uint64_t *d_terms);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Seam S2 for the second round and the quotient terms: the kernels bj_prove runs, on caller-provided device columns.
+ * F_p^2 challenges are two u64 (c0, c1) in host memory; F_p^2 columns are (c0, c1) pairs of base columns.
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* compute_partial_products_in_extension + shifted_grand_product_in_extension (src/cs/implementations/copy_permutation.rs:
+ * 649-830, 425-510; per-row rationals :114-248): variables / sigmas [num_vars][n] in natural row order over the main domain,
+ * columns taken in chunks of `chunk` (= quotient degree).  Out: d_z [2][n] (z(1) = 1) and d_partials [n_chunks-1][2][n]. */
+int bj_copy_perm_stage2(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, const uint64_t *d_sigmas, size_t sig_stride,
+                        const uint64_t *h_non_residues, unsigned num_vars, unsigned chunk, unsigned log_n,
+                        const uint64_t *h_beta, const uint64_t *h_gamma, uint64_t *d_z, uint64_t *d_partials);
+/* compute_lookup_poly_pairs_specialized (src/cs/implementations/lookup_argument_in_ext.rs:320-700): A_i = 1 / (beta +
+ * sum_j gamma^j col_ij + gamma^width table_id), B = multiplicity / (beta + sum_j gamma^j table_j) per row.
+ * d_lookup_vars [reps*width][n], d_tables [width+1][n]; out d_A [reps][2][n], d_B [2][n]. */
+int bj_lookup_polys(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_stride, const uint64_t *d_table_id,
+                    const uint64_t *d_tables, size_t table_stride, const uint64_t *d_multiplicities, unsigned reps, unsigned width,
+                    unsigned log_n, const uint64_t *h_beta, const uint64_t *h_gamma, uint64_t *d_A, uint64_t *d_B);
+/* Gate terms of the quotient numerator at num_points LDE points (prover.rs:1031-1080 with buffering_source.rs:133-362 and
+ * the selectors of prover.rs:2775-2916): out = sum_g selector_g * sum_t alpha_t * term_t for the hand-written evaluators
+ * (kinds 1..4; op lists are evaluated by bj_gate_program_eval).  h_alphas: one F_p^2 power per (gate, repetition, term) in
+ * evaluator order.  OVERWRITES d_out0 / d_out1. */
+int bj_quotient_gates(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, unsigned num_gp_vars, const uint64_t *d_consts,
+                      size_t const_stride, unsigned num_constant_cols, const bj_gate_desc *gates, unsigned num_gates,
+                      const uint64_t *h_alphas, size_t num_points, uint64_t *d_out0, uint64_t *d_out1);
+/* compute_quotient_terms_for_lookup_specialized (lookup_argument_in_ext.rs:949-1319): ADDS sum_i alpha_i * (A_i * denom_i - 1)
+ * + alpha_reps * (B * denom_table - multiplicity) to d_out.  h_alphas: reps + 1 powers. */
+int bj_quotient_lookup(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_stride, const uint64_t *d_table_id,
+                       const uint64_t *d_tables, size_t table_stride, const uint64_t *d_multiplicities, const uint64_t *d_A,
+                       const uint64_t *d_B, size_t stage2_stride, unsigned reps, unsigned width, const uint64_t *h_beta,
+                       const uint64_t *h_gamma, const uint64_t *h_alphas, size_t num_points, uint64_t *d_out0, uint64_t *d_out1);
+/* (z - 1) * L1 (prover.rs:1189-1227), the copy-permutation chain compute_quotient_terms_in_extension
+ * (copy_permutation.rs:1000-1249) and divide_by_vanishing_for_bitreversed_coset_enumeration (utils.rs:770-817): ADDS the
+ * terms to d_out and then multiplies by 1 / (x^n - 1).  Points are the flat LDE indices first_point .. first_point +
+ * num_points (whole cosets of 2^log_n, bit-reversed inside); d_stage2 = z, partial products as (c0, c1) columns;
+ * h_alphas: 1 (L1 term) + n_chunks powers. */
+int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, const uint64_t *d_sigmas, size_t sig_stride,
+                          const uint64_t *d_stage2, size_t stage2_stride, const uint64_t *h_non_residues, unsigned num_vars,
+                          unsigned chunk, unsigned log_n, unsigned log_lde, const uint64_t *h_beta, const uint64_t *h_gamma,
+                          const uint64_t *h_alphas, size_t num_points, size_t first_point, uint64_t *d_out0, uint64_t *d_out1);
+
 typedef struct bj_circuit {
     unsigned log_n;              /* trace length 2^log_n */
     unsigned num_vars;           /* all variable columns: general purpose first, then the specialized lookup columns, then the

@@ -130,3 +130,70 @@ def test_full_size_2_20_properties_and_spot_columns():
         ctx().intt_batch(d_o.ptr, d_o.ptr, log_n, n_cols, coset=coset)
         assert np.array_equal(d_o.get(a.shape), O.canonical(a))
     d_a.free(); d_o.free()
+
+
+def _splitmix64_column(seed, n):
+    """n outputs of SplitMix64 started at `seed`, reduced to [0, p) (column c of cfg2 uses seed 20240807 + c)."""
+    g = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + g * np.arange(1, n + 1, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z % np.uint64(P)
+
+
+def test_splitmix64_known_answer():
+    # first outputs of SplitMix64(seed = 0), the generator's published test vector
+    g = np.uint64(0x9E3779B97F4A7C15)
+    with np.errstate(over="ignore"):
+        z = g * np.arange(1, 4, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    assert [int(v) for v in z] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+@pytest.mark.parametrize("noncanonical", [False, True])
+def test_cfg2_all_256_columns_match_the_oracle(noncanonical):
+    """BASELINE cfg2 exactly as SURVEY §8d defines it: 256 columns x 2^20, column c from SplitMix64(20240807 + c); forward NTT
+    natural -> bit-reversed with coset shift 1 and 7; EVERY column compared with the oracle.  Second run: a fraction of the
+    values forced into [p, 2^64) (non-canonical inputs are legal in the reference's memory)."""
+    log_n, n_cols = 20, 256
+    n = 1 << log_n
+    a = np.stack([_splitmix64_column(20240807 + c, n) for c in range(n_cols)])
+    if noncanonical:
+        rng = np.random.default_rng(1)
+        idx = rng.integers(0, a.size, size=a.size // 16)
+        flat = a.reshape(-1)
+        small = flat[idx] < np.uint64((1 << 32) - 1)
+        flat[idx[small]] += np.uint64(P)             # same residue, representative in [p, 2^64)
+        flat[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        flat[-1] = np.uint64(P)
+    d_a, d_o = DevBuf(a), DevBuf(nelems=a.size)
+    for coset in (1, 7):
+        ctx().ntt_forward_batch(d_a.ptr, d_o.ptr, log_n, n_cols, coset=coset)
+        got = d_o.get(a.shape)
+        want = O.fft_batch(a, coset, threads=64)
+        assert np.array_equal(got, want), "coset %d: columns %s differ" % (coset, np.nonzero((got != want).any(axis=1))[0][:8])
+    d_a.free(); d_o.free()
+
+
+@pytest.mark.parametrize("log_n,log_lde,n_cols", [(20, 3, 6), (22, 3, 3), (21, 1, 3), (23, 1, 1)])
+def test_lde_at_bench_sizes_matches_oracle(log_n, log_lde, n_cols):
+    """The LDE of the bench sizes (2^20 and 2^22 rows x 8 cosets: the multi-pass NTT paths incl. the remainder rounds of sizes
+    with (log n - 12) mod 4 != 0) on a few columns, every value against the oracle."""
+    rng = np.random.default_rng(4000 + log_n)
+    mono = rand_gl(rng, (n_cols, 1 << log_n), noncanonical=True)
+    want = O.lde_batch(mono, log_lde, threads=32)
+    d_m, d_o = DevBuf(mono), DevBuf(nelems=want.size)
+    ctx().lde_batch(d_m.ptr, d_o.ptr, log_n, n_cols, log_lde)
+    assert np.array_equal(d_o.get(want.shape), want)
+    # the inverse transform at the same size brings coset 0 back to the monomials
+    if log_lde:
+        d_c = DevBuf(want[:, 0, :])
+        ctx().bitreverse_batch(d_c.ptr, d_c.ptr, log_n, n_cols)
+        ctx().intt_batch(d_c.ptr, d_c.ptr, log_n, n_cols, coset=7)
+        assert np.array_equal(d_c.get(mono.shape), O.canonical(mono))
+        d_c.free()
+    d_m.free(); d_o.free()

@@ -53,6 +53,37 @@ def test_hip_proof_of_the_8_kib_bench_circuit_verifies(transcript):
     gsetup.close()
 
 
+@pytest.mark.parametrize("transcript,kind", [("poseidon2", 1), ("poseidon", 2)])
+def test_hip_proof_of_the_8_kib_bench_circuit_equals_oracle_proof(transcript, kind):
+    """BASELINE config 1's circuit (8 KiB, 2^16 rows, LDE 8, cap 16, security 100) under both transcripts the bench offers:
+    every cap, opening, FRI layer and query of the HIP proof equals the oracle prover's (not only "verifier accepts")."""
+    c = S.sha256_circuit(S.bench_message(8 << 10))
+    assert c.log_n == 16
+    osetup = OP.Setup(c, 8, 16, threads=32)
+    po = OP.prove(c, osetup, 8, 16, security_level=100, threads=32, transcript_kind=kind)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript=transcript)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    _compare(proof_format.parse(buf, security_level=100), po)
+    gsetup.close()
+
+
+def test_hip_proof_at_2p18_rows_equals_oracle_proof():
+    """The same identity four times larger (SHA-256 of 34 KB, 2^18 rows, the bench's parameters): the 3-pass NTT sizes, the
+    multi-workgroup scans of stage 2 and the large-tree kernels are all on this path.  ~1 minute of oracle time."""
+    c = S.sha256_circuit(S.bench_message(34000, seed=11))
+    assert c.log_n == 18
+    osetup = OP.Setup(c, 8, 16, threads=64)
+    po = OP.prove(c, osetup, 8, 16, security_level=100, threads=64, transcript_kind=1)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript="poseidon2")
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=100)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg)
+    gsetup.close()
+
+
 def test_prove_from_memcopy_dumps():
     """A Rust host's `SetupBaseStorage` / `WitnessVec` / `DenseVariablesCopyHint` dumps (era_boojum_amd/memcopy_format.py)
     give the same proof as the in-memory circuit."""
