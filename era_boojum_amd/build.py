@@ -57,6 +57,11 @@ def build(force=False, verbose=False):
     build_synth(force)
     from . import gate_codegen          # csrc/gate_aot.hip: straight-line kernels generated from the known gate op lists
     gate_codegen.write()
+    import importlib.util               # csrc/gl_asm.inc: hand-scheduled lazy-arithmetic sequences (tools/gen_gl_asm.py)
+    spec = importlib.util.spec_from_file_location("gen_gl_asm", os.path.join(os.path.dirname(HERE), "tools", "gen_gl_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(p) for p in _deps()):
         return LIB
     objs = []

@@ -213,6 +213,43 @@ __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 
+}  // namespace gl
+#include "gl_asm.inc"   // generated: butterfly2_weak_asm, addsub2_weak_asm (tools/gen_gl_asm.py)
+namespace gl {
+#if defined(__HIP_DEVICE_COMPILE__)
+// Lazy radix-2 butterflies of the NTT kernels, two at a time (the two chains fill each other's SGPR wait states):
+//   (u, v) <- (u + v * w, u - v * w)  on weak residues, 15 half-rate + 6 full-rate VALU instructions per butterfly instead of
+//   the 21 + 9 of canonical mul / add / sub.  The wave-uniform fallback (a second wrap of the sum or the difference, the
+//   borrow-without-carry product: ~2^-32 per butterfly) recomputes all four results canonically.
+__device__ __forceinline__ void butterfly2_weak(u64 &ua, u64 &va, u64 wa, u64 &ub, u64 &vb, u64 wb) {
+    u64 sa, da, sb, db;
+    const u64 rare = butterfly2_weak_asm(ua, va, wa, ub, vb, wb, sa, da, sb, db);
+    if (__builtin_expect(rare != 0, 0)) {
+        const u64 ta = mul(va, wa), tb = mul(vb, wb), ca = canon(ua), cb = canon(ub);
+        sa = add(ca, ta); da = sub(ca, ta); sb = add(cb, tb); db = sub(cb, tb);
+    }
+    ua = sa; va = da; ub = sb; vb = db;
+}
+__device__ __forceinline__ void addsub2_weak(u64 &ua, u64 &va, u64 &ub, u64 &vb) {
+    u64 sa, da, sb, db;
+    const u64 rare = addsub2_weak_asm(ua, va, ub, vb, sa, da, sb, db);
+    if (__builtin_expect(rare != 0, 0)) {
+        const u64 ca = canon(ua), cb = canon(ub), ta = canon(va), tb = canon(vb);
+        sa = add(ca, ta); da = sub(ca, ta); sb = add(cb, tb); db = sub(cb, tb);
+    }
+    ua = sa; va = da; ub = sb; vb = db;
+}
+#else
+__host__ __forceinline__ void butterfly2_weak(u64 &ua, u64 &va, u64 wa, u64 &ub, u64 &vb, u64 wb) {   // host pass of the kernels' TUs
+    const u64 ta = mul(canon(va), canon(wa)), tb = mul(canon(vb), canon(wb)), ca = canon(ua), cb = canon(ub);
+    ua = add(ca, ta); va = sub(ca, ta); ub = add(cb, tb); vb = sub(cb, tb);
+}
+__host__ __forceinline__ void addsub2_weak(u64 &ua, u64 &va, u64 &ub, u64 &vb) {
+    const u64 ca = canon(ua), cb = canon(ub), ta = canon(va), tb = canon(vb);
+    ua = add(ca, ta); va = sub(ca, ta); ub = add(cb, tb); vb = sub(cb, tb);
+}
+#endif
+
 // a * 2^k mod p for 0 <= k < 32 (shift instead of multiply; used by Poseidon2's internal matrix): the part shifted
 // out is < 2^32, so the reduction is  lo + out*(2^32-1)  with one wrap/canonicalisation fix
 __host__ __device__ __forceinline__ u64 mul_pow2(u64 a, unsigned k) {

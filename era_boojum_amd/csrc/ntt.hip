@@ -401,7 +401,8 @@ void launch_canonicalize(u64 *d, size_t n, hipStream_t s) {
 
 // elementwise field operators on arbitrary u64 inputs (row a1/a2 of SURVEY §8 at operator level; field/goldilocks/mod.rs:188-255,
 // field/traits/field.rs:407-512); op: 0 add, 1 sub, 2 mul, 3 mul through the weak (lazy) product of the hash kernels,
-// 4 square, 5 inverse (0 -> 0), 6 F_p^2 multiplication on (a0,a1) x (b0,b1) with the second halves at +n
+// 4 square, 5 inverse (0 -> 0), 6 F_p^2 multiplication on (a0,a1) x (b0,b1) with the second halves at +n,
+// 7 the NTT butterfly (u, v) <- (u + v*w, u - v*w) with a = [u | v], b = w, 8 the same with w = 1
 __global__ void field_op_kernel(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -410,6 +411,17 @@ __global__ void field_op_kernel(int op, const u64 *a, const u64 *b, u64 *out, si
         gl::e2 r = gl::e2_mul(x, y);
         out[i] = r.c0;
         out[n + i] = r.c1;
+        return;
+    }
+    if (op == 7 || op == 8) {   // two lazy butterflies per thread, exactly as the NTT kernels run them (n even)
+        const size_t h = n / 2;
+        if (i >= h) return;
+        u64 ua = a[i], va = a[n + i], ub = a[i + h], vb = a[n + i + h];
+        if (op == 7)
+            gl::butterfly2_weak(ua, va, b[i], ub, vb, b[i + h]);
+        else
+            gl::addsub2_weak(ua, va, ub, vb);
+        out[i] = gl::canon(ua); out[n + i] = gl::canon(va); out[i + h] = gl::canon(ub); out[n + i + h] = gl::canon(vb);
         return;
     }
     const u64 x = a[i], y = b ? b[i] : 0;

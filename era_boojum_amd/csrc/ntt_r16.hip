@@ -55,47 +55,34 @@ __device__ __forceinline__ void load_step_twiddles(u64 (&tw)[15], const u64 *__r
     }
 }
 
-// 4 rounds on 16 register-resident elements; round s pairs x[i], x[i + (8>>s)] inside groups of 16>>s
+// 4 rounds on 16 register-resident elements; round s pairs x[i], x[i + (8>>s)] inside groups of 16>>s.  The elements are WEAK
+// residues (any u64) from the load of the first pass to the store of the last one: butterflies run two at a time through
+// gl::butterfly2_weak, nothing is canonicalised in between (the last pass does it once per element when it stores).
+// tw: the step's 15 twiddles, in registers (array) or in LDS (pointer) — indexed by constants after unrolling either way.
 template <bool UNIT_FIRST>
-__device__ __forceinline__ void radix16(u64 (&x)[16], const u64 (&tw)[15]) {
+__device__ __forceinline__ void radix16(u64 (&x)[16], const u64 *tw) {
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int half = 8 >> s;
-#pragma unroll
-        for (int g = 0; g < (1 << s); g++) {
-            const u64 w = tw[(1 << s) - 1 + g];
-#pragma unroll
-            for (int j = 0; j < half; j++) {
-                const int iu = g * 2 * half + j, iv = iu + half;
-                u64 u = x[iu];
-                u64 v = (UNIT_FIRST && s == 0) ? x[iv] : gl::mul(x[iv], w);
-                x[iu] = gl::add(u, v);
-                x[iv] = gl::sub(u, v);
-            }
-        }
-    }
-}
-
-// the same with the 15 twiddles read from LDS where they are used (short live ranges instead of 30 resident VGPRs)
-template <bool UNIT_FIRST>
-__device__ __forceinline__ void radix16_lds(u64 (&x)[16], const u64 *tw) {
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 3; s++) {
         const int half = 8 >> s;
 #pragma unroll
         for (int g = 0; g < (1 << s); g++) {
             const u64 w = (UNIT_FIRST && s == 0) ? 1 : tw[(1 << s) - 1 + g];
 #pragma unroll
-            for (int j = 0; j < half; j++) {
+            for (int j = 0; j < half; j += 2) {
                 const int iu = g * 2 * half + j, iv = iu + half;
-                u64 u = x[iu];
-                u64 v = (UNIT_FIRST && s == 0) ? x[iv] : gl::mul(x[iv], w);
-                x[iu] = gl::add(u, v);
-                x[iv] = gl::sub(u, v);
+                if (UNIT_FIRST && s == 0)
+                    gl::addsub2_weak(x[iu], x[iv], x[iu + 1], x[iv + 1]);
+                else
+                    gl::butterfly2_weak(x[iu], x[iv], w, x[iu + 1], x[iv + 1], w);
             }
         }
     }
+#pragma unroll
+    for (int g = 0; g < 8; g += 2)   // last round: neighbours, one twiddle per pair
+        gl::butterfly2_weak(x[2 * g], x[2 * g + 1], tw[7 + g], x[2 * g + 2], x[2 * g + 3], tw[8 + g]);
 }
+template <bool UNIT_FIRST>
+__device__ __forceinline__ void radix16_lds(u64 (&x)[16], const u64 *tw) { radix16<UNIT_FIRST>(x, tw); }
 
 // block-uniform step twiddles: 15 lanes compute them once, everyone reads them back as LDS broadcasts
 template <bool SCALED>
@@ -145,7 +132,7 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + (size_t)b * TILE;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = gl::canon(src[j * 256 + t]);
+        for (int j = 0; j < 16; j++) x[j] = src[j * 256 + t];
         {   // step A: bits 11..8 in registers, twiddles uniform
             u64 twA[15];
 #pragma unroll
@@ -167,7 +154,7 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         __syncthreads();
         radix16<false>(x, twC);   // step C: bits 3..0
 #pragma unroll
-        for (int j = 0; j < 16; j++) lds[pad(t * 16 + j)] = x[j];
+        for (int j = 0; j < 16; j++) lds[pad(t * 16 + j)] = gl::canon(x[j]);   // the transform's output: canonical residues
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 16; j++) dst[j * 256 + t] = lds[pad(j * 256 + t)];
@@ -213,7 +200,7 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + base;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = gl::canon(src[(size_t)(j * 16 + tm) << rem_log]);
+        for (int j = 0; j < 16; j++) x[j] = src[(size_t)(j * 16 + tm) << rem_log];
         radix16_lds<UNIT_FIRST>(x, lds_tw);    // mid bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
@@ -251,7 +238,7 @@ __global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + base;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = gl::canon(src[(size_t)j << rem_log]);
+        for (int j = 0; j < 16; j++) x[j] = src[(size_t)j << rem_log];
         radix16<UNIT_FIRST>(x, tw1);
 #pragma unroll
         for (int j = 0; j < 16; j++) dst[(size_t)j << rem_log] = x[j];

@@ -115,7 +115,10 @@ int bj_canonicalize(bj_ctx *ctx, uint64_t *d_data, size_t n);
  * and the F_p^2 product (src/field/traits/field.rs:407-426).  Inputs may be any u64, outputs are canonical.  BJ_FIELD_MUL_LAZY
  * is the same product through the non-canonical ("weak") multiplication the hash / NTT kernels use internally. */
 enum { BJ_FIELD_ADD = 0, BJ_FIELD_SUB = 1, BJ_FIELD_MUL = 2, BJ_FIELD_MUL_LAZY = 3, BJ_FIELD_SQUARE = 4, BJ_FIELD_INVERSE = 5,
-       BJ_FIELD_EXT2_MUL = 6 };
+       BJ_FIELD_EXT2_MUL = 6,
+       BJ_FIELD_BUTTERFLY = 7, /* the radix-2 butterfly of serial_ct_ntt (src/fft/mod.rs:659-734) as the NTT kernels run it: d_a = [u | v]
+                                * (second half at +n), d_b = w;  out = [u + v*w | u - v*w]; n even */
+       BJ_FIELD_ADDSUB = 8     /* the same with twiddle 1: d_a = [u | v], d_b unused; out = [u + v | u - v] */ };
 int bj_field_op_batch(bj_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
 
 /* Host-memory convenience for single-polynomial plumbing (what a Rust `impl PrimeFieldLikeVectorized` would call);

@@ -85,3 +85,44 @@ def test_inverse_and_extension_product():
     w0 = [(int(p) * int(r) + 7 * int(q) * int(s)) % P for p, q, r, s in zip(x[0], x[1], y[0], y[1])]
     w1 = [(int(p) * int(s) + int(q) * int(r)) % P for p, q, r, s in zip(x[0], x[1], y[0], y[1])]
     assert np.array_equal(got, np.array([w0, w1], dtype=np.uint64))
+
+
+def _butterfly_inputs():
+    """u, v, w triples: the product's rare branches (v, w from the fixture), sums and differences that wrap twice (operands
+    next to 2^64), boundary words, random weak values."""
+    with open(os.path.join(HERE, "golden", "gl_mul_rare.json")) as f:
+        vec = json.load(f)["vectors"]
+    big = [(1 << 64) - 1, (1 << 64) - 2, (1 << 64) - (1 << 32), (1 << 64) - (1 << 32) + 1, P - 1, P, P + 1, 0, 1, (1 << 32) - 1, 1 << 32]
+    u, v, w = [], [], []
+    for x in vec:                      # rare products, with u at the edges
+        for uu in (0, (1 << 64) - 1, P - 1, x["product"], (P - x["product"]) % P):
+            u.append(uu); v.append(x["a"]); w.append(x["b"])
+    for uu in big:                     # v * 1 = v next to 2^64: the sum / difference wrap twice
+        for vv in big:
+            u.append(uu); v.append(vv); w.append(1)
+            u.append(uu); v.append(vv); w.append(P + 1 if vv < (1 << 32) - 2 else 1)
+    rng = np.random.default_rng(12)
+    k = (1 << 15) - (len(u) % (1 << 15))
+    u += [int(x) for x in rng.integers(0, 1 << 63, size=k, dtype=np.uint64) * 2 + rng.integers(0, 2, size=k, dtype=np.uint64)]
+    v += [int(x) for x in rng.integers(0, 1 << 63, size=k, dtype=np.uint64) * 2 + 1]
+    w += [int(x) for x in rand_gl(rng, (k,), noncanonical=True)]
+    if len(u) % 2:
+        u.append(0); v.append(0); w.append(0)
+    return np.array(u, dtype=np.uint64), np.array(v, dtype=np.uint64), np.array(w, dtype=np.uint64)
+
+
+def test_lazy_ntt_butterflies_match_python_integers():
+    u, v, w = _butterfly_inputs()
+    n = u.size
+    got = ctx().field_op("butterfly", np.stack([u, v]), w)
+    want_s = np.array([(int(a) + int(b) * int(c)) % P for a, b, c in zip(u, v, w)], dtype=np.uint64)
+    want_d = np.array([(int(a) - int(b) * int(c)) % P for a, b, c in zip(u, v, w)], dtype=np.uint64)
+    assert np.array_equal(got[0], want_s) and np.array_equal(got[1], want_d)
+    got = ctx().field_op("addsub", np.stack([u, v]))
+    assert np.array_equal(got[0], np.array([(int(a) + int(b)) % P for a, b in zip(u, v)], dtype=np.uint64))
+    assert np.array_equal(got[1], np.array([(int(a) - int(b)) % P for a, b in zip(u, v)], dtype=np.uint64))
+    # a lone wave whose only work is a rare case (the wave-uniform fallback must trigger on one lane's flag)
+    for i in (0, 5, 57):
+        uu, vv, ww = np.full(2, u[i]), np.full(2, v[i]), np.full(2, w[i])
+        g = ctx().field_op("butterfly", np.stack([uu, vv]), ww)
+        assert int(g[0][0]) == (int(u[i]) + int(v[i]) * int(w[i])) % P and int(g[1][1]) == (int(u[i]) - int(v[i]) * int(w[i])) % P
