@@ -221,12 +221,21 @@ namespace gl {
 //   (u, v) <- (u + v * w, u - v * w)  on weak residues, 15 half-rate + 6 full-rate VALU instructions per butterfly instead of
 //   the 21 + 9 of canonical mul / add / sub.  The wave-uniform fallback (a second wrap of the sum or the difference, the
 //   borrow-without-carry product: ~2^-32 per butterfly) recomputes all four results canonically.
+struct bfly4 {
+    u64 sa, da, sb, db;
+};
+// the slow path is ONE out-of-line function per kernel image: inlined it is ~100 instructions at each of the 96 butterfly
+// sites of a three-step NTT kernel, more code than the instruction cache holds
+__device__ __attribute__((noinline)) bfly4 butterfly2_canonical(u64 ua, u64 va, u64 wa, u64 ub, u64 vb, u64 wb) {
+    const u64 ta = mul(va, wa), tb = mul(vb, wb), ca = canon(ua), cb = canon(ub);
+    return {add(ca, ta), sub(ca, ta), add(cb, tb), sub(cb, tb)};
+}
 __device__ __forceinline__ void butterfly2_weak(u64 &ua, u64 &va, u64 wa, u64 &ub, u64 &vb, u64 wb) {
     u64 sa, da, sb, db;
     const u64 rare = butterfly2_weak_asm(ua, va, wa, ub, vb, wb, sa, da, sb, db);
     if (__builtin_expect(rare != 0, 0)) {
-        const u64 ta = mul(va, wa), tb = mul(vb, wb), ca = canon(ua), cb = canon(ub);
-        sa = add(ca, ta); da = sub(ca, ta); sb = add(cb, tb); db = sub(cb, tb);
+        const bfly4 r = butterfly2_canonical(ua, va, wa, ub, vb, wb);
+        sa = r.sa; da = r.da; sb = r.sb; db = r.db;
     }
     ua = sa; va = da; ub = sb; vb = db;
 }
@@ -234,8 +243,8 @@ __device__ __forceinline__ void addsub2_weak(u64 &ua, u64 &va, u64 &ub, u64 &vb)
     u64 sa, da, sb, db;
     const u64 rare = addsub2_weak_asm(ua, va, ub, vb, sa, da, sb, db);
     if (__builtin_expect(rare != 0, 0)) {
-        const u64 ca = canon(ua), cb = canon(ub), ta = canon(va), tb = canon(vb);
-        sa = add(ca, ta); da = sub(ca, ta); sb = add(cb, tb); db = sub(cb, tb);
+        const bfly4 r = butterfly2_canonical(ua, va, 1, ub, vb, 1);
+        sa = r.sa; da = r.da; sb = r.sb; db = r.db;
     }
     ua = sa; va = da; ub = sb; vb = db;
 }

@@ -38,6 +38,17 @@ static constexpr u32 TILE = 4096;
 static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
 
 __device__ __forceinline__ u32 pad(u32 l) { return l + (l >> 4); }
+// wave-uniform base pointer + 32-bit per-lane BYTE offset: the shape the compiler turns into `global_load v, v_off, s[base]`
+// (the empty asm pins the base in an SGPR pair: without it the optimiser re-associates base + offset into sixteen hoisted
+// 64-bit per-lane addresses)
+__device__ __forceinline__ u64 ld_off(const u64 *base, u32 byte_off) {
+    asm volatile("" : "+s"(base));
+    return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(u64 *base, u32 byte_off, u64 v) {
+    asm volatile("" : "+s"(base));
+    *reinterpret_cast<u64 *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
 
 // tw[(1<<s)-1+g] = T[(kb<<s)+g] * sc[r+s],  s = 0..3, g < 2^s
 template <bool SCALED>
@@ -132,13 +143,8 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + (size_t)b * TILE;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = src[j * 256 + t];
-        {   // step A: bits 11..8 in registers, twiddles uniform
-            u64 twA[15];
-#pragma unroll
-            for (int i = 0; i < 15; i++) twA[i] = lds_tw[i];
-            radix16<false>(x, twA);
-        }
+        for (int j = 0; j < 16; j++) x[j] = ld_off(src + j * 256, t * 8u);
+        radix16<false>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
         __syncthreads();
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         for (int j = 0; j < 16; j++) lds[pad(t * 16 + j)] = gl::canon(x[j]);   // the transform's output: canonical residues
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; j++) dst[j * 256 + t] = lds[pad(j * 256 + t)];
+        for (int j = 0; j < 16; j++) st_off(dst + j * 256, t * 8u, lds[pad(j * 256 + t)]);
         __syncthreads();
     }
 }
@@ -192,15 +198,18 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
     }
     __syncthreads();
 
-    const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 4) + tl;
+    // addressing: a wave-uniform pointer per access (SGPR pair, advanced by scalar adds) + ONE 32-bit per-lane offset for the
+    // loads and one for the stores; sixteen 64-bit per-lane addresses would cost 64 VGPRs and a wave out of every SIMD
+    const size_t tile_base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 4);
+    const u32 off_ld = ((tm << rem_log) + tl) * 8u, off_st = (((tm * 16) << rem_log) + tl) * 8u;   // bytes; a column is < 2^32 bytes
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
     for (unsigned col = col0; col < col1; col++) {
-        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + base;
-        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + base;
+        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + tile_base;
+        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + tile_base;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = src[(size_t)(j * 16 + tm) << rem_log];
+        for (int j = 0; j < 16; j++) x[j] = ld_off(src + ((size_t)(j * 16) << rem_log), off_ld);
         radix16_lds<UNIT_FIRST>(x, lds_tw);    // mid bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
@@ -210,7 +219,7 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
         __syncthreads();
         radix16_lds<false>(x, lds_tw2 + tm * 16);   // mid bits 3..0
 #pragma unroll
-        for (int j = 0; j < 16; j++) dst[(size_t)(tm * 16 + j) << rem_log] = x[j];
+        for (int j = 0; j < 16; j++) st_off(dst + ((size_t)j << rem_log), off_st, x[j]);
     }
 }
 
@@ -230,7 +239,7 @@ __global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
     u64 tw1[15];
 #pragma unroll
     for (int i = 0; i < 15; i++) tw1[i] = lds_tw[i];
-    const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 8) + t;
+    const size_t base = ((size_t)hi << (a.log_n - a.r0)) + ((size_t)lo_tile << 8);
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
     for (unsigned col = col0; col < col1; col++) {
@@ -238,10 +247,10 @@ __global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + base;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = src[(size_t)j << rem_log];
+        for (int j = 0; j < 16; j++) x[j] = ld_off(src + ((size_t)j << rem_log), t * 8u);
         radix16<UNIT_FIRST>(x, tw1);
 #pragma unroll
-        for (int j = 0; j < 16; j++) dst[(size_t)j << rem_log] = x[j];
+        for (int j = 0; j < 16; j++) st_off(dst + ((size_t)j << rem_log), t * 8u, x[j]);
     }
 }
 
