@@ -101,7 +101,10 @@ int h2d_async(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (bytes > RING_MAX_BLOCK) return bj_memcpy_h2d(ctx, d_dst, h_src, bytes);
     if (!ctx->h_ring) BJ_HIP(ctx, hipHostMalloc((void **)&ctx->h_ring, RING_BYTES, hipHostMallocDefault));
     const size_t slot = (bytes + 63) & ~(size_t)63;
-    if (ctx->ring_off + slot > RING_BYTES) ctx->ring_off = 0;
+    if (ctx->ring_off + slot > RING_BYTES) {   // wrap: the skipped tail counts as in flight, or a reset at a mid-ring offset
+        ctx->ring_inflight += RING_BYTES - ctx->ring_off;   // would let the next lap overwrite copies still queued
+        ctx->ring_off = 0;
+    }
     if (ctx->ring_inflight + slot > RING_BYTES) {   // the ring wrapped onto copies that may not have run yet
         BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->ring_inflight = 0;

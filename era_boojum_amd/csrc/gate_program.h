@@ -14,10 +14,12 @@ struct DevProgram {
     DevRelation *d_rel = nullptr;
     uint32_t *d_writes = nullptr;
     unsigned n_rel = 0, n_writes = 0, n_tmp = 0;
-    uint64_t hash = 0;        // of the program's content: selects a generated kernel when one exists
+    uint64_t hash = 0, check = 0;   // two fingerprints of the program's content: select a generated kernel when one exists
     int upload(bj_ctx *ctx, const bj_gate_program *p);   // validates, packs and copies the program
     void release();
 };
+// highest variable / constant column index (relative to the repetition) the program reads, + 1; 0 if it reads none
+void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent);
 // quotient mode (d_alphas != nullptr): out += selector * sum alpha * term; stand-alone mode (d_terms != nullptr): raw terms
 void launch_gate_program(const DevProgram &P, const gl::u64 *d_vars, size_t var_stride, const gl::u64 *d_consts,
                          size_t const_stride, unsigned path_len, const unsigned char *path, unsigned reps,

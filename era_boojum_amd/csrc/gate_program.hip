@@ -83,15 +83,13 @@ __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
 }
 }  // namespace
 
-// FNV-1a over the program as 32-bit words: the key of the generated kernels (era_boojum_amd/gate_codegen.py walks the same way)
-uint64_t gate_program_hash(const bj_gate_program *p) {
-    uint64_t h = 0xcbf29ce484222325ULL;
-    auto mix = [&](uint32_t w) {
-        for (int b = 0; b < 4; b++) {
-            h ^= (w >> (8 * b)) & 0xFFu;
-            h *= 0x100000001b3ULL;
-        }
-    };
+// The program as a stream of 32-bit words, section lengths first (era_boojum_amd/gate_codegen.py walks the same way).  Two
+// independent 64-bit fingerprints of that stream select a generated kernel: FNV-1a is the key of the switch, the second one is
+// compared on a hit, so a program that merely collides with a known one under FNV-1a still runs in the interpreter.
+template <typename F>
+static void walk_program(const bj_gate_program *p, F mix) {
+    mix(p->num_relations);
+    mix(p->num_writes);
     for (uint32_t i = 0; i < p->num_relations; i++) {
         const bj_gate_relation &R = p->relations[i];
         const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
@@ -105,7 +103,41 @@ uint64_t gate_program_hash(const bj_gate_program *p) {
     }
     for (uint32_t t = 0; t < p->num_writes; t++) { mix(p->writes[t].kind); mix(p->writes[t].index); }
     mix(p->num_temporaries);
+}
+uint64_t gate_program_hash(const bj_gate_program *p) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    walk_program(p, [&](uint32_t w) {
+        for (int b = 0; b < 4; b++) {
+            h ^= (w >> (8 * b)) & 0xFFu;
+            h *= 0x100000001b3ULL;
+        }
+    });
     return h;
+}
+uint64_t gate_program_check(const bj_gate_program *p) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    walk_program(p, [&](uint32_t w) {
+        h ^= w;
+        h *= 0xFF51AFD7ED558CCDULL;
+        h ^= h >> 32;
+    });
+    return h;
+}
+
+void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent) {
+    unsigned v = 0, c = 0;
+    auto see = [&](const bj_gate_index &ix) {
+        if (ix.kind == BJ_IDX_VARIABLE_POLY && ix.index + 1 > v) v = ix.index + 1;
+        if (ix.kind == BJ_IDX_CONSTANT_POLY && ix.index + 1 > c) c = ix.index + 1;
+    };
+    for (uint32_t i = 0; p && p->relations && i < p->num_relations; i++) {
+        const bj_gate_relation &R = p->relations[i];
+        see(R.a);
+        if (R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL) see(R.b);
+    }
+    for (uint32_t t = 0; p && p->writes && t < p->num_writes; t++) see(p->writes[t]);
+    *var_extent = v;
+    *const_extent = c;
 }
 
 int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
@@ -141,6 +173,7 @@ int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     n_rel = p->num_relations;
     n_tmp = p->num_temporaries;
     hash = gate_program_hash(p);
+    this->check = gate_program_check(p);
     n_writes = p->num_writes;
     const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + wr.size() * 4 + 64;
     if (hipMalloc(&block, bytes) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "gate program: allocation failed");
@@ -172,7 +205,7 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
     if (!Q) return;
     const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
     static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr;
-    if (!no_aot && launch_gate_aot(P.hash, a, grid.x, s)) return;   // a generated straight-line kernel exists for this program
+    if (!no_aot && launch_gate_aot(P.hash, P.check, a, grid.x, s)) return;   // a generated straight-line kernel exists for this program
     if (P.n_tmp <= 8)
         hipLaunchKernelGGL(gate_program_kernel<8>, grid, block, 0, s, a);
     else if (P.n_tmp <= 16)
@@ -187,7 +220,7 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
 
 extern "C" int bj_gate_program_generated(const bj_gate_program *program) {
     if (!program || !program->relations || !program->writes) return 0;
-    return bj::gate_aot_known(bj::gate_program_hash(program)) ? 1 : 0;
+    return bj::gate_aot_known(bj::gate_program_hash(program), bj::gate_program_check(program)) ? 1 : 0;
 }
 
 extern "C" int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint64_t *d_vars, size_t var_stride,

@@ -61,7 +61,8 @@ struct ProgArgs {
 };
 }  // namespace gpdev
 // true if a generated kernel exists for the program with this hash (and it was launched)
-bool launch_gate_aot(uint64_t hash, const gpdev::ProgArgs &a, unsigned blocks, hipStream_t s);
-bool gate_aot_known(uint64_t hash);
+bool launch_gate_aot(uint64_t hash, uint64_t check, const gpdev::ProgArgs &a, unsigned blocks, hipStream_t s);
+bool gate_aot_known(uint64_t hash, uint64_t check);
 uint64_t gate_program_hash(const bj_gate_program *p);
+uint64_t gate_program_check(const bj_gate_program *p);
 }  // namespace bj

@@ -225,6 +225,14 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: a byte tree hasher (Blake2s / Keccak256) goes with a byte transcript and "
                                                      "the Poseidon2 tree hasher with an algebraic transcript");
     }
+    if (cfg->fri_lde_factor > 64 || c->quotient_degree > 64)   // per-coset tables of the quotient kernels hold 64 entries
+        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: fri_lde_factor and quotient_degree are limited to 64");
+    if (c->num_public_inputs && (!c->public_input_cols || !c->public_input_rows))
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: public input locations missing");
+    for (unsigned i = 0; i < c->num_public_inputs; i++)
+        if (c->public_input_cols[i] >= c->num_vars || (c->public_input_rows[i] >> c->log_n) != 0)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: public input %u at (column %u, row %u) is outside the %u x 2^%u trace",
+                            i, c->public_input_cols[i], c->public_input_rows[i], c->num_vars, c->log_n);
     if (cfg->pow_bits > 32 || cfg->pow_bits >= cfg->security_level)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: pow_bits must be <= 32 and below the security level (pow.rs:53, prover.rs:2293)");
     if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || c->table_id_col >= c->num_constant_cols))
@@ -276,6 +284,31 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             bj_setup_destroy(s);
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad gate descriptor %u", g);
         }
+        {   // every column index the evaluator will form must exist: (reps - 1) * stride + the widest operand, after the selector path
+            unsigned var_extent = 0, const_extent = 0;
+            bool const_per_rep = true;
+            switch (G.kind) {
+                case BJ_GATE_CONSTANT_ALLOCATOR: var_extent = 1; const_extent = 1; break;
+                case BJ_GATE_FMA_NO_CONSTANT: var_extent = 4; const_extent = 2; const_per_rep = false; break;
+                case BJ_GATE_REDUCTION4: var_extent = 5; const_extent = 4; const_per_rep = false; break;
+                case BJ_GATE_POSEIDON2_FLATTENED: var_extent = 130; break;
+                case BJ_GATE_PROGRAM: bj::gate_program_extent(G.program, &var_extent, &const_extent); break;
+                default: break;
+            }
+            const size_t last = G.num_repetitions ? G.num_repetitions - 1 : 0;
+            const size_t var_end = var_extent ? last * G.var_stride + var_extent : 0;
+            const size_t const_end = G.path_len + (const_extent ? (const_per_rep ? last * G.const_stride : 0) + const_extent : 0);
+            if (G.kind != BJ_GATE_NOP && (G.num_repetitions == 0 || var_end > c->num_gp_vars || const_end > c->num_constant_cols)) {
+                bj_setup_destroy(s);
+                return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: gate %u reads variable column %zu / constant column %zu of %u / %u "
+                                "(repetitions x stride + operand index, after a selector path of %u)", g, var_end, const_end,
+                                c->num_gp_vars, c->num_constant_cols, G.path_len);
+            }
+            if (G.path_len > c->num_constant_cols) {
+                bj_setup_destroy(s);
+                return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: gate %u: selector path longer than the constant columns", g);
+            }
+        }
         s->programs.emplace_back();
         if (G.kind == BJ_GATE_PROGRAM) {
             if (G.program->num_writes != G.num_terms) {
@@ -300,6 +333,11 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             const bj_gate_desc &G = c->specialized_gates[g];
             bool ok = c->specialized_gates && G.kind == BJ_GATE_PROGRAM && G.program && G.path_len == 0 && G.num_repetitions &&
                       G.var_stride && G.program->num_writes == G.num_terms;
+            if (ok) {
+                unsigned ve = 0, ce = 0;
+                bj::gate_program_extent(G.program, &ve, &ce);
+                ok = ve <= G.var_stride && ce == 0;      // a repetition reads its own var_stride columns and no constants
+            }
             for (uint32_t i = 0; ok && i < G.program->num_relations; i++) {
                 const bj_gate_relation &R = G.program->relations[i];
                 const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
@@ -454,6 +492,17 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
         ~HasherGuard() { c->hasher = saved; }
     } hasher_guard{ctx, ctx->hasher};
     ctx->hasher = (int)S->hasher;
+    if (!S->pub_cols.empty()) {   // the values that go into the transcript must be the cells they claim to be (witness.rs:21-27)
+        std::vector<u64> cells(S->pub_cols.size());
+        for (size_t i = 0; i < cells.size(); i++)
+            BJ_HIP(ctx, hipMemcpyAsync(&cells[i], d_variables + (size_t)S->pub_cols[i] * n + S->pub_rows[i], 8, hipMemcpyDeviceToHost, st));
+        BJ_HIP(ctx, hipStreamSynchronize(st));
+        for (size_t i = 0; i < cells.size(); i++)
+            if (gl::canon(cells[i]) != gl::canon(h_public_values[i]))
+                return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: public input %zu: value %llu given, the witness holds %llu at (column %u, row %u)",
+                                i, (unsigned long long)gl::canon(h_public_values[i]), (unsigned long long)gl::canon(cells[i]),
+                                S->pub_cols[i], S->pub_rows[i]);
+    }
     StageTimer timer(st);
     bj::host::Transcript tr;
     tr.kind = (int)S->transcript;

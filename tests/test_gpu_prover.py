@@ -181,3 +181,43 @@ def test_repeated_proofs_are_identical_and_do_not_leak_device_memory():
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
     gsetup.close()
+
+
+def test_setup_rejects_descriptors_that_would_index_past_the_columns():
+    """bj_setup_create validates every column index a gate descriptor implies (repetitions x stride + operand), the public
+    input locations and the domain sizes of the per-coset tables instead of letting kernels read past HBM buffers."""
+    import copy
+    c = S.sha_shaped_circuit(8, seed=3, table_bits=2)
+    bad = copy.copy(c)
+    bad.gates = [copy.copy(g) for g in c.gates]
+    bad.gates[1].reps = 16                                   # 16 FMA repetitions of stride 4 need 64 > 60 columns
+    with pytest.raises(E.BoojumHipError, match="reads variable column"):
+        E.ProverSetup(ctx(), bad, 8, 16, 20)
+    bad = copy.copy(c)
+    bad.gates = [copy.copy(g) for g in c.gates]
+    bad.gates[0].const_stride = 7                            # ConstantsAllocator: repetition 3 would read constant column 3 + 21
+    with pytest.raises(E.BoojumHipError, match="constant column"):
+        E.ProverSetup(ctx(), bad, 8, 16, 20)
+    bad = copy.copy(c)
+    bad.public_inputs = [(c.num_vars, 0, 1)]                 # column past the trace
+    with pytest.raises(E.BoojumHipError, match="outside"):
+        E.ProverSetup(ctx(), bad, 8, 16, 20)
+    bad = copy.copy(c)
+    bad.public_inputs = [(0, c.n, 1)]                        # row past the trace
+    with pytest.raises(E.BoojumHipError, match="outside"):
+        E.ProverSetup(ctx(), bad, 8, 16, 20)
+    with pytest.raises(E.BoojumHipError, match="limited to 64"):
+        E.ProverSetup(ctx(), c, 128, 16, 20)
+
+
+def test_prover_checks_public_values_against_the_witness():
+    c = S.sha_shaped_circuit(8, seed=4, table_bits=2)
+    assert c.public_inputs
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 20)
+    vals = [v for (_, _, v) in c.public_inputs]
+    vals[0] = (vals[0] + 1) % E.P
+    with pytest.raises(E.BoojumHipError, match="public input 0"):
+        gsetup.prove(public_values=vals)
+    buf, _ = gsetup.prove()                                  # and the setup is still usable
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), proof_format.parse(buf, security_level=20))
+    gsetup.close()
