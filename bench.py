@@ -115,7 +115,21 @@ def main():
     t_gen = time.perf_counter() - t_gen
     ctx = E.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    comm = E.TorchComm(ctx) if sharded else None
+    comm, transport = None, None
+    if sharded:
+        # the library's own transport: ncclAllGather on the proof stream, straight on the prover's buffers (comm_rccl.hip); the
+        # 128-byte unique id travels through torch.distributed.  BJ_BENCH_TRANSPORT=torch keeps the host-callback transport
+        # (also the automatic choice for gloo, where several ranks may share a GPU, which RCCL refuses).
+        want = os.environ.get("BJ_BENCH_TRANSPORT", "rccl" if backend == "nccl" else "torch")
+        if want == "rccl":
+            try:
+                box = [E.binding.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm, transport = E.RcclComm(ctx, box[0], rank, world), "in-library RCCL all-gather on the proof stream"
+            except Exception as e:   # never lose the run to the transport: fall back to the host-callback one
+                print("in-library RCCL transport unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+        if comm is None:
+            comm, transport = E.TorchComm(ctx), "torch.distributed all_gather_into_tensor through the bj_comm host callback"
     setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security, comm=comm, transcript=args.transcript)
     # witness resident in HBM (torch owns the allocations)
     d_vars = torch.from_numpy(circuit.variables.view(np.int64)).to(dev)
@@ -189,7 +203,7 @@ def main():
                    "log_n": log_n, "rows": n, "circuit": circuit_name, "circuit_synthesis_s": round(t_gen, 1),
                    "sharding": ("one proof sharded by LDE cosets over %d GPUs (%d cosets = %d Merkle leaves each), all-gather of "
                                 "caps / quotient / first FRI layer / query openings, %d collectives and %.1f MB received per "
-                                "rank per proof" % (world, args.fri_lde // world, leaves, comm_calls, comm_mb))
+                                "rank per proof; transport: %s" % (world, args.fri_lde // world, leaves, comm_calls, comm_mb, transport))
                                if sharded else ("one GPU" if world == 1 else "one independent proof per rank (replicas), no data-path collective"),
                    "proof_bytes": int(proof_buf.size * 8)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

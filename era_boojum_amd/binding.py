@@ -60,6 +60,10 @@ _SIGNATURES = {
     "bj_quotient_copy_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "bj_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "bj_comm_rccl_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "bj_comm_rccl_destroy": (None, [C.c_void_p]),
+    "bj_comm_rccl_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bj_gate_program_generated": (C.c_int, [C.c_void_p]),
     "bj_gate_program_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint,
                                        C.c_uint, C.c_size_t, C.c_void_p]),
@@ -527,10 +531,59 @@ STAGE_NAMES = ["witness_lde_and_tree", "second_stage", "quotient_work_and_lde", 
 
 
 _ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_ALL_GATHER_STREAM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class _Comm(C.Structure):  # bj_comm
-    _fields_ = [("rank", C.c_uint), ("world", C.c_uint), ("all_gather", _ALL_GATHER_FN), ("user", C.c_void_p)]
+    _fields_ = [("rank", C.c_uint), ("world", C.c_uint), ("all_gather", _ALL_GATHER_FN), ("user", C.c_void_p),
+                ("all_gather_stream", _ALL_GATHER_STREAM_FN)]
+
+
+RCCL_UNIQUE_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """bj_rccl_unique_id: 128 opaque bytes made by rank 0 and handed to every rank of the proof."""
+    buf = C.create_string_buffer(RCCL_UNIQUE_ID_BYTES)
+    rc = load_library().bj_rccl_unique_id(buf)
+    if rc != 0:
+        raise BoojumHipError("bj_rccl_unique_id failed: %s" % load_library().bj_status_string(rc).decode())
+    return buf.raw
+
+
+class RcclComm:
+    """The in-library transport (bj_comm_rccl_create): ncclAllGather on the context's stream, directly on the prover's buffers.
+    `unique_id` = the 128 bytes of rccl_unique_id() from rank 0 (ship them with any channel, e.g. torch.distributed's
+    broadcast_object_list).  Collective: every rank of the proof constructs it."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self._ctx, self._lib = ctx, ctx._lib
+        self.rank, self.world = rank, world
+        self.struct = _Comm()
+        ctx._check(self._lib.bj_comm_rccl_create(ctx._h, C.c_char_p(unique_id), rank, world, C.byref(self.struct)))
+
+    @property
+    def calls(self):
+        return self._stats()[0]
+
+    @property
+    def bytes(self):
+        return self._stats()[1]
+
+    def _stats(self):
+        a, b = C.c_size_t(), C.c_size_t()
+        self._lib.bj_comm_rccl_stats(C.byref(self.struct), C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self.struct.user:
+            self._lib.bj_comm_rccl_destroy(C.byref(self.struct))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class TorchComm:
@@ -550,7 +603,7 @@ class TorchComm:
         self._send = self._recv = None
         self.calls, self.bytes = 0, 0
         self._fn = _ALL_GATHER_FN(self._all_gather)        # keep the trampoline alive
-        self.struct = _Comm(self.rank, self.world, self._fn, None)
+        self.struct = _Comm(self.rank, self.world, self._fn, None, _ALL_GATHER_STREAM_FN())
 
     def _staging(self, nbytes):
         t = self._torch

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libboojum_hip.so")
-SOURCES = ["abi.hip", "ntt.hip", "ntt_r16.hip", "poseidon2.hip", "blake2s.hip", "keccak.hip", "fri.hip", "fri_prover.hip", "openings.hip", "openings_abi.hip", "stage_ops_abi.hip", "stage2.hip", "quotient.hip", "gate_program.hip", "gate_aot.hip", "gate_poseidon2.hip", "prover.hip"]
+SOURCES = ["abi.hip", "ntt.hip", "ntt_r16.hip", "poseidon2.hip", "blake2s.hip", "keccak.hip", "fri.hip", "fri_prover.hip", "comm_rccl.hip", "openings.hip", "openings_abi.hip", "stage_ops_abi.hip", "stage2.hip", "quotient.hip", "gate_program.hip", "gate_aot.hip", "gate_poseidon2.hip", "prover.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -49,7 +49,7 @@ def build_variant(out_path, extra_flags):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path] + objs)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_path] + objs + ["-ldl"])
     return out_path
 
 
@@ -80,7 +80,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     return LIB
 

@@ -147,6 +147,11 @@ int all_gather(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_recv, siz
             BJ_HIP(ctx, hipMemcpyAsync(d_recv, d_send, elems * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return BJ_OK;
     }
+    if (sh.comm.all_gather_stream) {   // stream-ordered transport (in-library RCCL): no synchronisation on either side
+        if (int rc = sh.comm.all_gather_stream(sh.comm.user, d_send, d_recv, elems * 8, ctx->stream))
+            return fail(ctx, BJ_ERR_HIP, "sharded prover: the stream-ordered all_gather failed (%d)", rc);
+        return BJ_OK;
+    }
     if (!sh.comm.all_gather) return fail(ctx, BJ_ERR_INVALID_ARG, "sharded prover: no all_gather callback");
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (int rc = sh.comm.all_gather(sh.comm.user, d_send, d_recv, elems * 8))
@@ -243,7 +248,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     if (n_chunks < 2) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: a single copy-permutation chunk is not supported");
     if (comm && comm->world > 1) {
         const unsigned W = comm->world;
-        if (!bj::is_pow2(W) || comm->rank >= W || !comm->all_gather)
+        if (!bj::is_pow2(W) || comm->rank >= W || (!comm->all_gather && !comm->all_gather_stream))
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must be a power of two, rank < world, callback set");
         if (cfg->fri_lde_factor % W || cfg->cap_size % W || c->quotient_degree > cfg->fri_lde_factor)
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must divide fri_lde_factor and cap_size, and "

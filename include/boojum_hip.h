@@ -417,7 +417,19 @@ typedef struct bj_comm {
      * context's stream idle; the data must be visible to that stream when it returns.  Non-zero return = failure. */
     int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes);
     void *user;
+    /* optional, preferred when set: the same exchange ENQUEUED on the given hipStream_t (the context's stream) and returning at
+     * once — stream order replaces both synchronisations.  bj_comm_rccl_create sets it. */
+    int (*all_gather_stream)(void *user, const void *d_send, void *d_recv, size_t bytes, void *hip_stream);
 } bj_comm;
+/* The in-library transport: RCCL (ncclAllGather over xGMI) on the context's stream, directly on the prover's buffers; librccl
+ * is loaded at run time (BJ_RCCL_LIB overrides the search).  Rank 0 makes the id and hands its 128 bytes to the other ranks by
+ * whatever channel the host has; every rank then calls bj_comm_rccl_create (collective) with its device current, and passes
+ * the filled bj_comm to bj_setup_create_sharded.  A Rust / C host needs nothing else to shard a proof over the GPUs of a node. */
+#define BJ_RCCL_UNIQUE_ID_BYTES 128
+int bj_rccl_unique_id(void *out_id);
+int bj_comm_rccl_create(bj_ctx *ctx, const void *unique_id, unsigned rank, unsigned world, bj_comm *out);
+void bj_comm_rccl_destroy(bj_comm *comm);
+int bj_comm_rccl_stats(const bj_comm *comm, size_t *calls, size_t *bytes_received); /* collectives issued, bytes received */
 int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_sigmas, const uint64_t *h_constants,
                             const uint64_t *h_tables, const bj_proof_config *config, const bj_comm *comm, bj_setup **out);
 /* bj_prove / bj_prove_dev on a sharded setup are collective: every rank calls them with the same witness. */

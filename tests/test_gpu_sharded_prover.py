@@ -89,3 +89,35 @@ def test_torchcomm_all_gather_over_rccl_world_1():
         assert torch.equal(src, dst) and comm.calls == 1
     finally:
         dist.destroy_process_group()
+
+
+def test_in_library_rccl_transport_world_1():
+    """bj_comm_rccl_create: the library's own transport (ncclAllGather on the context's stream, no staging, no host trampoline).
+    One GPU can only form a world of 1 (RCCL refuses two ranks on one device); that still loads librccl, creates the
+    communicator from a unique id, and runs both entry points of the bj_comm it fills on device buffers."""
+    import ctypes as C
+    from gpu_util import DevBuf
+    uid = E.binding.rccl_unique_id()
+    assert len(uid) == E.binding.RCCL_UNIQUE_ID_BYTES
+    comm = E.RcclComm(ctx(), uid, 0, 1)
+    assert (comm.struct.rank, comm.struct.world) == (0, 1) and comm.struct.all_gather_stream and comm.struct.all_gather
+    src = np.arange(1 << 16, dtype=np.uint64) * np.uint64(5) + np.uint64(3)
+    d_s, d_r = DevBuf(src), DevBuf(nelems=src.size)
+    assert comm.struct.all_gather_stream(comm.struct.user, C.c_void_p(d_s.ptr), C.c_void_p(d_r.ptr), src.nbytes, None) == 0
+    ctx().sync()
+    assert np.array_equal(d_r.get(), src)
+    d_r2 = DevBuf(nelems=src.size)
+    assert comm.struct.all_gather(comm.struct.user, C.c_void_p(d_s.ptr), C.c_void_p(d_r2.ptr), src.nbytes) == 0
+    assert np.array_equal(d_r2.get(), src)
+    assert comm.calls == 2 and comm.bytes == 2 * src.nbytes
+    # a setup created through the sharded entry point with this communicator proves like the plain one
+    c = S.sha_shaped_circuit(9, seed=2, table_bits=2)
+    a = E.ProverSetup(ctx(), c, 8, 16, 20, comm=comm)
+    b = E.ProverSetup(ctx(), c, 8, 16, 20)
+    pa, _ = a.prove()
+    pb, _ = b.prove()
+    assert np.array_equal(pa, pb)
+    a.close(); b.close()
+    comm.close()
+    for d in (d_s, d_r, d_r2):
+        d.free()
