@@ -62,6 +62,10 @@ def build(force=False, verbose=False):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main()
+    spec = importlib.util.spec_from_file_location("gen_p2_asm", os.path.join(os.path.dirname(HERE), "tools", "gen_p2_asm.py"))
+    mod = importlib.util.module_from_spec(spec)      # csrc/p2_asm.inc: the Poseidon2 permutation as one scheduled instruction stream
+    spec.loader.exec_module(mod)
+    mod.main()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(p) for p in _deps()):
         return LIB
     objs = []

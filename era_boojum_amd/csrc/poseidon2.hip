@@ -190,8 +190,16 @@ __device__ __forceinline__ u64 shl_plus(u64 a, u64 sum_lo, u64 sum_hi) {
     return combine_split(A, B);
 }
 
+}  // namespace bj
+#include "p2_asm.inc"   // generated (tools/gen_p2_asm.py): poseidon2_permutation_asm, the scheduled instruction stream
+namespace bj {
+
 // state in: any u64 words; state out: weak words (canonicalise what leaves the sponge with gl::canon)
 __device__ __forceinline__ void poseidon2_permutation(u64 (&s)[12]) {
+#if !defined(BJ_P2_CPP)
+    poseidon2_permutation_asm(s);
+    return;
+#endif
     ext_mds(s);
     int r = 0;
 #pragma unroll 1
