@@ -154,3 +154,60 @@ def test_full_size_tree_properties():
         leaf, path = ctx().merkle_tree_proof(d_t.ptr, num_leaves, cap, int(I))
         assert O.merkle_verify(path, capv, leaf, int(I))
     d_c.free(); d_t.free()
+
+
+def _ext_matrix():
+    m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]                     # suggested_mds.rs:21-56
+    return [[m4[i % 4][j % 4] * (2 if i // 4 == j // 4 else 1) for j in range(12)] for i in range(12)]
+
+
+def _solve_mod_p(M, rhs):
+    P = O.P
+    n = len(M)
+    A = [row[:] + [rhs[i]] for i, row in enumerate(M)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if A[r][c] % P)
+        A[c], A[piv] = A[piv], A[c]
+        inv = pow(A[c][c], P - 2, P)
+        A[c] = [x * inv % P for x in A[c]]
+        for r in range(n):
+            if r != c and A[r][c]:
+                f = A[r][c]
+                A[r] = [(x - f * y) % P for x, y in zip(A[r], A[c])]
+    return [A[i][n] for i in range(n)]
+
+
+def test_permutation_takes_the_rare_branches_of_its_products():
+    """States built so that every S-box of the first round sees x = 2^48 (x * x = 2^96 = -1: the product's final subtraction
+    borrows without a carry, a 2^-32 event on random data that the scheduled instruction stream handles out of line), or other
+    operands of the rare-vector fixture, in every word and in single words of an otherwise random state."""
+    import json, os
+    P = O.P
+    rc0 = [int(x) % P for x in O.poseidon_round_constants()[0]]
+    M = _ext_matrix()
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gl_mul_rare.json")) as f:
+        rare = [v["a"] for v in json.load(f)["vectors"]]
+    rng = np.random.default_rng(3)
+    states = []
+    for t in range(64):
+        target = [int(rng.integers(0, P, dtype=np.uint64)) for _ in range(12)]
+        if t == 0:
+            target = [1 << 48] * 12
+        elif t < 13:
+            target[t - 1] = 1 << 48                      # one word only: a lone lane of a chain takes the stub
+        else:
+            for k in range(12):
+                if rng.random() < 0.5:
+                    target[k] = [1 << 48, (1 << 48) * 3 % P, rare[int(rng.integers(0, len(rare)))] % P][int(rng.integers(0, 3))]
+        st = _solve_mod_p(M, [(x - r) % P for x, r in zip(target, rc0)])
+        chk = [(sum(M[i][j] * st[j] for j in range(12)) + rc0[i]) % P for i in range(12)]
+        assert chk == target
+        states.append(st)
+    st = np.array(states, dtype=np.uint64)
+    want = np.stack([O.poseidon2_permutation(s) for s in st])
+    for reps in (1, 80):                                   # a single wave, and many waves with the rare lanes spread out
+        batch = np.tile(st, (reps, 1))
+        d = DevBuf(batch)
+        ctx().poseidon2_permute(d.ptr, batch.shape[0])
+        assert np.array_equal(d.get(batch.shape), np.tile(want, (reps, 1)))
+        d.free()
