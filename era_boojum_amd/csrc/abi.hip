@@ -181,6 +181,10 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_ptrs) (void)hipFree((void *)ctx->d_ptrs);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->wit_stage) (void)hipFree(ctx->wit_stage);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->copy_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

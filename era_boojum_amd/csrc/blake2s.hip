@@ -7,7 +7,7 @@
 // elements, i.e. 8 coalesced column loads.  Pure 32-bit add/xor/rotate (v_alignbit) work: ~1.3 k VALU instructions per
 // 64-byte block against ~14 k for one Poseidon2 permutation over the same 8 elements.
 // Digests are stored as four little-endian u64 words = the 32 digest bytes in memory order (never canonicalised).
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 #include "../../include/boojum_hip.h"
 

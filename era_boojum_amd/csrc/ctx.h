@@ -2,7 +2,7 @@
 // units (abi.hip, fri_prover.hip, ...).
 #pragma once
 #include "../../include/boojum_hip.h"
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -31,6 +31,12 @@ struct bj_ctx {
     // a copy out of pageable memory costs a blocking staging pass plus a stream synchronisation, ~35 us of idle GPU each
     unsigned char *h_ring = nullptr;
     size_t ring_off = 0, ring_inflight = 0;
+    // bj_prove (host witness): device staging of the witness columns, kept across proofs, and a copy stream with one event
+    // per column group so that the PCIe transfer of group k+1 runs under the iNTT / LDE of group k
+    gl::u64 *wit_stage = nullptr;
+    size_t wit_stage_elems = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[64] = {};
 };
 
 namespace bj {

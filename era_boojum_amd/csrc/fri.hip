@@ -6,7 +6,7 @@
 // roots = the inverse bit-reversed twiddle table of the FULL initial LDE domain (prefix reused at every level),
 // coset_inv is squared by the caller after every fold and alpha squared between the folds of one schedule step.
 // HBM-bound pointwise kernel: 32 B read + 16 B written per output element, one F_p^2 multiplication.
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 
 using gl::u64;

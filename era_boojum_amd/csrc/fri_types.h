@@ -1,6 +1,6 @@
 // Internal: the object behind the opaque `bj_fri` (shared by fri_prover.hip and prover.hip).
 #pragma once
-#include "gl.cuh"
+#include "gl.h"
 #include "../../include/boojum_hip.h"
 #include <vector>
 using gl::u64;

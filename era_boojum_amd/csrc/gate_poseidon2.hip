@@ -4,7 +4,7 @@
 // reset, output_i - state_i at the end.  The op-list interpreter (gate_program.hip) runs the same gate as 2.4 k recorded
 // operations with 122 temporaries in scratch memory; here the state stays in registers and the terms go straight into the
 // alpha-weighted 160-bit accumulators (~10x fewer instructions per LDE point).  Same terms, same order, same proof.
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 #include "poseidon_rc.inc"
 

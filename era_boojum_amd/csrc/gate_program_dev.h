@@ -2,7 +2,7 @@
 // era_boojum_amd/gate_codegen.py) share — the launch arguments, the lazy alpha accumulator, the in-kernel inversion.
 #pragma once
 #include "gate_program.h"
-#include "gl.cuh"
+#include "gl.h"
 
 namespace bj {
 namespace gpdev {

@@ -5,7 +5,7 @@
 //   transcript    src/cs/implementations/transcript.rs:48-131 (AlgebraicSpongeBasedTranscript), :144-151 (Poseidon2)
 //   BoolsBuffer   src/cs/implementations/transcript.rs:369-417; index split prover.rs:2161-2182
 #pragma once
-#include "gl.cuh"
+#include "gl.h"
 #include "poseidon_rc.inc"
 #include <cstdint>
 #include <vector>

@@ -3,7 +3,7 @@
 //   leaf = Keccak256( le64(canonical(e_0)) || le64(canonical(e_1)) || ... ),   node = Keccak256( left[32] || right[32] )
 // lane = leaf / node; the 25-lane state lives in VGPRs (50 registers); a rate block is 17 field elements = 17 state lanes,
 // so absorbing is 17 coalesced column loads XORed straight into the state.  Digests: state lanes 0..3 (little endian).
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 #include "../../include/boojum_hip.h"
 

@@ -15,7 +15,7 @@
 // Coset evaluation needs no separate "distribute powers" sweep: scaling the input by shift^i is equivalent to
 // multiplying the round-r twiddle by shift^(n/2^(r+1)) (the factor shift^(i mod n/2^(r+1)) commutes through the
 // butterfly), so the kernel takes a per-round scale table instead.  Same residues, one HBM pass fewer.
-#include "gl.cuh"
+#include "gl.h"
 #include <cstdint>
 #include <cstdlib>
 #include "kernels.h"

@@ -13,7 +13,7 @@
 // workgroup loops over: the block-uniform ones are staged in LDS, the per-thread ones stay in VGPRs.
 // All LDS indices go through pad(l) = l + l/16, which makes every transpose below bank-conflict free for
 // ds_read_b64 / ds_write_b64 (64 x 4-byte banks).
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 
 using gl::u64;

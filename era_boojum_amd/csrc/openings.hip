@@ -13,7 +13,7 @@
 // The sums are accumulated UNREDUCED: each 64x64 product is added as a 128-bit integer into a 160-bit accumulator
 // (five 32-bit words, carry chain) and reduced mod p once at the end, which replaces a modular reduction + modular add
 // per term (~28 VALU ops) by the four mads + five add-with-carry (~10 ops).  HBM: every column value is read once.
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 
 using gl::u64;

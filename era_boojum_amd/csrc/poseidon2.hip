@@ -12,7 +12,7 @@
 // for leaf I the lane reads element I of every column, so a wavefront reads 64 consecutive u64 of one column per
 // load (512 B, coalesced).  Round constants are wave-uniform and come through the scalar cache.
 // The work is integer-ALU bound (~472 field multiplications per 64 absorbed bytes), not HBM bound.
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 #include "poseidon_rc.inc"
 #include <cstdlib>
@@ -94,7 +94,7 @@ __device__ __forceinline__ u64 w3_reduce(W3 a) {
 //   both: the wrap and the borrow cancel.  So W = R + (c ? EPS : 0) - (b ? EPS : 0) mod 2^64 in every case.
 __device__ __forceinline__ u64 mulw(u64 a, u64 b) {
 #if !defined(BJ_P2_MULW_LIMBS)
-    return gl::mul_weak(a, b);   // chained multiply-adds, 12 instructions (gl.cuh)
+    return gl::mul_weak(a, b);   // chained multiply-adds, 12 instructions (gl.h)
 #else
     u32 hh, hl, e;
     u64 lo;

@@ -438,8 +438,32 @@ int bj_proof_stage_ms(const bj_proof *p, float *out8) {
     return BJ_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// bj_prove: the witness is still in host memory when the proof starts.  Its columns are copied in groups on a second stream,
+// every group followed by an event; the witness round below waits for a group right before it transforms it, so the PCIe
+// transfer of the later groups runs under the iNTT / LDE of the earlier ones (the host buffers should be pinned).
+struct HostWitness {
+    const uint64_t *h_variables, *h_multiplicities;
+    unsigned group;        // columns per group
+};
+int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, const uint64_t *d_multiplicities,
+               const uint64_t *h_public_values, bj_proof **out, const HostWitness *hw);
+}  // namespace
+
+extern "C" {
+
 int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, const uint64_t *d_multiplicities,
                  const uint64_t *h_public_values, bj_proof **out) {
+    return prove_impl(ctx, S, d_variables, d_multiplicities, h_public_values, out, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, const uint64_t *d_multiplicities,
+               const uint64_t *h_public_values, bj_proof **out, const HostWitness *hw) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_dev: null out pointer");
     *out = nullptr;
@@ -499,9 +523,14 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     ctx->hasher = (int)S->hasher;
     if (!S->pub_cols.empty()) {   // the values that go into the transcript must be the cells they claim to be (witness.rs:21-27)
         std::vector<u64> cells(S->pub_cols.size());
-        for (size_t i = 0; i < cells.size(); i++)
-            BJ_HIP(ctx, hipMemcpyAsync(&cells[i], d_variables + (size_t)S->pub_cols[i] * n + S->pub_rows[i], 8, hipMemcpyDeviceToHost, st));
-        BJ_HIP(ctx, hipStreamSynchronize(st));
+        for (size_t i = 0; i < cells.size(); i++) {
+            const size_t at = (size_t)S->pub_cols[i] * n + S->pub_rows[i];
+            if (hw)
+                cells[i] = hw->h_variables[at];
+            else
+                BJ_HIP(ctx, hipMemcpyAsync(&cells[i], d_variables + at, 8, hipMemcpyDeviceToHost, st));
+        }
+        if (!hw) BJ_HIP(ctx, hipStreamSynchronize(st));
         for (size_t i = 0; i < cells.size(); i++)
             if (gl::canon(cells[i]) != gl::canon(h_public_values[i]))
                 return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: public input %zu: value %llu given, the witness holds %llu at (column %u, row %u)",
@@ -524,9 +553,39 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     if ((rc = wit_lde.alloc(ctx, (size_t)nW * Ln))) return rc;
     if ((rc = mono.alloc(ctx, (size_t)nW * n))) return rc;
     if ((rc = mono_s2.alloc(ctx, (size_t)nS2 * n))) return rc;
-    rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
-    if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
-    if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L, S->c0, S->cl);
+    if (!hw) {
+        rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
+        if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
+        if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L, S->c0, S->cl);
+    } else {
+        // all copies are queued on the copy stream at once (they run back to back at PCIe speed); the proof stream picks the
+        // groups up as they land.  Column nW - 1 is the multiplicity column when there are lookups.
+        if (!ctx->copy_stream) BJ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        const unsigned G = hw->group, n_groups = (nW + G - 1) / G;
+        if (n_groups > 64) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: more than 64 column groups");
+        for (unsigned g = 0; g < n_groups; g++) {
+            if (!ctx->copy_ev[g]) BJ_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[g], hipEventDisableTiming));
+            const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
+            const unsigned v1 = c1 < V ? c1 : V;           // variable columns of this group: [c0, v1)
+            if (c0 < v1)
+                BJ_HIP(ctx, hipMemcpyAsync(const_cast<uint64_t *>(d_variables) + (size_t)c0 * n, hw->h_variables + (size_t)c0 * n,
+                                           (size_t)(v1 - c0) * n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
+            if (has_lookup && c1 == nW)
+                BJ_HIP(ctx, hipMemcpyAsync(const_cast<uint64_t *>(d_multiplicities), hw->h_multiplicities, n * 8, hipMemcpyHostToDevice,
+                                           ctx->copy_stream));
+            BJ_HIP(ctx, hipEventRecord(ctx->copy_ev[g], ctx->copy_stream));
+        }
+        for (unsigned g = 0; g < n_groups && !rc; g++) {
+            const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
+            const unsigned v1 = c1 < V ? c1 : V;
+            BJ_HIP(ctx, hipStreamWaitEvent(st, ctx->copy_ev[g], 0));
+            if (c0 < v1) rc = bj_intt_batch(ctx, d_variables + (size_t)c0 * n, mono.p + (size_t)c0 * n, log_n, v1 - c0, n, 1);
+            if (!rc && has_lookup && c1 == nW) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
+            if (!rc)
+                rc = bj::lde_cosets_strided(ctx, mono.p + (size_t)c0 * n, n, wit_lde.p + (size_t)c0 * Ln, Ln, log_n, c1 - c0, S->log_L,
+                                            S->c0, S->cl);
+        }
+    }
     if (rc) return rc;
     if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
     // witness tree; the leaf kernel (the dominant kernel of a proof) is bracketed by HIP events on the launch stream
@@ -1054,21 +1113,31 @@ int bj_prove_dev(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, co
     return BJ_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
              const uint64_t *h_public_values, bj_proof **out) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!S || !h_variables || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
-    const size_t n = (size_t)1 << S->log_n;
-    DevBuf vars, mult;
-    int rc = vars.alloc(ctx, (size_t)S->V * n);
-    if (!rc) rc = bj_memcpy_h2d(ctx, vars.p, h_variables, (size_t)S->V * n * 8);
-    if (!rc && S->lookup_reps) {
-        if (!h_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
-        rc = mult.alloc(ctx, n);
-        if (!rc) rc = bj_memcpy_h2d(ctx, mult.p, h_multiplicities, n * 8);
+    if (S->lookup_reps && !h_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
+    const size_t n = (size_t)1 << S->log_n, need = (size_t)(S->V + 1) * n;
+    if (ctx->wit_stage_elems < need) {   // device staging of the witness, kept for the next proof (no 3 GB hipMalloc per proof)
+        if (ctx->wit_stage) BJ_HIP(ctx, hipFree(ctx->wit_stage));
+        ctx->wit_stage = nullptr;
+        ctx->wit_stage_elems = 0;
+        BJ_HIP(ctx, hipMalloc((void **)&ctx->wit_stage, need * 8));
+        ctx->wit_stage_elems = need;
     }
-    if (rc) return rc;
-    return bj_prove_dev(ctx, S, vars.p, S->lookup_reps ? mult.p : nullptr, h_public_values, out);
+    static const unsigned group = [] {
+        const char *e = getenv("BJ_PROVE_H2D_GROUP");
+        const unsigned v = e ? (unsigned)strtoul(e, nullptr, 10) : 8u;
+        return v ? v : 8u;
+    }();
+    const HostWitness hw{h_variables, h_multiplicities, group};
+    // the copies are queued inside the proof (after the workspace is reserved); a previous proof on this context has drained
+    return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + (size_t)S->V * n, h_public_values, out, &hw);
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@
 //   1 / (x^n - 1) per coset                         divide_by_vanishing_for_bitreversed_coset_enumeration utils.rs:770-817
 // One lane = one LDE point; consecutive lanes read consecutive addresses of every column (coalesced).  Sums of
 // challenge * term products are accumulated unreduced in 160-bit accumulators and reduced once.
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 
 using gl::u64;

@@ -7,7 +7,7 @@
 //   compute_lookup_poly_pairs_specialized       src/cs/implementations/lookup_argument_in_ext.rs:320-700
 // The reference's results do not depend on its thread chunking (products in a commutative ring), so the device may use
 // any association order: per-row products, a three-phase device-wide exclusive scan under F_p^2 multiplication.
-#include "gl.cuh"
+#include "gl.h"
 #include "kernels.h"
 
 using gl::u64;

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from era_boojum_amd import sharding
+import sharding_model as sharding
 from gpu_util import DevBuf, ctx, rand_gl
 
 pytestmark = pytest.mark.gpu

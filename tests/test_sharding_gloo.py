@@ -1,5 +1,5 @@
 """world_size-2 (and 4) CPU tests of the N>1 path over the gloo backend: partition logic + the cap all-gather of
-era_boojum_amd/sharding.py.  The GPU compute is replaced by an oracle-backed stand-in *inside this test* so that the
+tests/sharding_model.py.  The GPU compute is replaced by an oracle-backed stand-in *inside this test* so that the
 collective/partition code that runs on 8 GPUs (backend = era_boojum_amd.Context, RCCL) is exactly what runs here."""
 import os
 import socket
@@ -58,7 +58,7 @@ def _worker(rank, world, port, log_n, n_cols, log_lde, cap, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    from era_boojum_amd import sharding
+    import sharding_model as sharding
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rng = np.random.default_rng(123)             # same monomials on every rank (replicated input)
@@ -105,7 +105,7 @@ def test_coset_sharded_commit_and_column_sharding(world):
 
 
 def test_partition_helpers():
-    from era_boojum_amd import sharding as S
+    import sharding_model as S
     for n_cols in (0, 1, 7, 93, 256):
         for world in (1, 2, 3, 8):
             parts = [S.column_shard(n_cols, world, r) for r in range(world)]

@@ -144,7 +144,7 @@ def gen_addsub2():
 HEADER = '''// GENERATED by tools/gen_gl_asm.py — do not edit.  Hand-scheduled gfx950 sequences for lazy Goldilocks arithmetic.
 // Values are "weak" residues: any u64 congruent to the field element.  Every function returns a wave-uniform mask of the
 // lanes (probability ~2^-32 per operation on random data) whose result the straight-line sequence did NOT finish: a
-// second wrap of an addition / subtraction, or the borrow-without-carry case of the product (gl.cuh, mul_weak); the
+// second wrap of an addition / subtraction, or the borrow-without-carry case of the product (gl.h, mul_weak); the
 // caller recomputes those through the canonical operators.  Temporaries are the fixed VGPRs v%d.. (clobbers).
 #pragma once
 '''

@@ -2,7 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -I era_boojum_amd/csrc tools/microbench.hip -o tools/microbench
 // Prints wave-instruction throughput of the building blocks of a Goldilocks multiplication and the resulting
 // field-mul / butterfly / Poseidon2-sbox rates for the whole chip.
-#include "gl.cuh"
+#include "gl.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
