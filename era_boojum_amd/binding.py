@@ -497,7 +497,8 @@ class FriProof:
 
 class _GateDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("path_len", C.c_uint), ("path", C.c_ubyte * 8), ("num_repetitions", C.c_uint),
-                ("var_stride", C.c_uint), ("const_stride", C.c_uint), ("num_terms", C.c_uint), ("program", C.c_void_p)]
+                ("var_stride", C.c_uint), ("wit_stride", C.c_uint), ("const_stride", C.c_uint), ("num_terms", C.c_uint),
+                ("program", C.c_void_p)]
 
 
 def gate_desc_array(gates):
@@ -658,6 +659,7 @@ class ProverSetup:
                 gates[i].path[b] = 1 if bit else 0
             gates[i].num_repetitions, gates[i].var_stride, gates[i].const_stride, gates[i].num_terms = \
                 g.reps, g.var_stride, g.const_stride, g.num_terms
+            gates[i].wit_stride = getattr(g, "wit_stride", 0)
             prog = getattr(g, "program", None)       # seam S3: evaluate this gate from its op list (gate_program.py)
             if prog is not None:
                 gates[i].kind = 5
@@ -671,7 +673,8 @@ class ProverSetup:
         nr = np.array(c.non_residues, dtype=np.uint64)
         cols = (C.c_uint * max(1, len(c.public_inputs)))(*[p[0] for p in c.public_inputs])
         rows = (C.c_uint * max(1, len(c.public_inputs)))(*[p[1] for p in c.public_inputs])
-        cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, 0, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
+        self.num_witness_cols = int(getattr(c, "num_witness_cols", 0))
+        cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, self.num_witness_cols, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
                       c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
                       cols, rows, len(spec_list), spec if spec_list else None)
         self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3, "keccak256": 4}[transcript]
@@ -717,6 +720,8 @@ class ProverSetup:
         """Host-memory entry point (bj_prove): returns (serialised proof u64 array, per-stage ms)."""
         c = self.circuit
         v = np.ascontiguousarray(c.variables if variables is None else variables, dtype=np.uint64)
+        if self.num_witness_cols and v.shape[0] == c.num_vars:     # the non-copiable witness columns travel behind the variables
+            v = np.ascontiguousarray(np.concatenate([v, c.witness], axis=0))
         m = np.ascontiguousarray(c.multiplicities if multiplicities is None else multiplicities, dtype=np.uint64)
         pv = np.array([p[2] for p in c.public_inputs] if public_values is None else public_values, dtype=np.uint64)
         if pv.size == 0:

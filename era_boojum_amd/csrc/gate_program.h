@@ -19,10 +19,11 @@ struct DevProgram {
     void release();
 };
 // highest variable / constant column index (relative to the repetition) the program reads, + 1; 0 if it reads none
-void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent);
+void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent, unsigned *wit_extent = nullptr);
 // quotient mode (d_alphas != nullptr): out += selector * sum alpha * term; stand-alone mode (d_terms != nullptr): raw terms
 void launch_gate_program(const DevProgram &P, const gl::u64 *d_vars, size_t var_stride, const gl::u64 *d_consts,
                          size_t const_stride, unsigned path_len, const unsigned char *path, unsigned reps,
                          unsigned rep_var_stride, unsigned rep_const_stride, const gl::u64 *d_alphas, size_t Q,
-                         gl::u64 *d_out0, gl::u64 *d_out1, gl::u64 *d_terms, hipStream_t s);
+                         gl::u64 *d_out0, gl::u64 *d_out1, gl::u64 *d_terms, hipStream_t s, const gl::u64 *d_wits = nullptr,
+                         unsigned rep_wit_stride = 0);
 }  // namespace bj

@@ -32,10 +32,12 @@ __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
         unsigned stride;
         __device__ __forceinline__ u64 &operator[](u32 i) const { return p[(size_t)i * stride]; }
     } tmp{SLOTS ? &lds_tmp[0][threadIdx.x] : priv, SLOTS ? 256u : 1u};
+    size_t wb = 0;   // witness column offset of the current repetition
     auto fetch = [&](u32 packed, size_t vb, size_t cb) -> u64 {
         const u32 kind = packed >> 28, idx = packed & 0x0FFFFFFFu;
         switch (kind) {
             case BJ_IDX_VARIABLE_POLY: return gl::canon(a.vars[(vb + idx) * a.var_stride + I]);
+            case BJ_IDX_WITNESS_POLY: return gl::canon(a.wits[(wb + idx) * a.var_stride + I]);
             case BJ_IDX_CONSTANT_POLY: return gl::canon(a.consts[(cb + idx) * a.const_stride + I]);
             case BJ_IDX_TEMPORARY: return tmp[idx];
             default: return a.values[idx];
@@ -51,6 +53,7 @@ __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
     s1.clear();
     for (unsigned r = 0; r < a.reps; r++) {
         const size_t vb = (size_t)r * a.rep_var_stride, cb = (size_t)a.path_len + (size_t)r * a.rep_const_stride;
+        wb = (size_t)r * a.rep_wit_stride;
         for (unsigned i = 0; i < a.n_rel; i++) {
             const DevRelation R = a.rel[i];
             const u64 x = fetch(R.a, vb, cb);
@@ -124,11 +127,12 @@ uint64_t gate_program_check(const bj_gate_program *p) {
     return h;
 }
 
-void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent) {
-    unsigned v = 0, c = 0;
+void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent, unsigned *wit_extent) {
+    unsigned v = 0, c = 0, w = 0;
     auto see = [&](const bj_gate_index &ix) {
         if (ix.kind == BJ_IDX_VARIABLE_POLY && ix.index + 1 > v) v = ix.index + 1;
         if (ix.kind == BJ_IDX_CONSTANT_POLY && ix.index + 1 > c) c = ix.index + 1;
+        if (ix.kind == BJ_IDX_WITNESS_POLY && ix.index + 1 > w) w = ix.index + 1;
     };
     for (uint32_t i = 0; p && p->relations && i < p->num_relations; i++) {
         const bj_gate_relation &R = p->relations[i];
@@ -138,6 +142,7 @@ void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigne
     for (uint32_t t = 0; p && p->writes && t < p->num_writes; t++) see(p->writes[t]);
     *var_extent = v;
     *const_extent = c;
+    if (wit_extent) *wit_extent = w;
 }
 
 int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
@@ -148,10 +153,11 @@ int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     auto check = [&](const bj_gate_index &ix) -> bool {
         switch (ix.kind) {
             case BJ_IDX_VARIABLE_POLY:
+            case BJ_IDX_WITNESS_POLY:
             case BJ_IDX_CONSTANT_POLY: return ix.index < (1u << 20);
             case BJ_IDX_TEMPORARY: return ix.index < p->num_temporaries;
             case BJ_IDX_CONSTANT_VALUE: return ix.index < p->num_values && p->values;
-            default: return false;   // witness columns are not supported
+            default: return false;
         }
     };
     std::vector<DevRelation> rel(p->num_relations);
@@ -194,8 +200,9 @@ void DevProgram::release() {
 void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
                          unsigned path_len, const unsigned char *path, unsigned reps, unsigned rep_var_stride,
                          unsigned rep_const_stride, const u64 *d_alphas, size_t Q, u64 *d_out0, u64 *d_out1, u64 *d_terms,
-                         hipStream_t s) {
+                         hipStream_t s, const u64 *d_wits, unsigned rep_wit_stride) {
     ProgArgs a{};
+    a.wits = d_wits; a.rep_wit_stride = rep_wit_stride;
     a.vars = d_vars; a.var_stride = var_stride; a.consts = d_consts; a.const_stride = const_stride;
     a.rel = P.d_rel; a.values = P.d_values; a.writes = P.d_writes; a.n_rel = P.n_rel; a.n_writes = P.n_writes;
     a.path_len = path_len;
@@ -228,6 +235,11 @@ extern "C" int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program,
                                     unsigned rep_var_stride, unsigned rep_const_stride, size_t n_points, uint64_t *d_terms) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!d_vars || !d_terms || num_repetitions == 0) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_gate_program_eval: null argument");
+    {
+        unsigned ve = 0, ce = 0, we = 0;
+        if (program && program->relations && program->writes) bj::gate_program_extent(program, &ve, &ce, &we);
+        if (we) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_gate_program_eval: the stand-alone evaluator takes no witness columns");
+    }
     bj::DevProgram P;
     if (int rc = P.upload(ctx, program)) {
         P.release();

@@ -54,6 +54,8 @@ struct ProgArgs {
     unsigned path_len;
     unsigned char path[8];
     unsigned reps, rep_var_stride, rep_const_stride;
+    const u64 *wits;     // witness (non-copiable) columns, same stride as vars; nullptr when the program reads none
+    unsigned rep_wit_stride;
     const u64 *alphas;   // [reps * n_writes][2] for this gate, or nullptr
     size_t Q;
     u64 *out0, *out1;    // accumulated into (quotient mode)

@@ -61,6 +61,8 @@ struct bj_setup {
     int device = 0;
     // circuit
     unsigned log_n = 0, V = 0, num_gp_vars = 0, nC = 0, lookup_w = 0, lookup_reps = 0, table_id_col = 0, q = 0;
+    unsigned Wc = 0;               // non-copiable witness columns (behind the V variable columns in the witness oracle)
+    std::vector<unsigned> gate_wit_stride;   // per general-purpose gate: per_chunk_offset.witnesses_offset
     std::vector<int> gates_flat;   // 12 ints per gate
     std::vector<bj::DevProgram> programs;   // per gate; empty (block == nullptr) unless kind == BJ_GATE_PROGRAM
     unsigned n_gates = 0;
@@ -217,7 +219,6 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     *out = nullptr;
     if (!c || !cfg || !h_sigmas || !h_constants) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: null argument");
     if (c->log_n < 1 || c->log_n > 26) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: log_n out of range");
-    if (c->num_witness_cols != 0) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: witness columns are not supported");
     if (c->num_gates == 0 || c->num_gates > 16 || !c->gates) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: 1..16 gates expected");
     if (!bj::is_pow2(c->quotient_degree) || !bj::is_pow2(cfg->fri_lde_factor) || cfg->fri_lde_factor < 2 ||
         !bj::is_pow2(cfg->cap_size))
@@ -273,6 +274,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         s->sh.comm = *comm;
     }
     s->log_n = c->log_n; s->V = c->num_vars; s->num_gp_vars = c->num_gp_vars; s->nC = c->num_constant_cols;
+    s->Wc = c->num_witness_cols;
     s->lookup_w = c->lookup_width; s->lookup_reps = c->lookup_reps; s->table_id_col = c->table_id_col;
     s->q = c->quotient_degree;
     s->n_gates = c->num_gates;
@@ -290,15 +292,21 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad gate descriptor %u", g);
         }
         {   // every column index the evaluator will form must exist: (reps - 1) * stride + the widest operand, after the selector path
-            unsigned var_extent = 0, const_extent = 0;
+            unsigned var_extent = 0, const_extent = 0, wit_extent = 0;
             bool const_per_rep = true;
             switch (G.kind) {
                 case BJ_GATE_CONSTANT_ALLOCATOR: var_extent = 1; const_extent = 1; break;
                 case BJ_GATE_FMA_NO_CONSTANT: var_extent = 4; const_extent = 2; const_per_rep = false; break;
                 case BJ_GATE_REDUCTION4: var_extent = 5; const_extent = 4; const_per_rep = false; break;
                 case BJ_GATE_POSEIDON2_FLATTENED: var_extent = 130; break;
-                case BJ_GATE_PROGRAM: bj::gate_program_extent(G.program, &var_extent, &const_extent); break;
+                case BJ_GATE_PROGRAM: bj::gate_program_extent(G.program, &var_extent, &const_extent, &wit_extent); break;
                 default: break;
+            }
+            s->gate_wit_stride.push_back(G.wit_stride);
+            if (wit_extent && (size_t)(G.num_repetitions ? G.num_repetitions - 1 : 0) * G.wit_stride + wit_extent > c->num_witness_cols) {
+                bj_setup_destroy(s);
+                return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: gate %u reads witness column %zu of %u", g,
+                                (size_t)(G.num_repetitions - 1) * G.wit_stride + wit_extent, c->num_witness_cols);
             }
             const size_t last = G.num_repetitions ? G.num_repetitions - 1 : 0;
             const size_t var_end = var_extent ? last * G.var_stride + var_extent : 0;
@@ -339,9 +347,9 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             bool ok = c->specialized_gates && G.kind == BJ_GATE_PROGRAM && G.program && G.path_len == 0 && G.num_repetitions &&
                       G.var_stride && G.program->num_writes == G.num_terms;
             if (ok) {
-                unsigned ve = 0, ce = 0;
-                bj::gate_program_extent(G.program, &ve, &ce);
-                ok = ve <= G.var_stride && ce == 0;      // a repetition reads its own var_stride columns and no constants
+                unsigned ve = 0, ce = 0, we = 0;
+                bj::gate_program_extent(G.program, &ve, &ce, &we);
+                ok = ve <= G.var_stride && ce == 0 && we == 0;   // a repetition reads its own var_stride columns, no constants, no witness
             }
             for (uint32_t i = 0; ok && i < G.program->num_relations; i++) {
                 const bj_gate_relation &R = G.program->relations[i];
@@ -482,7 +490,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     // theirs and the pieces are all-gathered
     const bool q_local = S->cl >= q;
     const size_t Qe = q_local ? Q : (S->c0 < q ? Ln : 0);   // points this rank evaluates
-    const unsigned nW = V + (has_lookup ? 1 : 0);
+    const unsigned VW = V + S->Wc;                         // variables, then the non-copiable witness columns (prover.rs:317-343)
+    const unsigned nW = VW + (has_lookup ? 1 : 0);
     const unsigned n_chunks = (V + q - 1) / q, n_part = n_chunks - 1;
     const unsigned nS2 = 2 * (1 + n_part) + (has_lookup ? 2 * (S->lookup_reps + 1) : 0);
     const unsigned nT = has_lookup ? S->lookup_w + 1 : 0;
@@ -554,8 +563,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     if ((rc = mono.alloc(ctx, (size_t)nW * n))) return rc;
     if ((rc = mono_s2.alloc(ctx, (size_t)nS2 * n))) return rc;
     if (!hw) {
-        rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, V, n, 1);
-        if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
+        rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, VW, n, 1);
+        if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)VW * n, log_n, 1, n, 1);
         if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L, S->c0, S->cl);
     } else {
         // all copies are queued on the copy stream at once (they run back to back at PCIe speed); the proof stream picks the
@@ -566,7 +575,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         for (unsigned g = 0; g < n_groups; g++) {
             if (!ctx->copy_ev[g]) BJ_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[g], hipEventDisableTiming));
             const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
-            const unsigned v1 = c1 < V ? c1 : V;           // variable columns of this group: [c0, v1)
+            const unsigned v1 = c1 < VW ? c1 : VW;         // variable / witness columns of this group: [c0, v1)
             if (c0 < v1)
                 BJ_HIP(ctx, hipMemcpyAsync(const_cast<uint64_t *>(d_variables) + (size_t)c0 * n, hw->h_variables + (size_t)c0 * n,
                                            (size_t)(v1 - c0) * n * 8, hipMemcpyHostToDevice, ctx->copy_stream));
@@ -577,10 +586,10 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         }
         for (unsigned g = 0; g < n_groups && !rc; g++) {
             const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
-            const unsigned v1 = c1 < V ? c1 : V;
+            const unsigned v1 = c1 < VW ? c1 : VW;
             BJ_HIP(ctx, hipStreamWaitEvent(st, ctx->copy_ev[g], 0));
             if (c0 < v1) rc = bj_intt_batch(ctx, d_variables + (size_t)c0 * n, mono.p + (size_t)c0 * n, log_n, v1 - c0, n, 1);
-            if (!rc && has_lookup && c1 == nW) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)V * n, log_n, 1, n, 1);
+            if (!rc && has_lookup && c1 == nW) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)VW * n, log_n, 1, n, 1);
             if (!rc)
                 rc = bj::lde_cosets_strided(ctx, mono.p + (size_t)c0 * n, n, wit_lde.p + (size_t)c0 * Ln, Ln, log_n, c1 - c0, S->log_L,
                                             S->c0, S->cl);
@@ -674,7 +683,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                 unsigned char path[8] = {0};
                 for (int b = 0; b < f[1]; b++) path[b] = (unsigned char)f[6 + b];
                 bj::launch_gate_program(S->programs[g], wit_lde.p, Ln, d_con_lde, Ln, (unsigned)f[1], path, (unsigned)f[2],
-                                        (unsigned)f[3], (unsigned)f[4], a_gates + 2 * (size_t)aoff, Qe, t0, t1, nullptr, st);
+                                        (unsigned)f[3], (unsigned)f[4], a_gates + 2 * (size_t)aoff, Qe, t0, t1, nullptr, st,
+                                        S->Wc ? wit_lde.p + (size_t)V * Ln : nullptr, S->gate_wit_stride[g]);
             }
             aoff += (unsigned)(f[2] * f[5]);
         }
@@ -689,7 +699,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     if (has_lookup && Qe) {
         const u64 *dA = s2_lde.p + (size_t)(2 + 2 * n_part) * Ln, *dB = dA + (size_t)2 * S->lookup_reps * Ln;
         bj::launch_quotient_lookup(wit_lde.p + (size_t)S->num_gp_vars * Ln, Ln, d_con_lde + (size_t)S->table_id_col * Ln, d_tab_lde,
-                                   Ln, wit_lde.p + (size_t)V * Ln, dA, dB, Ln, S->lookup_reps, S->lookup_w, lbeta, lgamma,
+                                   Ln, wit_lde.p + (size_t)VW * Ln, dA, dB, Ln, S->lookup_reps, S->lookup_w, lbeta, lgamma,
                                    a_lookup, Qe, t0, t1, st);
     }
     if (Qe)
@@ -740,7 +750,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     struct Src { const u64 *c0, *c1; };
     std::vector<Src> srcs, msrcs;   // msrcs: the monomial forms of the same polynomials, same order (for the DEEP numerator)
     const u64 *m_sig = S->d_mono, *m_con = S->d_mono + (size_t)V * n, *m_tab = S->d_mono + (size_t)(V + nC) * n;
-    for (unsigned i = 0; i < V; i++) srcs.push_back({wit_lde.p + (size_t)i * Ln, nullptr}), msrcs.push_back({mono.p + (size_t)i * n, nullptr});
+    for (unsigned i = 0; i < VW; i++) srcs.push_back({wit_lde.p + (size_t)i * Ln, nullptr}), msrcs.push_back({mono.p + (size_t)i * n, nullptr});   // variables, witness
     for (unsigned i = 0; i < nC; i++) srcs.push_back({d_con_lde + (size_t)i * Ln, nullptr}), msrcs.push_back({m_con + (size_t)i * n, nullptr});
     for (unsigned i = 0; i < V; i++) srcs.push_back({d_sig_lde + (size_t)i * Ln, nullptr}), msrcs.push_back({m_sig + (size_t)i * n, nullptr});
     for (unsigned j = 0; j < 1 + n_part; j++) {
@@ -748,8 +758,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         msrcs.push_back({mono_s2.p + (size_t)(2 * j) * n, mono_s2.p + (size_t)(2 * j + 1) * n});
     }
     if (has_lookup) {
-        srcs.push_back({wit_lde.p + (size_t)V * Ln, nullptr});
-        msrcs.push_back({mono.p + (size_t)V * n, nullptr});
+        srcs.push_back({wit_lde.p + (size_t)VW * Ln, nullptr});
+        msrcs.push_back({mono.p + (size_t)VW * n, nullptr});
         for (unsigned i = 0; i < S->lookup_reps + 1; i++) {
             size_t o = (size_t)(2 + 2 * n_part + 2 * i);
             srcs.push_back({s2_lde.p + o * Ln, s2_lde.p + (o + 1) * Ln});
@@ -817,12 +827,12 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         zo[0] = gl::mul(gl::canon(z[0]), om);
         zo[1] = gl::mul(gl::canon(z[1]), om);
     }
-    std::vector<Src> zsrc{srcs[V + nC + V]};
+    std::vector<Src> zsrc{srcs[VW + nC + V]};
     if ((rc = evaluate(zsrc, zo, vzo))) return rc;
     tr.absorb(vzo.data(), vzo.size());
     std::vector<Src> lsrc;
     if (has_lookup) {
-        for (unsigned i = 0; i < S->lookup_reps + 1; i++) lsrc.push_back(srcs[V + nC + V + 1 + n_part + 1 + i]);
+        for (unsigned i = 0; i < S->lookup_reps + 1; i++) lsrc.push_back(srcs[VW + nC + V + 1 + n_part + 1 + i]);
         u64 zero2[2] = {0, 0};
         if ((rc = evaluate(lsrc, zero2, v0))) return rc;
         tr.absorb(v0.data(), v0.size());
@@ -916,12 +926,12 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     };
     if ((rc = deep_set(srcs, msrcs, vz.data(), z, 0))) return rc;
     {
-        std::vector<Src> mz{msrcs[V + nC + V]};                      // z(x) at z*omega
+        std::vector<Src> mz{msrcs[VW + nC + V]};                      // z(x) at z*omega
         if ((rc = deep_set(zsrc, mz, vzo.data(), zo, 1))) return rc;
     }
     if (has_lookup) {
         std::vector<Src> ml;
-        for (unsigned i = 0; i < S->lookup_reps + 1; i++) ml.push_back(msrcs[V + nC + V + 1 + n_part + 1 + i]);
+        for (unsigned i = 0; i < S->lookup_reps + 1; i++) ml.push_back(msrcs[VW + nC + V + 1 + n_part + 1 + i]);
         u64 zero2[2] = {0, 0};
         if ((rc = deep_set(lsrc, ml, v0.data(), zero2, 1))) return rc;
     }
@@ -1122,7 +1132,7 @@ int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const 
     if (int rc = bj::bind(ctx)) return rc;
     if (!S || !h_variables || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
     if (S->lookup_reps && !h_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
-    const size_t n = (size_t)1 << S->log_n, need = (size_t)(S->V + 1) * n;
+    const size_t n = (size_t)1 << S->log_n, need = (size_t)(S->V + S->Wc + 1) * n;
     if (ctx->wit_stage_elems < need) {   // device staging of the witness, kept for the next proof (no 3 GB hipMalloc per proof)
         if (ctx->wit_stage) BJ_HIP(ctx, hipFree(ctx->wit_stage));
         ctx->wit_stage = nullptr;
@@ -1137,7 +1147,7 @@ int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const 
     }();
     const HostWitness hw{h_variables, h_multiplicities, group};
     // the copies are queued inside the proof (after the workspace is reserved); a previous proof on this context has drained
-    return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + (size_t)S->V * n, h_public_values, out, &hw);
+    return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + (size_t)(S->V + S->Wc) * n, h_public_values, out, &hw);
 }
 
 }  // extern "C"

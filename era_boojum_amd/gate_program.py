@@ -55,6 +55,7 @@ class GateProgramBuilder:
         self.relations, self.values, self.writes, self.n_tmp = [], [], [], 0
 
     def var(self, i): return _Val(self, IDX_VARIABLE, i)
+    def wit(self, i): return _Val(self, IDX_WITNESS, i)          # a non-copiable witness column (TraceSource::get_witness_value)
     def const_poly(self, i): return _Val(self, IDX_CONSTANT_POLY, i)
 
     def value(self, x):
@@ -121,14 +122,20 @@ class GateProgram:
     def num_terms(self):
         return len(self.writes)
 
-    def evaluate(self, var, con):
-        """Reference semantics in python integers (for tests): var/con = lists of ints; returns the terms."""
+    @property
+    def witness_width(self):
+        """Witness columns one repetition reads (0 for almost every evaluator)."""
+        refs = [r for _, _, a, b in self.relations for r in (a, b)] + list(self.writes)
+        return max([i + 1 for k, i in refs if k == IDX_WITNESS], default=0)
+
+    def evaluate(self, var, con, wit=()):
+        """Reference semantics in python integers (for tests): var/con/wit = lists of ints; returns the terms."""
         tmp = {}
 
         def get(ix):
             k, i = ix
-            return {IDX_VARIABLE: lambda: var[i], IDX_CONSTANT_POLY: lambda: con[i], IDX_TEMPORARY: lambda: tmp[i],
-                    IDX_VALUE: lambda: self.values[i]}[k]() % P
+            return {IDX_VARIABLE: lambda: var[i], IDX_WITNESS: lambda: wit[i], IDX_CONSTANT_POLY: lambda: con[i],
+                    IDX_TEMPORARY: lambda: tmp[i], IDX_VALUE: lambda: self.values[i]}[k]() % P
         for op, dst, a, b in self.relations:
             x = get(a)
             if op == OP_ADD: r = x + get(b)
@@ -142,7 +149,7 @@ class GateProgram:
         return [get(w) for w in self.writes]
 
 
-def _evaluate_columns(self, var_cols, con_cols):
+def _evaluate_columns(self, var_cols, con_cols, wit_cols=()):
     """The same semantics over whole columns (numpy uint64, era_boojum_amd.field_np): returns one array per term."""
     import numpy as np
     from . import field_np as F
@@ -152,6 +159,7 @@ def _evaluate_columns(self, var_cols, con_cols):
     def get(ix):
         k, i = ix
         if k == IDX_VARIABLE: return F.canon(np.asarray(var_cols[i], dtype=np.uint64))
+        if k == IDX_WITNESS: return F.canon(np.asarray(wit_cols[i], dtype=np.uint64))
         if k == IDX_CONSTANT_POLY: return F.canon(np.asarray(con_cols[i], dtype=np.uint64))
         if k == IDX_TEMPORARY: return tmp[i]
         return np.full(n, self.values[i] % P, dtype=np.uint64)
@@ -210,9 +218,12 @@ def dot_product4_program():
     return b.build()
 
 
-def zero_check_program():
+def zero_check_program(use_witness_column_for_inversion=False):
+    """ZeroCheckGate (zero_check.rs:143-175); with use_witness_column_for_inversion the inverse lives in a non-copiable witness
+    column (variables_offset 2, witnesses_offset 1, zero_check.rs:76-91)."""
     b = GateProgramBuilder()
-    inp, flag, inv = b.var(0), b.var(1), b.var(2)
+    inp, flag = b.var(0), b.var(1)
+    inv = b.wit(0) if use_witness_column_for_inversion else b.var(2)
     b.push(flag + inp * inv - 1)                                     # zero_check.rs:143-175
     b.push(inp * flag)
     return b.build()

@@ -42,6 +42,7 @@ class GateDesc:
     needs_selector: bool
     path: list = field(default_factory=list)   # selector path, True = constant, False = 1 - constant
     program: object = None   # op list for kind GATE_PROGRAM (and, optionally, for the hand-written kinds)
+    wit_stride: int = 0      # per_chunk_offset.witnesses_offset: non-copiable witness columns per repetition
 
 
 def sha_bench_gates(num_gp_vars=60, num_constant_cols=4):
@@ -67,6 +68,16 @@ def extended_gates(num_gp_vars=60, num_constant_cols=4):
         GateDesc(GATE_PROGRAM, "UIntXAddGate", 2, 1, 5, num_gp_vars // 5, 5, 0, 2, True, program=GP.uintx_add_program()),
     ]
     return g[:3] + extra + g[3:]
+
+
+def witness_gates(num_gp_vars=60, num_constant_cols=4, num_witness_cols=5):
+    """The bench's gates plus ZeroCheckGate with its inversion witness in a non-copiable witness column
+    (use_witness_column_for_inversion = true, zero_check.rs:76-112: 2 variables + 1 witness per repetition)."""
+    from . import gate_program as GP
+    g = sha_bench_gates(num_gp_vars, num_constant_cols)
+    reps = min(num_gp_vars // 2, num_witness_cols)
+    zc = GateDesc(GATE_PROGRAM, "ZeroCheckGate[witness]", 2, 0, 2, reps, 2, 0, 2, True, program=GP.zero_check_program(True), wit_stride=1)
+    return g[:3] + [zc] + g[3:]
 
 
 def recursion_gates(num_gp_vars=130, num_constant_cols=8, poseidon2_as_op_list=False):
@@ -223,6 +234,11 @@ class Circuit:
     max_allowed_constraint_degree: int = 4
     geometry_constant_cols: int = 4    # CSGeometry::num_constant_columns (the rest of num_constants_for_gates are selector extras)
     specialized_gates: list = field(default_factory=list)   # GateDesc with .program: gates over their own columns after the lookup ones
+    witness: np.ndarray = None      # [Wc, n] non-copiable witness columns (WitnessSet::witness, witness.rs:25), or None
+
+    @property
+    def num_witness_cols(self):
+        return 0 if self.witness is None else int(self.witness.shape[0])
 
     @property
     def n(self):
@@ -239,7 +255,7 @@ class Circuit:
 
 def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
                        lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False, boolean_columns=0, gates=None,
-                       max_allowed_constraint_degree=4):
+                       max_allowed_constraint_degree=4, num_witness_cols=0):
     """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
     (ConstantsAllocator, FMA, Reduction); the rest are Nop rows.  boolean_columns > 0 adds a BooleanConstraintGate placed
     over that many specialized columns (GatePlacementStrategy::UseSpecializedColumns, boolean_allocator.rs): every row of
@@ -260,6 +276,7 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     Kc = consts_for_gates + 1
     V = num_gp_vars + lookup_width * lookup_reps + boolean_columns
     variables = np.zeros((V, n), dtype=np.uint64)
+    witness = rand_f((num_witness_cols, n)) if num_witness_cols else None   # unconstrained cells hold anything: they are committed and opened all the same
     constants = np.zeros((Kc, n), dtype=np.uint64)
     swaps = []   # copy cycles of length 2: (col_a, col_b, row slice) — sigma exchanges the two cells' identities
 
@@ -302,6 +319,14 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
                 a, b, sel = rand_f(m), rand_f(m), rng.integers(0, 2, size=m).astype(np.uint64)
                 variables[base, rows], variables[base + 1, rows], variables[base + 2, rows] = a, b, sel
                 variables[base + 3, rows] = np.where(sel == 1, a, b)
+        elif g.name == "ZeroCheckGate[witness]":           # use_witness_column_for_inversion (zero_check.rs:76-91): inverse in a witness column
+            for r in range(g.reps):
+                base = r * g.var_stride
+                x = rand_f(m)
+                x[rng.random(m) < 0.3] = 0
+                inv = np.array([pow(int(v), P - 2, P) for v in x], dtype=np.uint64)
+                variables[base, rows], variables[base + 1, rows] = x, (x == 0).astype(np.uint64)
+                witness[r * g.wit_stride, rows] = inv
         elif g.name == "ZeroCheckGate":
             for r in range(g.reps):
                 base = r * g.var_stride
@@ -459,7 +484,7 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
                    table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len,
                    selector_tree=getattr(place_selectors, "last_tree", None), geometry_constant_cols=num_constant_cols,
-                   specialized_gates=specialized, max_allowed_constraint_degree=max_allowed_constraint_degree)
+                   specialized_gates=specialized, max_allowed_constraint_degree=max_allowed_constraint_degree, witness=witness)
 
 
 def check_satisfied(c: Circuit):
@@ -498,7 +523,8 @@ def check_satisfied(c: Circuit):
             for r in range(g.reps):
                 vcols = [var[r * g.var_stride + k][rows] for k in range(g.principal_width)]
                 ccols = [consts[k][rows] for k in range(d + r * g.const_stride, consts.shape[0])]
-                for t in prog.evaluate_columns(vcols, ccols):
+                wcols = [c.witness[k][rows] for k in range(r * g.wit_stride, c.num_witness_cols)] if c.num_witness_cols else []
+                for t in prog.evaluate_columns(vcols, ccols, wcols):
                     assert not t.any(), "%s unsatisfied" % g.name
     assert sum(m.sum() for m in sel_rows.values()) == n, "selector paths must partition the rows"
     col = c.num_gp_vars + c.num_lookup_vars

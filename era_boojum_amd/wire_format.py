@@ -83,7 +83,7 @@ def vk_to_reference_json(circuit, setup_cap, fri_lde_factor, cap_size):
     gate_index = {id(g): i for i, g in enumerate(c.gates)}
     return {
         "fixed_parameters": {
-            "parameters": {"num_columns_under_copy_permutation": c.num_gp_vars, "num_witness_columns": 0,
+            "parameters": {"num_columns_under_copy_permutation": c.num_gp_vars, "num_witness_columns": int(getattr(c, "num_witness_cols", 0)),
                            "num_constant_columns": c.geometry_constant_cols,
                            "max_allowed_constraint_degree": c.max_allowed_constraint_degree},
             "lookup_parameters": lookup,

@@ -269,7 +269,8 @@ typedef enum bj_gate_kind {
  * src/gpu_synthesizer/mod.rs:113-133, 354-444): `relations` are executed in order, each writes one temporary;
  * operands are variable columns (relative to the repetition), constant columns (relative to the end of the selector
  * path, plus the repetition's constant offset), temporaries or field constants; `writes` are the quotient terms of one
- * repetition in push order (GPUPolyDestination::push_evaluation_result).  Witness columns are not supported. */
+ * repetition in push order (GPUPolyDestination::push_evaluation_result).  Witness columns (Index::WitnessPoly) are relative to
+ * the repetition's witness offset (bj_gate_desc.wit_stride). */
 typedef enum bj_gate_op { /* Relation<F>, gpu_synthesizer/mod.rs:123-133 */
     BJ_OP_ADD = 1, BJ_OP_DOUBLE = 2, BJ_OP_SUB = 3, BJ_OP_NEGATE = 4, BJ_OP_MUL = 5, BJ_OP_SQUARE = 6, BJ_OP_INVERSE = 7
 } bj_gate_op;
@@ -301,6 +302,7 @@ typedef struct bj_gate_desc {
     unsigned char path[8];    /* 1: multiply by constant column i, 0: by (1 - constant column i)  (prover.rs:2775-2916) */
     unsigned num_repetitions; /* num_repetitions_in_geometry */
     unsigned var_stride;      /* per_chunk_offset.variables_offset */
+    unsigned wit_stride;      /* per_chunk_offset.witnesses_offset (0 for evaluators that read no witness column) */
     unsigned const_stride;    /* per_chunk_offset.constants_offset */
     unsigned num_terms;       /* quotient terms per repetition (0 for markers) */
     const bj_gate_program *program; /* BJ_GATE_PROGRAM only, NULL otherwise */
@@ -362,7 +364,10 @@ typedef struct bj_circuit {
     unsigned num_vars;           /* all variable columns: general purpose first, then the specialized lookup columns, then the
                                   * columns of the gates over specialized columns */
     unsigned num_gp_vars;        /* CSGeometry::num_columns_under_copy_permutation */
-    unsigned num_witness_cols;   /* must be 0 */
+    unsigned num_witness_cols;   /* CSGeometry::num_witness_columns: non-copiable columns (WitnessSet::witness, witness.rs:25).  They
+                                  * are committed with the variables (leaf = variables || witness || multiplicities, prover.rs:317-347),
+                                  * opened after them, and readable only by op-list gates (BJ_IDX_WITNESS_POLY).  bj_prove / bj_prove_dev
+                                  * take them right behind the variable columns: [num_vars + num_witness_cols][n] */
     unsigned num_constant_cols;  /* selector/gate constants + (lookups) the table-id column */
     unsigned lookup_width;       /* LookupParameters::UseSpecializedColumnsWithTableIdAsConstant { width, .. } */
     unsigned lookup_reps;        /* num_repetitions; 0 = no lookup argument */
@@ -436,12 +441,13 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *circuit, const uint64
 void bj_setup_destroy(bj_setup *s);
 int bj_setup_cap(const bj_setup *s, uint64_t *h_cap); /* vk.setup_merkle_tree_cap: cap_size*4 u64 */
 
-/* WitnessSet (witness.rs:21-27) in: variables [num_vars][n] natural order, multiplicities [n] (NULL without lookups),
+/* WitnessSet (witness.rs:21-27) in: variables, then the non-copiable witness columns: [num_vars + num_witness_cols][n] natural
+ * order, multiplicities [n] (NULL without lookups),
  * public input values in location order.  Proof out (bj_proof_serialize).  Returns BJ_ERR_INVALID_ARG with
  * "constraint system is not satisfied" where the reference panics "unsatisfied" (prover.rs:1425-1438). */
 int bj_prove(bj_ctx *ctx, const bj_setup *setup, const uint64_t *h_variables, const uint64_t *h_multiplicities,
              const uint64_t *h_public_values, bj_proof **out);
-/* same with the witness already resident in HBM ([num_vars][n] contiguous; not modified) */
+/* same with the witness already resident in HBM ([num_vars + num_witness_cols][n] contiguous; not modified) */
 int bj_prove_dev(bj_ctx *ctx, const bj_setup *setup, const uint64_t *d_variables, const uint64_t *d_multiplicities,
                  const uint64_t *h_public_values, bj_proof **out);
 void bj_proof_destroy(bj_proof *p);

@@ -82,6 +82,13 @@ def ev_zero_check(var, con):
     return [esub(eadd(flag, emul(inp, inv)), ONE), emul(inp, flag)]
 
 
+# --- the same evaluator with use_witness_column_for_inversion (zero_check.rs:76-91, 157-161): the inverse comes from a non-copiable
+#     witness column (TraceSource::get_witness_value(0)); takes the witness values as a third argument
+def ev_zero_check_witness(var, con, wit):
+    inp, flag = var[:2]
+    return [esub(eadd(flag, emul(inp, wit[0])), ONE), emul(inp, flag)]
+
+
 # --- uintx_add.rs:96-130: a + b + carry_in - c - 2^N*carry_out ; carry_out^2 - carry_out   (row-shared constant 2^N)
 def ev_uintx_add(var, con):
     a, b, cin, c, cout = var[:5]
@@ -201,6 +208,7 @@ EVALUATORS = {
     "Poseidon2FlattenedGate": (130, lambda v, k: 1, 0, 0, 118, ev_poseidon2_flattened),
     "DotProductGate<4>": (9, lambda v, k: v // 9, 0, 0, 1, ev_dot_product4),
     "ZeroCheckGate": (3, lambda v, k: v // 3, 0, 0, 2, ev_zero_check),
+    "ZeroCheckGate[witness]": (2, lambda v, k: v // 2, 0, 0, 2, ev_zero_check_witness),
     "FmaGateInBaseFieldWithoutConstant": (4, lambda v, k: v // 4, 2, 0, 1, ev_fma),
     "UIntXAddGate": (5, lambda v, k: v // 5, 1, 0, 2, ev_uintx_add),
     "SelectionGate": (4, lambda v, k: v // 4, 0, 0, 1, ev_selection),

@@ -87,7 +87,7 @@ def _F():
     return field_np
 
 
-def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec):
+def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec, wits_q=None):
     """sum over the op-list gates of selector * sum alpha * term on the quotient domain, from the programs' own semantics
     (GateProgram.evaluate_columns: plain numpy field arithmetic).  General-purpose gates of kind >= 5 with their selector
     path; gates over specialized columns without one, on their own columns after the lookup ones."""
@@ -102,9 +102,9 @@ def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec):
         assert g.name == "Poseidon2FlattenedGate"
         return poseidon2_flattened_program()
 
-    def weighted(prog, vcols, ccols, alphas, aoff):
+    def weighted(prog, vcols, ccols, alphas, aoff, wcols=()):
         s0, s1 = np.zeros(Qn, dtype=np.uint64), np.zeros(Qn, dtype=np.uint64)
-        for term in prog.evaluate_columns(vcols, ccols):
+        for term in prog.evaluate_columns(vcols, ccols, wcols):
             a = alphas[aoff]
             s0 = F.add(s0, F.mul(term, np.uint64(a[0])))
             s1 = F.add(s1, F.mul(term, np.uint64(a[1])))
@@ -122,7 +122,9 @@ def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec):
         for r in range(g.reps):
             vcols = [vars_q[r * g.var_stride + k] for k in range(g.principal_width)]
             ccols = [con_q[k] for k in range(d + r * g.const_stride, con_q.shape[0])]
-            s0, s1, aoff = weighted(prog, vcols, ccols, a_gates, aoff)
+            ws = getattr(g, "wit_stride", 0)
+            wcols = [wits_q[k] for k in range(r * ws, wits_q.shape[0])] if (ws and wits_q is not None) else ()
+            s0, s1, aoff = weighted(prog, vcols, ccols, a_gates, aoff, wcols)
             acc0, acc1 = F.add(acc0, F.mul(s0, sel)), F.add(acc1, F.mul(s1, sel))
     col, aoff = c.num_gp_vars + c.lookup_reps * c.lookup_width, 0
     for g in spec_gates:
@@ -215,7 +217,9 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
         return lde, view, tree, H.merkle_cap(tree, N, cap_size)
 
     # ---- round 1: witness (prover.rs:270-353); leaf = variables || witness || multiplicities
-    wit_nat = np.concatenate([c.variables, c.multiplicities], axis=0) if has_lookup else c.variables
+    Wc = int(getattr(c, "num_witness_cols", 0))                          # non-copiable witness columns sit behind the variables
+    parts = [c.variables] + ([c.witness] if Wc else []) + ([c.multiplicities] if has_lookup else [])
+    wit_nat = np.concatenate(parts, axis=0) if len(parts) > 1 else c.variables
     wit_lde, wit_view, wit_tree, wit_cap = commit(wit_nat)
     t.absorb_cap(wit_cap)
     # ---- round 2: copy-permutation + lookup (prover.rs:360-554)
@@ -247,7 +251,8 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     alphas = alphas_all[:n_lookup_terms] + alphas_all[n_lookup_terms + n_spec_terms:]     # what the C quotient consumes
     sub = lambda lde: np.ascontiguousarray(lde[:, :q, :].reshape(lde.shape[0], Q))
     vars_q = sub(wit_lde[:V])
-    mult_q = sub(wit_lde[V:V + 1]).reshape(-1) if has_lookup else np.zeros(0, dtype=np.uint64)
+    mult_q = sub(wit_lde[V + Wc:V + Wc + 1]).reshape(-1) if has_lookup else np.zeros(0, dtype=np.uint64)
+    wits_q = sub(wit_lde[V:V + Wc]) if Wc else None
     nS, nC = V, c.num_constant_cols
     sig_q, con_q = sub(setup.lde[:nS]), sub(setup.lde[nS:nS + nC])
     tab_q = sub(setup.lde[nS + nC:]) if has_lookup else np.zeros(0, dtype=np.uint64)
@@ -258,7 +263,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     T = quotient(vars_q, con_q, sig_q, np.ascontiguousarray(z_q), np.ascontiguousarray(part_q), np.ascontiguousarray(A_q),
                  np.ascontiguousarray(B_q), mult_q, tab_q, c, log_q, alphas, beta, gamma, lbeta, lgamma, threads)
     if spec_gates or any(g.kind >= 5 for g in c.gates):
-        e0, e1 = _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec)
+        e0, e1 = _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec, wits_q)
         for cs in range(q):   # divide by x^n - 1, constant on a coset: x^n = (7 * w_{nL}^{bitrev_L(cs)})^n
             xn = pow(7 * pow(O.omega(log_n + log_L), O.bitrev(cs, log_L), P) % P, n, P)
             inv = np.uint64(O.inv((xn - 1) % P))
@@ -281,13 +286,13 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     w0, w1 = O.barycentric_weights(log_n, 7, z)
     ev_base = lambda lde_col: O.barycentric_eval_base(lde_col[0], w0, w1)
     ev_ext = lambda a, b: O.barycentric_eval_ext(a[0], b[0], w0, w1)
-    values_at_z = [ev_base(wit_lde[i]) for i in range(V)]                                   # variables (no witness columns)
+    values_at_z = [ev_base(wit_lde[i]) for i in range(V + Wc)]                              # variables, then witness columns
     values_at_z += [ev_base(setup.lde[nS + i]) for i in range(nC)]                          # constants
     values_at_z += [ev_base(setup.lde[i]) for i in range(nS)]                               # sigmas
     values_at_z.append(ev_ext(s2_lde[0], s2_lde[1]))                                        # z
     values_at_z += [ev_ext(s2_lde[2 + 2 * j], s2_lde[3 + 2 * j]) for j in range(n_partials)]
     if has_lookup:
-        values_at_z.append(ev_base(wit_lde[V]))                                             # multiplicities
+        values_at_z.append(ev_base(wit_lde[V + Wc]))                                        # multiplicities
         o = 2 + 2 * n_partials
         values_at_z += [ev_ext(s2_lde[o + 2 * i], s2_lde[o + 2 * i + 1]) for i in range(c.lookup_reps + 1)]   # A_i, B
         values_at_z += [ev_base(setup.lde[nS + nC + i]) for i in range(c.lookup_width + 1)]  # tables
@@ -326,13 +331,13 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     fri_sub = lambda lde_col: np.ascontiguousarray(lde_col[:fri_lde_factor].reshape(-1))
     b_ = lambda col: (fri_sub(col), None)
     e_ = lambda a, b: (fri_sub(a), fri_sub(b))
-    src = [b_(wit_lde[i]) for i in range(V)]
+    src = [b_(wit_lde[i]) for i in range(V + Wc)]
     src += [b_(setup.lde[nS + i]) for i in range(nC)]
     src += [b_(setup.lde[i]) for i in range(nS)]
     src.append(e_(s2_lde[0], s2_lde[1]))
     src += [e_(s2_lde[2 + 2 * j], s2_lde[3 + 2 * j]) for j in range(n_partials)]
     if has_lookup:
-        src.append(b_(wit_lde[V]))
+        src.append(b_(wit_lde[V + Wc]))
         o = 2 + 2 * n_partials
         src += [e_(s2_lde[o + 2 * i], s2_lde[o + 2 * i + 1]) for i in range(c.lookup_reps + 1)]
         src += [b_(setup.lde[nS + nC + i]) for i in range(c.lookup_width + 1)]

@@ -18,6 +18,7 @@ class VerificationKey:
         c = circuit
         self.log_n, self.n = c.log_n, c.n
         self.num_vars, self.num_gp_vars = c.num_vars, c.num_gp_vars
+        self.num_witness_cols = int(getattr(c, "num_witness_cols", 0))      # CSGeometry::num_witness_columns
         self.num_constant_cols = c.num_constant_cols
         self.lookup_reps, self.lookup_width = c.lookup_reps, c.lookup_width
         self.table_id_col = c.table_id_col
@@ -73,8 +74,8 @@ def vk_from_reference_geometry(geometry, setup_cap, general_gates, specialized_g
     return vk
 
 
-def _gate_terms_at(vk, var, con):
-    """[(selector, [terms...])] with var/con = F_p^2 values of the variable / constant polys at z."""
+def _gate_terms_at(vk, var, con, wit=()):
+    """[(selector, [terms...])] with var/con/wit = F_p^2 values of the variable / constant / witness polys at z."""
     out = []
     one = (1, 0)
     for g in vk.gates:
@@ -100,7 +101,11 @@ def _gate_terms_at(vk, var, con):
             else:                # any other evaluator, by name: the golden-pinned formulas of oracle/gates.py
                 from oracle.gates import EVALUATORS
                 width, fn = EVALUATORS[g.name][0], EVALUATORS[g.name][5]
-                terms.extend(fn(var[vb:vb + width], con[cb:]))
+                ws = getattr(g, "wit_stride", 0)
+                if ws:       # the evaluator reads witness columns, relative to its repetition (per_chunk_offset.witnesses_offset)
+                    terms.extend(fn(var[vb:vb + width], con[cb:], wit[r * ws:]))
+                else:
+                    terms.extend(fn(var[vb:vb + width], con[cb:]))
         out.append((sel, terms))
     return out
 
@@ -147,14 +152,15 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
             t.absorb(v)
     n_lookup_terms = vk.lookup_reps + 1 if has_lookup else 0
     n_lookup_polys = (vk.lookup_reps + 2 + vk.lookup_width + 1) if has_lookup else 0
-    if len(vz) != V + nC + V + 1 + n_partials + n_lookup_polys + q:
+    Wc = getattr(vk, "num_witness_cols", 0)
+    if len(vz) != V + Wc + nC + V + 1 + n_partials + n_lookup_polys + q:
         return fail("unexpected number of openings at z")
     if len(vzo) != 1 or len(v0) != n_lookup_terms:
         return fail("unexpected number of openings at z*omega / 0")
     # ---- split the openings (verifier.rs:1150-1206)
     it = iter(vz)
     take = lambda k: [next(it) for _ in range(k)]
-    var_z, con_z, sig_z = take(V), take(nC), take(V)
+    var_z, wit_z, con_z, sig_z = take(V), take(Wc), take(nC), take(V)       # variables, witness, constants, sigmas (verifier.rs:1150-1206)
     z_at_z = next(it)
     part_z = take(n_partials)
     mult_z = take(1) if has_lookup else []
@@ -209,7 +215,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
         return fail("specialized gate bookkeeping")
     # gates (verifier.rs:1640-1720)
     off = 0
-    for sel, terms in _gate_terms_at(vk, var_z, con_z):
+    for sel, terms in _gate_terms_at(vk, var_z, con_z, wit_z):
         acc = (0, 0)
         for term in terms:
             acc = eadd(acc, emul(term, a_gates[off]))
@@ -279,7 +285,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
     z_omega = escale(z, om)
     base = lambda l: [(e, 0) for e in l]
     ext = lambda l: [(l[i], l[i + 1]) for i in range(0, len(l), 2)]
-    wl = V + (1 if has_lookup else 0)
+    wl = V + Wc + (1 if has_lookup else 0)
     s2l = 2 * (1 + n_partials) + (2 * (vk.lookup_reps + 1) if has_lookup else 0)
     sul = V + nC + ((vk.lookup_width + 1) if has_lookup else 0)
     named_caps = {"witness_query": proof["witness_oracle_cap"], "stage_2_query": proof["stage_2_oracle_cap"],
@@ -297,10 +303,10 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
                 return fail("Merkle path of %s does not verify" % name)
         W, S2, Q_, SU = (query[k]["leaf_elements"] for k in ("witness_query", "stage_2_query", "quotient_query", "setup_query"))
         # source order of verifier.rs:2233-2290 == opening order: vars, constants, sigmas, z, partials, mult, A, B, tables, quotient
-        src = base(W[:V]) + base(SU[V:V + nC]) + base(SU[:V]) + ext(S2[0:2]) + ext(S2[2:2 + 2 * n_partials])
+        src = base(W[:V + Wc]) + base(SU[V:V + nC]) + base(SU[:V]) + ext(S2[0:2]) + ext(S2[2:2 + 2 * n_partials])
         if has_lookup:
             o = 2 + 2 * n_partials
-            src += base(W[V:V + 1]) + ext(S2[o:o + 2 * vk.lookup_reps]) + ext(S2[o + 2 * vk.lookup_reps:]) + base(SU[V + nC:])
+            src += base(W[V + Wc:V + Wc + 1]) + ext(S2[o:o + 2 * vk.lookup_reps]) + ext(S2[o + 2 * vk.lookup_reps:]) + base(SU[V + nC:])
         src += ext(Q_)
         x = pow(O.omega(LOGN), O.bitrev(idx, LOGN), P) * 7 % P
 

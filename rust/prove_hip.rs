@@ -208,7 +208,6 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
         let n = self.max_trace_len;
         let geometry: &CSGeometry = &vk.fixed_parameters.parameters;
         let fixed = &vk.fixed_parameters;
-        assert_eq!(geometry.num_witness_columns, 0, "non-copiable witness columns are not supported by libboojum_hip yet");
         let (lookup_width, lookup_reps) = match fixed.lookup_parameters {
             LookupParameters::NoLookup => (0u32, 0usize),
             LookupParameters::UseSpecializedColumnsWithTableIdAsConstant { width, num_repetitions, share_table_id } => {
@@ -235,8 +234,8 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
             d.num_repetitions = ev.num_repetitions_on_row as c_uint;
             d.num_terms = ev.num_quotient_terms as c_uint;
             if let GatePlacementType::MultipleOnRow { per_chunk_offset } = ev.placement_type {
-                assert_eq!(per_chunk_offset.witnesses_offset, 0);
                 d.var_stride = per_chunk_offset.variables_offset as c_uint;
+                d.wit_stride = per_chunk_offset.witnesses_offset as c_uint; // non-copiable witness columns per repetition
                 d.const_stride = per_chunk_offset.constants_offset as c_uint;
             }
             match ev.gate_purpose {
@@ -296,7 +295,7 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
             log_n: n.trailing_zeros(),
             num_vars: num_vars as c_uint,
             num_gp_vars: geometry.num_columns_under_copy_permutation as c_uint,
-            num_witness_cols: 0,
+            num_witness_cols: geometry.num_witness_columns as c_uint,
             num_constant_cols: setup_base.constant_columns.len() as c_uint,
             lookup_width,
             lookup_reps: lookup_reps as c_uint,
@@ -360,10 +359,10 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
         H: TreeHasher<F, Output = TR::CompatibleCap>,
     {
         let WitnessSet { public_inputs_values, public_inputs_with_locations, variables, witness, multiplicities } = witness_set;
-        assert!(witness.is_empty(), "non-copiable witness columns are not supported by libboojum_hip yet");
         assert_eq!(public_inputs_values.len(), public_inputs_with_locations.len());
         assert_eq!(variables.len(), setup.num_vars);
-        let vars = flatten(variables.iter().map(|p| &p.storage[..]), setup.n);
+        // the non-copiable witness columns travel right behind the variable columns (leaf = variables || witness || multiplicities)
+        let vars = flatten(variables.iter().chain(witness.iter()).map(|p| &p.storage[..]), setup.n);
         let mult = flatten(multiplicities.iter().map(|p| &p.storage[..]), setup.n);
         let publics: Vec<u64> = public_inputs_values.iter().map(|el| el.as_u64_reduced()).collect();
         let mut proof = std::ptr::null_mut();

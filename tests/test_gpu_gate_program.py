@@ -9,6 +9,7 @@ from era_boojum_amd import gate_program as GP, proof_format, synthetic as S
 from gpu_util import DevBuf, ctx, rand_gl, P
 from oracle import gates as OG
 from oracle import prover as OP
+from oracle import verifier as OV
 
 pytestmark = pytest.mark.gpu
 
@@ -329,3 +330,35 @@ def test_generated_kernels_and_interpreter_give_the_same_proof(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BJ_GATE_NO_AOT="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert np.array_equal(np.load(out), mine)
+
+
+def test_witness_columns_are_committed_opened_and_read_by_an_op_list_gate():
+    """WitnessSet::witness (witness.rs:25): non-copiable columns behind the variables in the witness oracle
+    (leaf = variables || witness || multiplicities, prover.rs:317-347), opened after the variables, outside the copy
+    permutation; ZeroCheckGate with use_witness_column_for_inversion (zero_check.rs:76-161) keeps its inverse there.  The HIP
+    proof equals the oracle prover's, the verifier restatement accepts it, and a wrong witness cell is refused."""
+    from era_boojum_amd import synthetic as S
+    c = S.sha_shaped_circuit(10, seed=5, table_bits=2, gates=S.witness_gates(60, 4, 5), mix=(0.05, 0.3, 0.3, 0.2), num_witness_cols=5)
+    S.check_satisfied(c)
+    assert c.num_witness_cols == 5 and any(getattr(g, "wit_stride", 0) for g in c.gates)
+    osetup = OP.Setup(c, 8, 16, threads=8)
+    po = OP.prove(c, osetup, 8, 16, security_level=30, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=30)
+    assert len(pg["values_at_z"]) == len(po["values_at_z"]) and len(pg["queries_per_fri_repetition"][0]["witness_query"]["leaf_elements"]) == c.num_vars + 5 + 1
+    from test_gpu_prover import _compare
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    # the inverse of a non-zero input is checked through the witness column
+    zc = next(g for g in c.gates if g.name == "ZeroCheckGate[witness]")
+    m = np.ones(c.n, dtype=bool)
+    for i, bit in enumerate(zc.path):
+        m &= c.constants[i] == (1 if bit else 0)
+    r = int(np.flatnonzero(m & (c.variables[0] != 0))[0])
+    bad_w = c.witness.copy()
+    bad_w[0, r] = (int(bad_w[0, r]) + 1) % E.P
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        gsetup.prove(variables=np.concatenate([c.variables, bad_w], axis=0))
+    gsetup.close()
