@@ -313,6 +313,9 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
                 if prev_d is not None:
                     swaps.append((base + 2, base - 1, rows))
                 prev_d = dd
+        elif g.name in ("BoundedBooleanConstraintGate", "BooleanConstraintGate"):     # over general-purpose columns: a bit per repetition
+            for r in range(g.reps):
+                variables[r * g.var_stride, rows] = rng.integers(0, 2, size=m).astype(np.uint64)
         elif g.name == "SelectionGate":
             for r in range(g.reps):
                 base = r * g.var_stride

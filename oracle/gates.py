@@ -204,6 +204,8 @@ def ev_nop(var, con):
 EVALUATORS = {
     "ConstantsAllocatorGate": (1, lambda v, k: k, 0, 1, 1, ev_constants_allocator),
     "BooleanConstraintGate": (1, lambda v, k: v, 0, 0, 1, ev_boolean),
+    # bounded_boolean_allocator.rs:74-78: the same evaluator, repetitions capped by max_on_row (the descriptor carries the count)
+    "BoundedBooleanConstraintGate": (1, lambda v, k: v, 0, 0, 1, ev_boolean),
     "U8x4FMAGate": (26, lambda v, k: v // 26, 0, 0, 2, ev_u8x4_fma),
     "Poseidon2FlattenedGate": (130, lambda v, k: 1, 0, 0, 118, ev_poseidon2_flattened),
     "DotProductGate<4>": (9, lambda v, k: v // 9, 0, 0, 1, ev_dot_product4),

@@ -136,3 +136,34 @@ def test_generated_kernels_cover_the_known_programs_and_the_committed_file_is_cu
     b = G.GateProgramBuilder()
     b.push(b.var(0) * b.var(1) - b.var(2) + 5)
     assert lib.bj_gate_program_generated(C.byref(b.build().struct)) == 0                                   # a host's own gate
+
+
+def test_captures_in_the_references_own_order_and_numbering():
+    """Op lists as `GPUDataCapture::from_evaluator` records them (tests/reference_capture.py: the call order of evaluate_once,
+    fresh temporaries from a process-wide counter), converted the way rust/prove_hip.rs converts them, give the golden-pinned
+    formulas of oracle/gates.py."""
+    import random
+    import reference_capture as RC
+    from oracle import gates as OG
+    rnd = random.Random(5)
+    e = lambda x: (x % P, 0)
+    for cap_fn, ev, nv, nc, nw in ((RC.capture_fma, OG.ev_fma, 4, 2, 0), (RC.capture_zero_check, OG.ev_zero_check, 3, 0, 0),
+                                   (RC.capture_uintx_add, OG.ev_uintx_add, 5, 1, 0),
+                                   (lambda: RC.capture_zero_check(True), OG.ev_zero_check_witness, 2, 0, 1)):
+        cap = cap_fn()
+        tmps = [dst[1] for dst, _ in cap.relations]
+        assert min(tmps) > 900 and len(set(tmps)) == len(tmps)            # global counter: sparse, never reused
+        prog = RC.to_program(cap)
+        assert prog.num_temporaries == len(cap.relations)
+        for _ in range(20):
+            var = [rnd.randrange(P) for _ in range(nv)]
+            con = [rnd.randrange(P) for _ in range(nc)]
+            wit = [rnd.randrange(P) for _ in range(nw)]
+            want = ev([e(v) for v in var], [e(c) for c in con], [e(w) for w in wit]) if nw else ev([e(v) for v in var], [e(c) for c in con])
+            assert prog.evaluate(var, con, wit) == [t[0] for t in want]
+    # the tracer of era_boojum_amd/gate_program.py and the capture agree term by term (different op order and slot numbering)
+    for cap_fn, mine in ((RC.capture_fma, G.fma_program()), (RC.capture_uintx_add, G.uintx_add_program()),
+                         (RC.capture_zero_check, G.zero_check_program())):
+        prog = RC.to_program(cap_fn())
+        var, con = [rnd.randrange(P) for _ in range(8)], [rnd.randrange(P) for _ in range(4)]
+        assert prog.evaluate(var, con) == mine.evaluate(var, con)

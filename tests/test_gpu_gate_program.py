@@ -362,3 +362,54 @@ def test_witness_columns_are_committed_opened_and_read_by_an_op_list_gate():
     with pytest.raises(E.BoojumHipError, match="not satisfied"):
         gsetup.prove(variables=np.concatenate([c.variables, bad_w], axis=0))
     gsetup.close()
+
+
+def test_captures_in_the_references_order_run_through_the_interpreter():
+    """The op lists of tests/reference_capture.py — the reference's own call order in evaluate_once, sparse temporaries from a
+    process-wide counter, converted like rust/prove_hip.rs does — evaluated on the device equal the golden-pinned formulas."""
+    import reference_capture as RC
+    for cap_fn, name, width, n_const in ((RC.capture_fma, "FmaGateInBaseFieldWithoutConstant", 4, 2), (RC.capture_zero_check, "ZeroCheckGate", 3, 0),
+                                         (RC.capture_uintx_add, "UIntXAddGate", 5, 1)):
+        prog = RC.to_program(cap_fn())
+        n_points, reps = 512, 3
+        rng = np.random.default_rng(width)
+        var = rand_gl(rng, (width * reps, n_points), noncanonical=True)
+        con = rand_gl(rng, (max(1, n_const), n_points), noncanonical=True)
+        d_var, d_con, d_out = DevBuf(var), DevBuf(con), DevBuf(nelems=reps * prog.num_terms * n_points)
+        ctx().gate_program_eval(prog, d_var.ptr, n_points, d_con.ptr, n_points, reps, width, 0, n_points, d_out.ptr)
+        got = d_out.get((reps, prog.num_terms, n_points))
+        fn = OG.EVALUATORS[name][5]
+        for i in range(0, n_points, 37):
+            for r in range(reps):
+                v = [(int(x) % P, 0) for x in var[r * width:(r + 1) * width, i]]
+                c = [(int(x) % P, 0) for x in con[:, i]]
+                assert [int(x) for x in got[r, :, i]] == [t[0] for t in fn(v, c)], (name, i, r)
+        for d in (d_var, d_con, d_out):
+            d.free()
+
+
+def test_bounded_wrappers_are_the_inner_evaluator_with_fewer_repetitions():
+    """BoundedEvaluatorWrapper / BoundedConstantsAllocatorGate / BoundedBooleanConstraintGate (bounded_wrapper.rs:60-67,
+    bounded_constant_allocator.rs:78-92, bounded_boolean_allocator.rs:74-78) only cap num_repetitions_in_geometry; the formula is
+    the inner evaluator's.  At this boundary the descriptor carries the repetition count, so a bounded gate is the same kind /
+    op list with fewer repetitions: 2 constants per row instead of 4, 5 FMA instances instead of 15, a boolean gate over 7 of
+    the general-purpose columns."""
+    from era_boojum_amd.synthetic import GateDesc, GATE_CONSTANT_ALLOCATOR, GATE_FMA, GATE_PROGRAM, GATE_NOP, GATE_REDUCTION4
+    gates = [
+        GateDesc(GATE_CONSTANT_ALLOCATOR, "BoundedConstantsAllocatorGate", 1, 2, 1, 2, 1, 1, 1, True),
+        GateDesc(GATE_FMA, "BoundedEvaluatorWrapper<FmaGateInBaseFieldWithoutConstant>", 3, 2, 4, 5, 4, 0, 1, True),
+        GateDesc(GATE_REDUCTION4, "ReductionGate<4>", 2, 4, 5, 12, 5, 0, 1, True),
+        GateDesc(GATE_PROGRAM, "BoundedBooleanConstraintGate", 2, 0, 1, 7, 1, 0, 1, True, program=GP.boolean_program()),
+        GateDesc(GATE_NOP, "NopGate", 0, 0, 0, 1, 0, 0, 0, True),
+    ]
+    c = S.sha_shaped_circuit(10, seed=8, table_bits=2, gates=gates, mix=(0.1, 0.3, 0.3, 0.2))
+    S.check_satisfied(c)
+    osetup = OP.Setup(c, 8, 16, threads=8)
+    po = OP.prove(c, osetup, 8, 16, security_level=30, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=30)
+    from test_gpu_prover import _compare
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    gsetup.close()
