@@ -189,7 +189,7 @@ __device__ __forceinline__ u64 mul_weak(u64 a, u64 b) {
         "v_mad_u64_u32 %[out], vcc, v52, -1, v[50:51]"
         : [out] "=&v"(out), [cm] "=&s"(cm), [c] "=&s"(c)
         : [a0] "v"(lo32(a)), [a1] "v"(hi32(a)), [b0] "v"(lo32(b)), [b1] "v"(hi32(b))
-        : "vcc", "v48", "v49", "v50", "v51", "v52", "v53");
+        : "vcc", "scc", "v48", "v49", "v50", "v51", "v52", "v53");   // scc: the s_andn2_b64 of the borrow path writes it
     return out;
 }
 #else

@@ -83,6 +83,31 @@ def test_deep_quotient_matches_oracle(log_n, log_lde, n_base, n_ext):
     d_b.free(); d_e.free(); d_d.free()
 
 
+@pytest.mark.timeout(240)
+def test_deep_quotient_at_a_trace_domain_point_2p25():
+    """The opening set of a public input: at = (omega_n^row, 0) over the 2^25-point LDE domain.  In one thread of this launch
+    the running product of the four denominators has a 2-power order, so the inversion chain squares 2^48 (2^96 = -1):
+    the borrow-without-carry branch of gl::mul_weak, taken in the middle of a counted loop.  (Its s_andn2_b64 writes SCC;
+    with SCC missing from the asm clobbers the loop lost its exit test and ran 2^29 more trips.)"""
+    log_n, log_lde = 22, 3
+    N = 1 << (log_n + log_lde)
+    rng = np.random.default_rng(2225)
+    col = rand_gl(rng, (1, N))
+    values, challenges = rand_gl(rng, (1, 2)), rand_gl(rng, (1, 2))
+    values[0][1] = 0
+    om = pow(0x185629dcda58878c, 1 << (32 - log_n), P)
+    at = (pow(om, 5, P), 0)
+    dst = rand_gl(rng, (2, N))
+    w0, w1 = dst[0].copy(), dst[1].copy()
+    O.deep_quotient_accumulate([(col[0], None)], values, challenges, at, log_n, log_lde, w0, w1, threads=8)
+    d_b, d_d = DevBuf(col), DevBuf(dst)
+    ctx().deep_quotient_accumulate([(d_b.ptr, None)], values, challenges, at, log_n, log_lde, d_d.ptr, d_d.ptr + 8 * N,
+                                   accumulate=True)
+    got = d_d.get((2, N))
+    assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1)
+    d_b.free(); d_d.free()
+
+
 def test_deep_then_fri_is_low_degree():
     """Size-independent property: the DEEP combination of true openings of low-degree polynomials is itself a
     low-degree codeword, so bj_fri_prove accepts it (and rejects it if one opening value is wrong)."""

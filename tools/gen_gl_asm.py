@@ -166,7 +166,7 @@ __device__ __forceinline__ u64 butterfly2_weak_asm(u64 ua, u64 va, u64 wa, u64 u
           [xa] "=&s"(xa), [ya] "=&s"(ya), [pb] "=&s"(pb), [qb] "=&s"(qb), [rb] "=&s"(rb), [xb] "=&s"(xb), [yb] "=&s"(yb)
         : [ua0] "v"(lo32(ua)), [ua1] "v"(hi32(ua)), [va0] "v"(lo32(va)), [va1] "v"(hi32(va)), [wa0] "v"(lo32(wa)), [wa1] "v"(hi32(wa)),
           [ub0] "v"(lo32(ub)), [ub1] "v"(hi32(ub)), [vb0] "v"(lo32(vb)), [vb1] "v"(hi32(vb)), [wb0] "v"(lo32(wb)), [wb1] "v"(hi32(wb))
-        : "vcc", %s);
+        : "vcc", "scc", %s);
     return xa;
 }
 // the same without the multiplication (twiddle 1):  (u, v) <- (u + v, u - v)
@@ -178,7 +178,7 @@ __device__ __forceinline__ u64 addsub2_weak_asm(u64 ua, u64 va, u64 ub, u64 vb, 
           [ya] "=&s"(ya), [pb] "=&s"(pb), [qb] "=&s"(qb), [rb] "=&s"(rb), [yb] "=&s"(yb)
         : [ua0] "v"(lo32(ua)), [ua1] "v"(hi32(ua)), [va0] "v"(lo32(va)), [va1] "v"(hi32(va)),
           [ub0] "v"(lo32(ub)), [ub1] "v"(hi32(ub)), [vb0] "v"(lo32(vb)), [vb1] "v"(hi32(vb))
-        : "vcc", %s);
+        : "vcc", "scc", %s);
     return ra;
 }
 #endif
