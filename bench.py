@@ -171,10 +171,10 @@ def main():
     # separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh) is used when it matches the launch shape
     traffic, traffic_src, valu = None, None, None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_2p22_leaf_traffic.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_2p22_leaf_traffic.json")))
         if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
             traffic = pm["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_bench_2p22_leaf_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc passes over this command"
+            traffic_src = "profiles/r02_pmc_bench_2p22_leaf_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc passes over this command"
             valu = pm.get("valu") or None
     except (OSError, KeyError, ValueError):
         pass
