@@ -250,6 +250,15 @@ def main():
                       "achieved": round(nb / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": round(nb / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nb,
                       "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
+        try:   # counters of the same two kernels from the committed rocprofv3 passes over tools/cfg2_ntt.py --cfg2-only
+            cs = json.load(open(os.path.join(ROOT, "profiles", "r02_cfg2_ntt_summary.json")))
+            out["ntt"]["pmc"] = {"source": "profiles/r02_cfg2_ntt_summary.json (tools/prof_cfg2.sh)",
+                                 "kernels": {k.split("(")[0].replace("void ", ""): {f: v[f] for f in
+                                             ("avg_ms", "SQ_INSTS_VALU", "cycles_per_valu_instruction_per_simd", "valu_busy_estimate",
+                                              "traffic_bytes", "traffic_over_algorithmic") if f in v}
+                                             for k, v in cs["kernels"].items()}}
+        except (OSError, KeyError, ValueError):
+            pass
         del src, dst
 
     if rank == 0:

@@ -195,6 +195,11 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
                           unsigned log_n, const u64 *tw, CopyPermQArgs ca, const u64 *alphas /* [n_chunks][2] */,
                           size_t Q, size_t I0 /* global index of local point 0 (multi-GPU coset shards) */, u64 *out0,
                           u64 *out1) {
+    // k_c * beta for every column, once per workgroup (a lane would otherwise spend a product per column on k_c * x first)
+    extern __shared__ u64 kbeta[];   // [V][2], sized by the launcher
+    for (unsigned t = threadIdx.x; t < 2 * V; t += blockDim.x)
+        kbeta[t] = gl::mul(non_res[t >> 1], (t & 1) ? ca.beta.c1 : ca.beta.c0);
+    __syncthreads();
     const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= Q) return;
     const size_t n = (size_t)1 << log_n;
@@ -224,12 +229,11 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
         gl::e2 rhs = (j == 0) ? zv
                               : gl::e2{gl::canon(stage2[((size_t)2 * j) * s2_stride + I]), gl::canon(stage2[((size_t)2 * j + 1) * s2_stride + I])};
         for (unsigned c = j * chunk; c < (j + 1) * chunk && c < V; c++) {
-            u64 w = gl::canon(vars[(size_t)c * var_stride + I]);
+            const u64 wg = gl::add(gl::canon(vars[(size_t)c * var_stride + I]), ca.gamma.c0);   // w + gamma_0, shared by both factors
             u64 sg = gl::canon(sigmas[(size_t)c * sig_stride + I]);
-            gl::e2 d{gl::add(gl::add(gl::mul(sg, ca.beta.c0), w), ca.gamma.c0), gl::add(gl::mul(sg, ca.beta.c1), ca.gamma.c1)};
+            gl::e2 d{gl::add(gl::mul(sg, ca.beta.c0), wg), gl::add(gl::mul(sg, ca.beta.c1), ca.gamma.c1)};
             lhs = gl::e2_mul(lhs, d);
-            u64 kx = gl::mul(x, non_res[c]);
-            gl::e2 nm{gl::add(gl::add(gl::mul(kx, ca.beta.c0), w), ca.gamma.c0), gl::add(gl::mul(kx, ca.beta.c1), ca.gamma.c1)};
+            gl::e2 nm{gl::add(gl::mul(x, kbeta[2 * c]), wg), gl::add(gl::mul(x, kbeta[2 * c + 1]), ca.gamma.c1)};
             rhs = gl::e2_mul(rhs, nm);
         }
         gl::e2 t = gl::e2_sub(lhs, rhs);
@@ -299,7 +303,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
         }
     }
     const unsigned n_chunks = (V + chunk - 1) / chunk;
-    hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_vars, var_stride,
+    hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 16, s, d_vars, var_stride,
                        d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
                        d_alphas_cp, Q, I0, d_out0, d_out1);
 }

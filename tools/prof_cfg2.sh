@@ -7,14 +7,14 @@ export TMPDIR=/tmp
 cd /tmp
 out=$repo/gpurun_out/prof_cfg2_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats -f csv -d $out/kt -o t -- python $repo/tools/cfg2_ntt.py > $out/stdout_kt.txt 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $out/kt -o t -- python $repo/tools/cfg2_ntt.py --cfg2-only > $out/stdout_kt.txt 2>&1
 f=$(find $out/kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $repo/gpurun_out/cfg2_${tag}_kernel_stats.csv && head -8 $f
 for pass in "sq1:SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "sq2:SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU" "tcc:FETCH_SIZE" "tccw:WRITE_SIZE"; do
   name=${pass%%:*}; ctrs=${pass#*:}
-  rocprofv3 --pmc $ctrs -f csv -d $out/$name -o p -- python $repo/tools/cfg2_ntt.py > $out/stdout_$name.txt 2>&1
+  rocprofv3 --pmc $ctrs -f csv -d $out/$name -o p -- python $repo/tools/cfg2_ntt.py --cfg2-only > $out/stdout_$name.txt 2>&1
   f=$(find $out/$name -name '*counter_collection.csv' | head -1)
   [ -n "$f" ] && python3 $repo/tools/pmc_summarize.py $f > $repo/gpurun_out/cfg2_${tag}_pmc_$name.csv
 done
 cd $repo
 rm -rf $out
-cat gpurun_out/cfg2_${tag}_pmc_*.csv | grep -E "Kernel|ntt_" | cut -c1-260
+python3 tools/cfg2_summary.py $tag > gpurun_out/cfg2_${tag}_summary.json; cat gpurun_out/cfg2_${tag}_summary.json
