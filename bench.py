@@ -298,10 +298,18 @@ def main():
         else:
             csmall = S.sha_shaped_circuit(args.cpu_log_n, seed=42, table_bits=4 if args.cpu_log_n >= 14 else 2)
         osetup = OP.Setup(csmall, args.fri_lde, args.cap, threads=threads)
+        quota = None                                  # cgroup CPU quota of this container, in cores (None = unlimited / unknown)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else round(float(q) / float(per), 2)
+        except (OSError, ValueError):
+            pass
+        cpu0 = sum(os.times()[:2])
         c0 = time.perf_counter()
         OP.prove(csmall, osetup, args.fri_lde, args.cap, security_level=args.security, threads=threads,
                  transcript_kind=setup.transcript_kind if setup.transcript_kind in (1, 2) else 1)
         t_cpu = time.perf_counter() - c0
+        busy_cores = (sum(os.times()[:2]) - cpu0) / t_cpu        # CPU seconds per wall second: the cores the proof actually kept busy
         del osetup, csmall
         # the oracle's C primitives at the bench's own sizes, all host cores (benches/benchmarks.rs:479-520 and :73-79)
         a = rng.integers(0, E.P, size=(256, 1 << 20), dtype=np.uint64)
@@ -319,7 +327,7 @@ def main():
         perms = (1 << tl_log) * 12 + (1 << tl_log) - args.cap
         del cols
         out["cpu_baseline"] = {"value": round((1 << args.cpu_log_n) / t_cpu, 1), "unit": "rows/s", "cores": threads, "kind": "port",
-                               "cpu_model": cpu_model, "affinity_cpus": affinity,
+                               "cpu_model": cpu_model, "affinity_cpus": affinity, "cgroup_quota_cores": quota, "busy_cores_measured": round(busy_cores, 1),
                                "sample": "one proof of the same circuit at 2^%d rows by the oracle prover (C bulk ops + python "
                                          "orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (args.cpu_log_n, t_cpu),
                                "micro": {"ntt_2p20_x256": {"ms": round(t_ntt * 1e3, 1), "GBps": round(16.0 * 256 * (1 << 20) / t_ntt / 1e9, 2),

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "bj_transcript_destroy": (None, [C.c_void_p]),
     "bj_transcript_absorb_cap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_ctx_set_tree_hasher": (C.c_int, [C.c_void_p, C.c_int]),
+    "bj_ctx_release_workspace": (C.c_int, [C.c_void_p]),
     "bj_transcript_absorb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_transcript_challenge": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "bj_transcript_query_index": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_uint64)]),
@@ -185,6 +186,10 @@ class Context:
 
     def sync(self):
         self._check(self._lib.bj_sync(self._h))
+
+    def release_workspace(self):
+        """Give the proof workspace (arena, NTT scratch, host-witness staging) back to the device allocator."""
+        self._check(self._lib.bj_ctx_release_workspace(self._h))
 
     def malloc(self, nbytes):
         p = C.c_void_p()

@@ -192,6 +192,23 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     delete ctx;
 }
 
+int bj_ctx_release_workspace(bj_ctx *ctx) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (ctx->in_proof) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ctx_release_workspace: a proof is running");
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) BJ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->arena) BJ_HIP(ctx, hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_elems = ctx->arena_off = 0;
+    if (ctx->d_scratch) BJ_HIP(ctx, hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_elems = 0;
+    if (ctx->wit_stage) BJ_HIP(ctx, hipFree(ctx->wit_stage));
+    ctx->wit_stage = nullptr;
+    ctx->wit_stage_elems = 0;
+    return BJ_OK;
+}
+
 int bj_ctx_set_stream(bj_ctx *ctx, void *hip_stream) {
     if (!ctx) return BJ_ERR_INVALID_ARG;
     if (ctx->ring_inflight) {   // staged copies are ordered on the old stream

@@ -53,6 +53,11 @@ void bj_ctx_destroy(bj_ctx *ctx);
 int bj_ctx_set_stream(bj_ctx *ctx, void *hip_stream);
 const char *bj_last_error(const bj_ctx *ctx);
 int bj_sync(bj_ctx *ctx);
+/* A context keeps the proof workspace (one bump-allocated arena sized by the largest proof so far, NTT scratch, the staging
+ * area of bj_prove's host witness) across proofs, the way the reference's prover reuses its `Vec`s inside one `prove_cpu_basic`
+ * call (prover.rs:153-168) but no further.  A host that moves from large circuits to small ones gives the memory back with this
+ * call; twiddle tables and setups stay.  Not allowed while a proof is running. */
+int bj_ctx_release_workspace(bj_ctx *ctx);
 
 /* Device memory helpers for hosts that do not bring their own allocator (the reference threads `A: GoodAllocator`,
  * src/cs/traits/mod.rs:13, through every buffer for exactly this purpose). */

@@ -180,6 +180,12 @@ def test_repeated_proofs_are_identical_and_do_not_leak_device_memory():
         assert np.array_equal(buf, first), i
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
+    # bj_ctx_release_workspace hands the arena back (more free memory than while it was held) and the next proof, which
+    # rebuilds it, is the same bytes again
+    ctx().release_workspace()
+    assert torch.cuda.mem_get_info()[0] > free0
+    buf, _ = gsetup.prove()
+    assert np.array_equal(buf, first)
     gsetup.close()
 
 
@@ -221,3 +227,21 @@ def test_prover_checks_public_values_against_the_witness():
     buf, _ = gsetup.prove()                                  # and the setup is still usable
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), proof_format.parse(buf, security_level=20))
     gsetup.close()
+
+
+@pytest.mark.timeout(300)
+def test_proof_at_2p23_rows_is_accepted_by_the_verifier_restatement():
+    """BASELINE config 5's size (2^23 rows, LDE 8 => 2^26-point oracles): the verifier restatement accepts the proof, public
+    inputs included (their DEEP opening sets run over all 2^26 points; one of those launches lost a loop's exit test to an
+    undeclared SCC write until round 2, tests/test_gpu_openings.py)."""
+    c = S.sha_shaped_circuit(23, seed=42, table_bits=4)
+    setup = E.ProverSetup(ctx(), c, 8, 16, 100)
+    d_vars, d_mult = ctx().upload(c.variables), ctx().upload(c.multiplicities)
+    buf, stage_ms = setup.prove_dev(d_vars, d_mult)
+    assert sum(v for k, v in stage_ms.items() if k != "witness_tree_leaf_kernel") < 5000.0      # ms; the regression took 500 s
+    pg = proof_format.parse(buf, security_level=100)
+    assert OV.verify(OV.VerificationKey(c, setup.cap(), 8, 16), pg, verbose=True)
+    setup.close()
+    ctx().free(d_vars)
+    ctx().free(d_mult)
+    ctx().release_workspace()      # ~150 GB of arena: give it back before the multi-process tests share this GPU
