@@ -16,6 +16,8 @@
 #include "gl.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 using gl::u64;
 using gl::u32;
 
@@ -70,10 +72,11 @@ __device__ __forceinline__ void load_step_twiddles(u64 (&tw)[15], const u64 *__r
 // residues (any u64) from the load of the first pass to the store of the last one: butterflies run two at a time through
 // gl::butterfly2_weak, nothing is canonicalised in between (the last pass does it once per element when it stores).
 // tw: the step's 15 twiddles, in registers (array) or in LDS (pointer) — indexed by constants after unrolling either way.
-template <bool UNIT_FIRST>
+// FIRST_S = 2 runs only the last two of the four rounds (the local pass after a front pass that has already done the other two).
+template <bool UNIT_FIRST, int FIRST_S = 0>
 __device__ __forceinline__ void radix16(u64 (&x)[16], const u64 *tw) {
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
+    for (int s = FIRST_S; s < 3; s++) {
         const int half = 8 >> s;
 #pragma unroll
         for (int g = 0; g < (1 << s); g++) {
@@ -110,7 +113,9 @@ __device__ __forceinline__ void stage_uniform_twiddles(u64 *lds_tw, const u64 *_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <bool SCALED>
+// ROUNDS = 12, or 10: the same kernel without the first two rounds of step A (a 4096-element chunk is then four independent
+// 1024-point sub-transforms; the rounds that remain are exactly rounds log_n-10 .. log_n-1, with the twiddle indices unchanged)
+template <bool SCALED, int ROUNDS = 12>
 __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args a) {
     __shared__ u64 lds[LDS_ELEMS + 16 + 16 * 16];
     u64 *lds_tw = lds + LDS_ELEMS;
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         u64 x[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = ld_off(src + j * 256, t * 8u);
-        radix16<false>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
+        radix16<false, ROUNDS == 12 ? 0 : 2>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
         __syncthreads();
@@ -255,6 +260,69 @@ __global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// The FIRST four rounds (strides n/2 .. n/16) of a transform with 14 + 4k rounds, for every coset at once: a lane owns the 16
+// elements {i + m * n/16} of two adjacent indices i (16-byte accesses, 1 KB per wave instruction), reads them ONCE and emits
+// every coset from them (an LDE reads its monomials once per column, not once per coset).  The 15 twiddles T[g] * sc[r] of
+// these rounds are uniform per coset and live in LDS.  No tile and no barrier in the data path.  The pass is bound by its
+// 8 * (1 + cosets) * n bytes per column, so its butterflies ride on VALU slots that would idle anyway: the local pass behind
+// it then runs 10 rounds instead of 12 (ntt_local12_kernel<., 10>).
+template <bool SCALED, int V>
+__global__ void __launch_bounds__(256) ntt_first4_kernel(R16Args a, unsigned n_cosets) {
+    __shared__ u64 tws[64 * 16];                          // [coset][15 (+1 pad)]
+    const size_t n = (size_t)1 << a.log_n, sl = n >> 4;
+    for (u32 t = threadIdx.x; t < n_cosets * 15; t += blockDim.x) {
+        const u32 c = t / 15, i = t % 15;
+        const int r = 31 - __clz(i + 1);
+        const int g = (int)(i + 1) - (1 << r);
+        u64 v = a.tw[g];
+        if (SCALED) v = gl::mul(v, a.round_scale[(size_t)c * 32 + r]);
+        tws[c * 16 + i] = v;
+    }
+    __syncthreads();
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (i >= sl) return;
+    const u64 *src = a.in + (size_t)blockIdx.y * a.in_col_stride + i;
+    u64 *dst = a.out + (size_t)blockIdx.y * a.out_col_stride + i;
+    auto load = [](const u64 *p, u64 &lo, u64 &hi) {
+        if (V == 2) {
+            const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(p);
+            lo = q.x;
+            hi = q.y;
+        } else {
+            lo = p[0];
+        }
+    };
+    u64 in0[16], in1[V == 2 ? 16 : 1];
+    if (a.in_coset_stride == 0) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) load(src + (size_t)m * sl, in0[m], in1[V == 2 ? m : 0]);
+    }
+    for (unsigned c = 0; c < n_cosets; c++) {
+        u64 x0[16], x1[V == 2 ? 16 : 1];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            if (a.in_coset_stride == 0) {
+                x0[m] = in0[m];
+                if (V == 2) x1[m] = in1[m];
+            } else {
+                load(src + (size_t)c * a.in_coset_stride + (size_t)m * sl, x0[m], x1[V == 2 ? m : 0]);
+            }
+        }
+        const u64 *tw = tws + c * 16;
+        radix16<!SCALED>(x0, tw);   // unscaled: T[0] = 1, the first round is additions only
+        if constexpr (V == 2) radix16<!SCALED>(x1, tw);
+        u64 *o = dst + (size_t)c * n;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            if (V == 2)
+                *reinterpret_cast<ulonglong2 *>(o + (size_t)m * sl) = make_ulonglong2(x0[m], x1[V == 2 ? m : 0]);
+            else
+                o[(size_t)m * sl] = x0[m];
+        }
+    }
+}
+
 static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_cosets) {
     // amortise the per-workgroup twiddle preparation over several columns, but keep >= ~4096 workgroups in flight
 #ifndef BJ_R16_CPB
@@ -267,15 +335,20 @@ static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_
 
 void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n,
                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
-                        size_t out_col_stride, hipStream_t s) {
+                        size_t out_col_stride, unsigned rounds, hipStream_t s) {
     unsigned tiles = 1u << (log_n - 12);
     unsigned cpb = pick_cols_per_block(tiles, n_cols, n_cosets);
     R16Args a{in, out, tw, round_scale, log_n, log_n - 12, n_cols, cpb, in_col_stride, in_coset_stride, out_col_stride};
     dim3 grid(tiles, (n_cols + cpb - 1) / cpb, n_cosets);
-    if (round_scale)
-        hipLaunchKernelGGL(ntt_local12_kernel<true>, grid, dim3(256), 0, s, a);
+    if (rounds == 10) {
+        if (round_scale)
+            hipLaunchKernelGGL((ntt_local12_kernel<true, 10>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((ntt_local12_kernel<false, 10>), grid, dim3(256), 0, s, a);
+    } else if (round_scale)
+        hipLaunchKernelGGL((ntt_local12_kernel<true, 12>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(ntt_local12_kernel<false>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((ntt_local12_kernel<false, 12>), grid, dim3(256), 0, s, a);
 }
 
 void launch_ntt_strided8(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
@@ -306,6 +379,28 @@ void launch_ntt_strided4(const u64 *in, u64 *out, const u64 *tw, const u64 *roun
         hipLaunchKernelGGL((ntt_strided4_kernel<false, true>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((ntt_strided4_kernel<false, false>), grid, dim3(256), 0, s, a);
+}
+
+// first four rounds of all cosets; the caller has checked first4_applicable()
+void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
+                       unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s) {
+    R16Args a{in, out, tw, round_scale, log_n, 0, n_cols, 1, in_col_stride, in_coset_stride, out_col_stride};
+    const size_t sl = ((size_t)1 << log_n) >> 4;
+    // two adjacent indices per lane (16-byte accesses, 206 VGPRs: 2 waves per SIMD) or one (8-byte accesses, 4 waves)
+    static const int v = [] {
+        const char *e = getenv("BJ_NTT_FIRST4_V");
+        return e && e[0] == '1' ? 1 : 2;
+    }();
+    dim3 grid((unsigned)((sl / v + 255) / 256), n_cols, 1);
+    if (v == 2) {
+        if (round_scale)
+            hipLaunchKernelGGL((ntt_first4_kernel<true, 2>), grid, dim3(256), 0, s, a, n_cosets);
+        else
+            hipLaunchKernelGGL((ntt_first4_kernel<false, 2>), grid, dim3(256), 0, s, a, n_cosets);
+    } else if (round_scale)
+        hipLaunchKernelGGL((ntt_first4_kernel<true, 1>), grid, dim3(256), 0, s, a, n_cosets);
+    else
+        hipLaunchKernelGGL((ntt_first4_kernel<false, 1>), grid, dim3(256), 0, s, a, n_cosets);
 }
 
 }  // namespace bj

@@ -245,6 +245,8 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad lookup parameters");
     if (c->num_vars < c->num_gp_vars + c->lookup_width * c->lookup_reps || !c->non_residues)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad column counts");
+    if (c->num_vars > 4096)   // the copy-permutation quotient keeps k_c * beta of every column in LDS (16 bytes per column)
+        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: %u copiable columns, at most 4096 are supported", c->num_vars);
     unsigned n_chunks = (c->num_vars + c->quotient_degree - 1) / c->quotient_degree;
     if (n_chunks < 2) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: a single copy-permutation chunk is not supported");
     if (comm && comm->world > 1) {
@@ -529,6 +531,13 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         int saved;
         ~HasherGuard() { c->hasher = saved; }
     } hasher_guard{ctx, ctx->hasher};
+    struct CopyDrain {   // bj_prove: whatever way the proof ends, no queued copy may still read the caller's witness afterwards
+        bj_ctx *c;
+        bool active;
+        ~CopyDrain() {
+            if (active && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        }
+    } copy_drain{ctx, hw != nullptr};
     ctx->hasher = (int)S->hasher;
     if (!S->pub_cols.empty()) {   // the values that go into the transcript must be the cells they claim to be (witness.rs:21-27)
         std::vector<u64> cells(S->pub_cols.size());

@@ -164,8 +164,8 @@ int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride
     if (int rc = bj::bind(ctx)) return rc;
     if (!d_vars || !d_sigmas || !d_stage2 || !h_non_residues || !h_beta || !h_gamma || !h_alphas || !d_out0 || !d_out1)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_quotient_copy_perm: null pointer");
-    if (num_vars == 0 || chunk == 0 || log_n > 30 || log_lde > 6)
-        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_quotient_copy_perm: bad geometry (LDE factor at most 64)");
+    if (num_vars == 0 || num_vars > 4096 || chunk == 0 || log_n > 30 || log_lde > 6)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_quotient_copy_perm: bad geometry (1..4096 columns, LDE factor at most 64)");
     const size_t n = (size_t)1 << log_n;
     if (first_point + num_points > (n << log_lde)) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_quotient_copy_perm: points past the LDE domain");
     if (var_stride < num_points || sig_stride < num_points || stage2_stride < num_points)
