@@ -122,12 +122,36 @@ def main():
         # (also the automatic choice for gloo, where several ranks may share a GPU, which RCCL refuses).
         want = os.environ.get("BJ_BENCH_TRANSPORT", "rccl" if backend == "nccl" else "torch")
         if want == "rccl":
+            # the unique id travels through torch.distributed; then a self-test before trusting the transport with a proof:
+            # every rank contributes 1 KiB of its own pattern and checks the gathered block.  Whatever happens on a rank, ALL
+            # ranks meet in one all-reduce (MIN) and keep the transport only if every one of them succeeded.
+            ok_local, err = 0, None
             try:
                 box = [E.binding.rccl_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm, transport = E.RcclComm(ctx, box[0], rank, world), "in-library RCCL all-gather on the proof stream"
-            except Exception as e:   # never lose the run to the transport: fall back to the host-callback one
-                print("in-library RCCL transport unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+            except Exception as e:
+                box, err = [None], e
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    comm = E.RcclComm(ctx, box[0], rank, world)
+                    mine = torch.full((128,), 0x0101010101010101 * (rank + 1), dtype=torch.int64, device=dev)
+                    got = torch.zeros((world, 128), dtype=torch.int64, device=dev)
+                    torch.cuda.synchronize()
+                    comm.all_gather(mine.data_ptr(), got.data_ptr(), 1024, stream=torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                    want_blk = (torch.arange(1, world + 1, dtype=torch.int64, device=dev) * 0x0101010101010101).view(world, 1)
+                    ok_local = 1 if bool((got == want_blk).all()) else 0
+                    if not ok_local:
+                        err = "self-test of the in-library all-gather returned wrong data"
+                except Exception as e:
+                    err = e
+            flag = torch.tensor([ok_local], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                transport = "in-library RCCL all-gather on the proof stream"
+            else:   # never lose the run to the transport: fall back to the host-callback one
+                print("rank %d: in-library RCCL transport not used (%s); using torch.distributed" % (rank, err), file=sys.stderr)
+                comm = None
         if comm is None:
             comm, transport = E.TorchComm(ctx), "torch.distributed all_gather_into_tensor through the bj_comm host callback"
     setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security, comm=comm, transcript=args.transcript)

@@ -581,6 +581,16 @@ class RcclComm:
         self._lib.bj_comm_rccl_stats(C.byref(self.struct), C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def all_gather(self, d_send, d_recv, nbytes, stream=None):
+        """One all-gather through the transport's own entry (bj_comm.all_gather_stream when `stream` is given, the blocking
+        bj_comm.all_gather otherwise): what the sharded prover calls, exposed for self-tests."""
+        if stream is not None:
+            rc = self.struct.all_gather_stream(self.struct.user, C.c_void_p(d_send), C.c_void_p(d_recv), nbytes, C.c_void_p(stream))
+        else:
+            rc = self.struct.all_gather(self.struct.user, C.c_void_p(d_send), C.c_void_p(d_recv), nbytes)
+        if rc != 0:
+            raise BoojumHipError("RcclComm.all_gather failed (%d)" % rc)
+
     def close(self):
         if self.struct.user:
             self._lib.bj_comm_rccl_destroy(C.byref(self.struct))

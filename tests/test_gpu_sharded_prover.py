@@ -110,6 +110,11 @@ def test_in_library_rccl_transport_world_1():
     assert comm.struct.all_gather(comm.struct.user, C.c_void_p(d_s.ptr), C.c_void_p(d_r2.ptr), src.nbytes) == 0
     assert np.array_equal(d_r2.get(), src)
     assert comm.calls == 2 and comm.bytes == 2 * src.nbytes
+    d_r3 = DevBuf(nelems=src.size)          # the same through the binding's helper (bench.py's transport self-test)
+    comm.all_gather(d_s.ptr, d_r3.ptr, src.nbytes, stream=0)
+    ctx().sync()
+    assert np.array_equal(d_r3.get(), src)
+    d_r3.free()
     # a setup created through the sharded entry point with this communicator proves like the plain one
     c = S.sha_shaped_circuit(9, seed=2, table_bits=2)
     a = E.ProverSetup(ctx(), c, 8, 16, 20, comm=comm)
