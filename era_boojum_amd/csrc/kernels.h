@@ -21,7 +21,9 @@ void launch_field_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n, hip
 // ntt_r16.hip (register-radix-16 passes)
 void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n,
                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
-                        size_t out_col_stride, unsigned rounds /* 12, or 10 behind launch_ntt_first4 */, hipStream_t s);
+                        size_t out_col_stride, unsigned rounds /* 12, or 10 / 9 behind launch_ntt_first4 / first5 */, hipStream_t s);
+void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
+                       unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s);
 void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
                        unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s);
 void launch_ntt_strided8(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,

@@ -303,16 +303,33 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
         return;
     }
     unsigned front = log_n - 12;
-    // 14 + 4k rounds: four rounds in the coset-expanding front pass (bound by its traffic whatever it computes) and ten in the
-    // local pass, instead of two and twelve — the same number of passes, two rounds of butterflies moved into idle VALU slots
-    static const bool no_first4 = getenv("BJ_NTT_NO_FIRST4") != nullptr;
+    // 14 + 4k and 15 + 4k rounds: the coset-expanding front pass is bound by its traffic whatever it computes, so it takes four
+    // or five rounds (ntt_first4 / ntt_first5) and the local pass runs ten or nine instead of twelve — the same number of passes,
+    // butterflies moved into idle VALU slots.  13 + 4k rounds keep the remainder pass of one round.
+    static const int front_policy = [] {
+        const char *e = getenv("BJ_NTT_FRONT");      // 0: remainder passes only (the round-1 plan); 5: first5 wherever it applies; default: measured best
+        return e ? atoi(e) : 4;
+    }();
     const bool aligned16 = ((uintptr_t)d_in % 16) == 0 && ((uintptr_t)d_out % 16) == 0 && in_col_stride % 2 == 0 &&
                            out_col_stride % 2 == 0;
-    if (front % 4 == 2 && !no_first4 && aligned16 && n_cosets <= 64) {   // log_n >= 14: the slice n/16 is a multiple of 512
-        launch_ntt_first4(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
-                          out_col_stride, s);
-        advance(4);
-        front = log_n - 14;
+    unsigned F = 0, Lr = 12;
+    if (n_cosets <= 64 && front_policy) {
+        if (front % 4 == 2) {          // 2^22: 4 + 8 + 10 measured 283.5 ms per proof, 5 + 8 + 9 284.5 (2 + 8 + 12: 284.7)
+            if (front_policy < 5 && aligned16) F = 4, Lr = 10;
+            else F = 5, Lr = 9;
+        } else if (front % 4 == 3) {   // 2^23: 5 + 8 + 10 measured 560.0 ms per proof against 565.4 for 3 + 8 + 12
+            F = 5, Lr = 10;
+        }
+    }
+    if (F) {
+        if (F == 5)
+            launch_ntt_first5(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
+                              out_col_stride, s);
+        else
+            launch_ntt_first4(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
+                              out_col_stride, s);
+        advance(F);
+        front = log_n - F - Lr;
         while (front >= 8) {
             launch_ntt_strided8(src, d_out, d_tw, d_round_scale, log_n, r0, n_cols, n_cosets, src_col_stride,
                                 src_coset_stride, out_col_stride, s);
@@ -325,7 +342,7 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
             advance(4);
         }
         launch_ntt_local12(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
-                           out_col_stride, 10, s);
+                           out_col_stride, Lr, s);
         return;
     }
     if (front % 4) {

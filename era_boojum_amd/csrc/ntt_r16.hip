@@ -113,8 +113,8 @@ __device__ __forceinline__ void stage_uniform_twiddles(u64 *lds_tw, const u64 *_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ROUNDS = 12, or 10: the same kernel without the first two rounds of step A (a 4096-element chunk is then four independent
-// 1024-point sub-transforms; the rounds that remain are exactly rounds log_n-10 .. log_n-1, with the twiddle indices unchanged)
+// ROUNDS = 12, or 10 / 9: the same kernel without the first two / three rounds of step A (a 4096-element chunk is then four /
+// eight independent sub-transforms; the rounds that remain are exactly the last ROUNDS rounds, with the twiddle indices unchanged)
 template <bool SCALED, int ROUNDS = 12>
 __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args a) {
     __shared__ u64 lds[LDS_ELEMS + 16 + 16 * 16];
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         u64 x[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = ld_off(src + j * 256, t * 8u);
-        radix16<false, ROUNDS == 12 ? 0 : 2>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
+        radix16<false, 12 - ROUNDS>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
         __syncthreads();
@@ -323,6 +323,67 @@ __global__ void __launch_bounds__(256) ntt_first4_kernel(R16Args a, unsigned n_c
     }
 }
 
+// The first FIVE rounds the same way, one index per lane (32 elements {i + m * n/32} in registers): round 0 pairs the two
+// halves of the register file, rounds 1..4 are one radix-16 step on each half with that half's twiddles.
+template <bool SCALED>
+__global__ void __launch_bounds__(256) ntt_first5_kernel(R16Args a, unsigned n_cosets) {
+    __shared__ u64 tws[64 * 40];                          // [coset]: [0] round 0; [8 + 16 h + i] step twiddles of half h
+    const size_t n = (size_t)1 << a.log_n, sl = n >> 5;
+    for (u32 t = threadIdx.x; t < n_cosets * 31; t += blockDim.x) {
+        const u32 c = t / 31, i = t % 31;
+        const int r = 31 - __clz(i + 1);
+        const int g = (int)(i + 1) - (1 << r);
+        u64 v = a.tw[g];
+        if (SCALED) v = gl::mul(v, a.round_scale[(size_t)c * 32 + r]);
+        if (r == 0) {
+            tws[c * 40] = v;
+        } else {
+            const int st = r - 1, h = g >> st, gg = g & ((1 << st) - 1);
+            tws[c * 40 + 8 + 16 * h + (1 << st) - 1 + gg] = v;
+        }
+    }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sl) return;
+    const u64 *src = a.in + (size_t)blockIdx.y * a.in_col_stride + i;
+    u64 *dst = a.out + (size_t)blockIdx.y * a.out_col_stride + i;
+    u64 in[32];
+    if (a.in_coset_stride == 0) {
+#pragma unroll
+        for (int m = 0; m < 32; m++) in[m] = src[(size_t)m * sl];
+    }
+    for (unsigned c = 0; c < n_cosets; c++) {
+        u64 lo[16], hi[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            if (a.in_coset_stride == 0) {
+                lo[m] = in[m];
+                hi[m] = in[m + 16];
+            } else {
+                lo[m] = src[(size_t)c * a.in_coset_stride + (size_t)m * sl];
+                hi[m] = src[(size_t)c * a.in_coset_stride + (size_t)(m + 16) * sl];
+            }
+        }
+        const u64 *tw = tws + c * 40;
+        const u64 w0 = tw[0];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            if (SCALED)
+                gl::butterfly2_weak(lo[j], hi[j], w0, lo[j + 1], hi[j + 1], w0);
+            else
+                gl::addsub2_weak(lo[j], hi[j], lo[j + 1], hi[j + 1]);      // T[0] = 1
+        }
+        radix16<false>(lo, tw + 8);
+        radix16<false>(hi, tw + 24);
+        u64 *o = dst + (size_t)c * n;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            o[(size_t)m * sl] = lo[m];
+            o[(size_t)(m + 16) * sl] = hi[m];
+        }
+    }
+}
+
 static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_cosets) {
     // amortise the per-workgroup twiddle preparation over several columns, but keep >= ~4096 workgroups in flight
 #ifndef BJ_R16_CPB
@@ -345,6 +406,11 @@ void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round
             hipLaunchKernelGGL((ntt_local12_kernel<true, 10>), grid, dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((ntt_local12_kernel<false, 10>), grid, dim3(256), 0, s, a);
+    } else if (rounds == 9) {
+        if (round_scale)
+            hipLaunchKernelGGL((ntt_local12_kernel<true, 9>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((ntt_local12_kernel<false, 9>), grid, dim3(256), 0, s, a);
     } else if (round_scale)
         hipLaunchKernelGGL((ntt_local12_kernel<true, 12>), grid, dim3(256), 0, s, a);
     else
@@ -401,6 +467,17 @@ void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
         hipLaunchKernelGGL((ntt_first4_kernel<true, 1>), grid, dim3(256), 0, s, a, n_cosets);
     else
         hipLaunchKernelGGL((ntt_first4_kernel<false, 1>), grid, dim3(256), 0, s, a, n_cosets);
+}
+
+void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
+                       unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s) {
+    R16Args a{in, out, tw, round_scale, log_n, 0, n_cols, 1, in_col_stride, in_coset_stride, out_col_stride};
+    const size_t sl = ((size_t)1 << log_n) >> 5;
+    dim3 grid((unsigned)((sl + 255) / 256), n_cols, 1);
+    if (round_scale)
+        hipLaunchKernelGGL(ntt_first5_kernel<true>, grid, dim3(256), 0, s, a, n_cosets);
+    else
+        hipLaunchKernelGGL(ntt_first5_kernel<false>, grid, dim3(256), 0, s, a, n_cosets);
 }
 
 }  // namespace bj
