@@ -16,8 +16,9 @@ bj_prove, i.e. with the witness in (pinned) host memory and its PCIe transfer in
 `value` = constraints/sec := trace rows proved / wall seconds.  It fits one GPU, so N = 1 proves it on one MI355X; with
 N > 1 the SAME proof is sharded over the N GPUs by LDE cosets (bj_setup_create_sharded: GPU g owns cosets
 [g*8/N, (g+1)*8/N) = a contiguous range of Merkle leaves; cap fragments, the quotient evaluations, the first folded FRI
-layer and the query openings are all-gathered over RCCL) and every rank ends with the identical proof: STRONG scaling
-(total work fixed).  `--mode replicas` instead lets every rank prove its own instance (weak scaling, no collective);
+layer and the query openings are all-gathered over RCCL — by the library itself on the proof's stream (comm_rccl.hip) after a
+self-test of that transport that all ranks agree on; otherwise through the torch.distributed callback) and every rank ends with
+the identical proof: STRONG scaling (total work fixed).  `--mode replicas` instead lets every rank prove its own instance (weak scaling, no collective);
 `--log-n 20` is BASELINE's cfg3.
 
 Extra objects on the JSON line:
@@ -28,7 +29,8 @@ Extra objects on the JSON line:
   stages_ms     per-round wall time, named after the reference's log lines.
   cpu_baseline  the C/Python oracle prover (restated reference CPU algorithm) on this box's host cores, on a smaller
                 instance of the same circuit (bounded to ~10-30 s), in rows/s; `micro` times the oracle's C primitives on all
-                cores at the bench's own sizes (NTT 2^20 x 256, Poseidon2 tree 2^23 x 93: benches/benchmarks.rs:479-520, 73-79).
+                cores at the bench's own sizes (NTT 2^20 x 256, Poseidon2 tree 2^23 x 93: benches/benchmarks.rs:479-520, 73-79);
+                `cores` = threads started, `cgroup_quota_cores` / `busy_cores_measured` = what the container actually gave them.
 """
 import argparse
 import json
