@@ -14,6 +14,7 @@ struct DevProgram {
     DevRelation *d_rel = nullptr;
     uint32_t *d_writes = nullptr;
     unsigned n_rel = 0, n_writes = 0, n_tmp = 0;
+    bool reads_witness = false;   // the program has BJ_IDX_WITNESS_POLY operands
     uint64_t hash = 0, check = 0;   // two fingerprints of the program's content: select a generated kernel when one exists
     int upload(bj_ctx *ctx, const bj_gate_program *p);   // validates, packs and copies the program
     void release();
@@ -26,4 +27,14 @@ void launch_gate_program(const DevProgram &P, const gl::u64 *d_vars, size_t var_
                          unsigned rep_var_stride, unsigned rep_const_stride, const gl::u64 *d_alphas, size_t Q,
                          gl::u64 *d_out0, gl::u64 *d_out1, gl::u64 *d_terms, hipStream_t s, const gl::u64 *d_wits = nullptr,
                          unsigned rep_wit_stride = 0);
+// one op-list gate of a circuit for launch_gate_programs (quotient mode)
+struct GateLaunch {
+    const DevProgram *program;
+    unsigned path_len;
+    unsigned char path[8];
+    unsigned reps, rep_var_stride, rep_const_stride, rep_wit_stride;
+    const gl::u64 *d_alphas;
+};
+void launch_gate_programs(const GateLaunch *gates, unsigned n, const gl::u64 *d_vars, size_t var_stride, const gl::u64 *d_consts,
+                          size_t const_stride, size_t Q, gl::u64 *d_out0, gl::u64 *d_out1, hipStream_t s, const gl::u64 *d_wits);
 }  // namespace bj

@@ -6,7 +6,9 @@
 #include "ctx.h"
 #include "gate_program.h"
 #include "gate_program_dev.h"
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 using gl::u64;
 using gl::u32;
@@ -178,6 +180,11 @@ int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     for (uint32_t i = 0; i < p->num_values; i++) vals[i] = gl::canon(p->values[i]);
     n_rel = p->num_relations;
     n_tmp = p->num_temporaries;
+    {
+        unsigned ve = 0, ce = 0, we = 0;
+        gate_program_extent(p, &ve, &ce, &we);
+        reads_witness = we != 0;
+    }
     hash = gate_program_hash(p);
     this->check = gate_program_check(p);
     n_writes = p->num_writes;
@@ -197,10 +204,10 @@ void DevProgram::release() {
     block = nullptr;
 }
 
-void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
-                         unsigned path_len, const unsigned char *path, unsigned reps, unsigned rep_var_stride,
-                         unsigned rep_const_stride, const u64 *d_alphas, size_t Q, u64 *d_out0, u64 *d_out1, u64 *d_terms,
-                         hipStream_t s, const u64 *d_wits, unsigned rep_wit_stride) {
+static ProgArgs make_prog_args(const DevProgram &P, const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                               unsigned path_len, const unsigned char *path, unsigned reps, unsigned rep_var_stride,
+                               unsigned rep_const_stride, const u64 *d_alphas, size_t Q, u64 *d_out0, u64 *d_out1, u64 *d_terms,
+                               const u64 *d_wits, unsigned rep_wit_stride) {
     ProgArgs a{};
     a.wits = d_wits; a.rep_wit_stride = rep_wit_stride;
     a.vars = d_vars; a.var_stride = var_stride; a.consts = d_consts; a.const_stride = const_stride;
@@ -209,6 +216,50 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
     for (unsigned b = 0; b < 8; b++) a.path[b] = b < path_len ? path[b] : 0;
     a.reps = reps; a.rep_var_stride = rep_var_stride; a.rep_const_stride = rep_const_stride;
     a.alphas = d_alphas; a.Q = Q; a.out0 = d_out0; a.out1 = d_out1; a.terms = d_terms;
+    return a;
+}
+
+// the op-list gates of one circuit, quotient mode: the ones with a generated body go out as ONE fused launch when there are
+// at least two of them (they all sweep the same general-purpose columns), everything else one launch per gate as before
+void launch_gate_programs(const GateLaunch *gates, unsigned n, const u64 *d_vars, size_t var_stride, const u64 *d_consts,
+                          size_t const_stride, size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s, const u64 *d_wits) {
+    if (!Q || !n) return;
+    static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr, no_fuse = getenv("BJ_GATE_NO_FUSE") != nullptr;
+    std::vector<unsigned> fused;
+    if (!no_aot && !no_fuse)
+        for (unsigned i = 0; i < n; i++) {
+            const GateLaunch &G = gates[i];
+            if (gate_aot_known(G.program->hash, G.program->check) && !G.program->reads_witness && G.rep_var_stride && G.reps &&
+                fused.size() < (size_t)gpdev::BJ_FUSED_MAX)
+                fused.push_back(i);
+        }
+    bool done_fused = false;
+    if (fused.size() >= 2) {
+        std::vector<ProgArgs> args;
+        std::vector<uint64_t> hs, cs;
+        for (unsigned i : fused) {
+            const GateLaunch &G = gates[i];
+            args.push_back(make_prog_args(*G.program, d_vars, var_stride, d_consts, const_stride, G.path_len, G.path, G.reps,
+                                          G.rep_var_stride, G.rep_const_stride, G.d_alphas, Q, d_out0, d_out1, nullptr, nullptr, 0));
+            hs.push_back(G.program->hash);
+            cs.push_back(G.program->check);
+        }
+        done_fused = launch_gate_aot_fused(hs.data(), cs.data(), args.data(), (unsigned)args.size(), (unsigned)((Q + 255) / 256), s);
+    }
+    for (unsigned i = 0; i < n; i++) {
+        if (done_fused && std::find(fused.begin(), fused.end(), i) != fused.end()) continue;
+        const GateLaunch &G = gates[i];
+        launch_gate_program(*G.program, d_vars, var_stride, d_consts, const_stride, G.path_len, G.path, G.reps, G.rep_var_stride,
+                            G.rep_const_stride, G.d_alphas, Q, d_out0, d_out1, nullptr, s, d_wits, G.rep_wit_stride);
+    }
+}
+
+void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                         unsigned path_len, const unsigned char *path, unsigned reps, unsigned rep_var_stride,
+                         unsigned rep_const_stride, const u64 *d_alphas, size_t Q, u64 *d_out0, u64 *d_out1, u64 *d_terms,
+                         hipStream_t s, const u64 *d_wits, unsigned rep_wit_stride) {
+    const ProgArgs a = make_prog_args(P, d_vars, var_stride, d_consts, const_stride, path_len, path, reps, rep_var_stride,
+                                      rep_const_stride, d_alphas, Q, d_out0, d_out1, d_terms, d_wits, rep_wit_stride);
     if (!Q) return;
     const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
     static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr;

@@ -11,11 +11,11 @@ using gl::u64;
 
 struct Acc160g {   // same lazy accumulator as quotient.hip
     u32 w[5];
-    __device__ __forceinline__ void clear() {
+    __host__ __device__ __forceinline__ void clear() {
 #pragma unroll
         for (int i = 0; i < 5; i++) w[i] = 0;
     }
-    __device__ __forceinline__ void fma(u64 a, u64 b) {
+    __host__ __device__ __forceinline__ void fma(u64 a, u64 b) {
         u32 hh, hl;
         u64 lo;
         gl::mul_limbs(a, b, hh, hl, lo);
@@ -26,13 +26,13 @@ struct Acc160g {   // same lazy accumulator as quotient.hip
         w[3] = __builtin_addc(w[3], hh, c, &c);
         w[4] += c;
     }
-    __device__ __forceinline__ u64 reduce() const {
+    __host__ __device__ __forceinline__ u64 reduce() const {
         u64 r = gl::reduce_limbs(w[3], w[2], gl::pack(w[0], w[1]));
         return gl::sub(r, (u64)w[4] << 32);
     }
 };
 
-__device__ inline u64 inv_pow(u64 x) {   // x^(p-2); inverse of 0 is 0 like the reference's batch inversion never sees
+__host__ __device__ inline u64 inv_pow(u64 x) {   // x^(p-2); inverse of 0 is 0 like the reference's batch inversion never sees
     u64 r = 1, b = x;
     u64 e = gl::P - 2;
     for (int i = 0; i < 64; i++) {
@@ -61,7 +61,21 @@ struct ProgArgs {
     u64 *out0, *out1;    // accumulated into (quotient mode)
     u64 *terms;          // raw terms (stand-alone mode)
 };
+// Several generated evaluators in ONE launch (the gates of a circuit that all sweep the same general-purpose columns): the
+// gates advance together over windows of `window` columns, so a column is read from HBM by the first gate that needs it and
+// from cache by the others.  sum_g sel_g * sum_t alpha_t term_t is accumulated as sum (sel_g term_t) alpha_t in one pair of
+// lazy accumulators — the same field element.
+constexpr int BJ_FUSED_MAX = 8;
+struct FusedArgs {
+    ProgArgs g[BJ_FUSED_MAX];
+    int id[BJ_FUSED_MAX];    // index of the generated body
+    int n;
+    unsigned window, span;   // columns per window; columns covered by the widest gate
+};
 }  // namespace gpdev
+// true if every program has a generated body and the launch was made (quotient mode only: alphas, out0 / out1 of args[0])
+bool launch_gate_aot_fused(const uint64_t *hashes, const uint64_t *checks, const gpdev::ProgArgs *args, unsigned n, unsigned blocks,
+                           hipStream_t s);
 // true if a generated kernel exists for the program with this hash (and it was launched)
 bool launch_gate_aot(uint64_t hash, uint64_t check, const gpdev::ProgArgs &a, unsigned blocks, hipStream_t s);
 bool gate_aot_known(uint64_t hash, uint64_t check);

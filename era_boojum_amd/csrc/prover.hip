@@ -680,6 +680,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     if (Qe) {
         bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Qe, t0, t1, st);
         unsigned aoff = 0;   // op-list gates (seam S3) add their contribution on top, with their own slice of alpha powers
+        std::vector<bj::GateLaunch> prog_gates;
         for (unsigned g = 0; g < S->n_gates; g++) {
             const int *f = S->gates_flat.data() + 12 * g;
             if (f[0] == BJ_GATE_POSEIDON2_FLATTENED) {
@@ -689,14 +690,22 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                                                         Qe, t0, t1, st);
             }
             if (f[0] == BJ_GATE_PROGRAM) {
-                unsigned char path[8] = {0};
-                for (int b = 0; b < f[1]; b++) path[b] = (unsigned char)f[6 + b];
-                bj::launch_gate_program(S->programs[g], wit_lde.p, Ln, d_con_lde, Ln, (unsigned)f[1], path, (unsigned)f[2],
-                                        (unsigned)f[3], (unsigned)f[4], a_gates + 2 * (size_t)aoff, Qe, t0, t1, nullptr, st,
-                                        S->Wc ? wit_lde.p + (size_t)V * Ln : nullptr, S->gate_wit_stride[g]);
+                bj::GateLaunch L{};
+                L.program = &S->programs[g];
+                L.path_len = (unsigned)f[1];
+                for (int b = 0; b < f[1]; b++) L.path[b] = (unsigned char)f[6 + b];
+                L.reps = (unsigned)f[2];
+                L.rep_var_stride = (unsigned)f[3];
+                L.rep_const_stride = (unsigned)f[4];
+                L.rep_wit_stride = S->gate_wit_stride[g];
+                L.d_alphas = a_gates + 2 * (size_t)aoff;
+                prog_gates.push_back(L);
             }
             aoff += (unsigned)(f[2] * f[5]);
         }
+        // the op-list gates: one fused launch for those with generated bodies (they all sweep the general-purpose columns)
+        bj::launch_gate_programs(prog_gates.data(), (unsigned)prog_gates.size(), wit_lde.p, Ln, d_con_lde, Ln, Qe, t0, t1, st,
+                                 S->Wc ? wit_lde.p + (size_t)V * Ln : nullptr);
         unsigned soff = 0;   // gates over specialized columns: every row, no selector
         const unsigned char no_path[8] = {0};
         for (const auto &sg : S->spec) {

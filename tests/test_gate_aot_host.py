@@ -1,0 +1,25 @@
+"""The fused gate sweep (csrc/gate_aot.hip, generated) on the host: its per-point logic is __host__ __device__, so the
+scheduling of repetitions over column windows and the folded selector can be checked without a GPU against the per-gate
+logic, for random gate sets (tools/gate_fused_host_check.cpp).  The -m gpu tests then check the kernels themselves through
+whole proofs (tests/test_gpu_gate_program.py)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_fused_gate_sweep_equals_per_gate_evaluation_on_the_host(tmp_path):
+    from era_boojum_amd import gate_codegen
+    gate_codegen.write()
+    exe = str(tmp_path / "gate_fused_host_check")
+    subprocess.check_call([HIPCC, "--cuda-host-only", "-x", "hip", "-std=c++17", "-O1", "-DBJ_GATE_AOT_HOST_ONLY",
+                           "-I" + os.path.join(ROOT, "era_boojum_amd", "csrc"), os.path.join(ROOT, "tools", "gate_fused_host_check.cpp"),
+                           "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fused == per-gate" in out.stdout
