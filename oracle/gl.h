@@ -23,14 +23,22 @@ typedef unsigned __int128 u128;
 #define GL_GEN 7ULL           /* multiplicative generator, LDE coset shift, and the F_p^2 non-residue */
 #define GL_OMEGA_2_32 0x185629dcda58878cULL /* radix_2_subgroup_generator, goldilocks/mod.rs:109-117 */
 
-static inline gl_t gl_canon(gl_t a) { return a >= GL_P ? a - GL_P : a; }
+/* written without data-dependent branches (the conditions are coin flips on random field elements: compilers turn these
+ * forms into conditional moves / masks, mispredicted branches cost more than the arithmetic) */
+static inline gl_t gl_canon(gl_t a) {
+    gl_t t = a - GL_P;
+    return a >= GL_P ? t : a;
+}
 
 static inline gl_t gl_add(gl_t a, gl_t b) { /* canonical in, canonical out */
     gl_t s = a + b;
-    if (s < a || s >= GL_P) s -= GL_P;
-    return s;
+    gl_t t = s - GL_P;                      /* = s + EPS mod 2^64: the value when the sum wrapped or reached p */
+    return ((s < a) | (s >= GL_P)) ? t : s;
 }
-static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a + (GL_P - b); }
+static inline gl_t gl_sub(gl_t a, gl_t b) {
+    gl_t d = a - b;
+    return d - ((0 - (gl_t)(a < b)) & GL_EPS);   /* borrowed 2^64 = p + EPS: give EPS back */
+}
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 static inline gl_t gl_dbl(gl_t a) { return gl_add(a, a); }
 
@@ -39,10 +47,10 @@ static inline gl_t gl_reduce128(u128 x) {
     uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
     uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
     uint64_t t0 = lo - hi_hi;
-    if (lo < hi_hi) t0 -= GL_EPS;          /* borrow: subtract 2^64 mod p */
-    uint64_t t1 = hi_lo * GL_EPS;          /* < 2^64 */
+    t0 -= (0 - (uint64_t)(lo < hi_hi)) & GL_EPS;   /* borrow: subtract 2^64 mod p */
+    uint64_t t1 = hi_lo * GL_EPS;                  /* < 2^64 */
     uint64_t r = t0 + t1;
-    if (r < t1) r += GL_EPS;               /* carry */
+    r += (0 - (uint64_t)(r < t1)) & GL_EPS;        /* carry */
     return gl_canon(r);
 }
 static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((u128)a * b); }

@@ -41,7 +41,29 @@ static void distribute_powers(gl_t *a, size_t n, gl_t el) {
     for (size_t i = 0; i < n; i++) { a[i] = gl_mul(a[i], s); s = gl_mul(s, el); }
 }
 
-/* fft/mod.rs:659-734 : round r has 2^r groups, group k uses tw[k]; butterfly (u, v*s) -> (u+v*s, u-v*s) */
+/* fft/mod.rs:659-734 : round r has 2^r groups, group k uses tw[k]; butterfly (u, v*s) -> (u+v*s, u-v*s).
+ * The rounds are the reference's; their ORDER OF EXECUTION is blocked for the cache the way the reference's "cache friendly"
+ * variant does it (fft/mod.rs:504 bench): once a group is no larger than CT_BLOCK elements, all remaining rounds of that group
+ * run back to back while it sits in L2 (group k of round r splits into groups 2k, 2k+1 of round r+1, so the sub-transform
+ * of a block only ever touches the block).  Same butterflies, same results. */
+#define CT_BLOCK ((size_t)1 << 15)
+static void ct_rounds_in_block(gl_t *a, size_t base, size_t len, size_t first_group, const gl_t *tw) {
+    /* the block [base, base + len) is group `first_group` of its round: run this and all later rounds inside it */
+    size_t groups = 1, pairs = len / 2;
+    while (pairs >= 1) {
+        for (size_t g = 0; g < groups; g++) {
+            size_t i1 = base + g * pairs * 2, i2 = i1 + pairs;
+            gl_t s = tw[first_group * groups + g];
+            for (size_t j = i1; j < i2; j++) {
+                gl_t u = a[j], v = gl_mul(a[j + pairs], s);
+                a[j + pairs] = gl_sub(u, v);
+                a[j] = gl_add(u, v);
+            }
+        }
+        groups *= 2;
+        pairs /= 2;
+    }
+}
 static void serial_ct_ntt(gl_t *a, unsigned log_n, const gl_t *tw) {
     size_t n = (size_t)1 << log_n;
     if (n == 1) return;
@@ -52,7 +74,7 @@ static void serial_ct_ntt(gl_t *a, unsigned log_n, const gl_t *tw) {
         a[j] = gl_add(u, v);
     }
     pairs /= 2; groups *= 2; dist /= 2;
-    while (groups < n) {
+    while (groups < n && 2 * pairs > CT_BLOCK) {   /* streaming rounds: groups larger than the cache block */
         for (size_t k = 0; k < groups; k++) {
             size_t i1 = k * pairs * 2, i2 = i1 + pairs;
             gl_t s = tw[k];
@@ -64,6 +86,8 @@ static void serial_ct_ntt(gl_t *a, unsigned log_n, const gl_t *tw) {
         }
         pairs /= 2; groups *= 2; dist /= 2;
     }
+    if (groups < n)                                 /* every remaining group fits the block: finish them one by one */
+        for (size_t k = 0; k < groups; k++) ct_rounds_in_block(a, k * pairs * 2, pairs * 2, k, tw);
 }
 
 /* fft/mod.rs:398-411 */

@@ -22,19 +22,20 @@ static inline gl_t pow7(gl_t x) {               /* state_generic_impl.rs:142-149
     gl_t x2 = gl_sqr(x), x3 = gl_mul(x2, x), x4 = gl_sqr(x2);
     return gl_mul(x4, x3);
 }
-static inline void block_mul(gl_t *x) {          /* suggested_mds.rs:21-56 */
-    gl_t t0 = gl_add(x[0], x[1]), t1 = gl_add(x[2], x[3]);
-    gl_t t2 = gl_add(gl_dbl(x[1]), t1), t3 = gl_add(gl_dbl(x[3]), t0);
-    gl_t t4 = gl_add(gl_dbl(gl_dbl(t1)), t3), t5 = gl_add(gl_dbl(gl_dbl(t0)), t2);
-    x[0] = gl_add(t3, t5); x[1] = t5; x[2] = gl_add(t2, t4); x[3] = t4;
+/* The linear layers are sums with small coefficients (external: entries of circ(2*M4, M4, M4) <= 14; internal: 1 + 2^k, k <= 14):
+ * they are accumulated in 128-bit integers and reduced once per output word instead of once per addition. */
+static inline void block_mul(const gl_t *x, u128 *y) {          /* suggested_mds.rs:21-56, on integers (y < 2^68) */
+    u128 t0 = (u128)x[0] + x[1], t1 = (u128)x[2] + x[3];
+    u128 t2 = 2 * (u128)x[1] + t1, t3 = 2 * (u128)x[3] + t0;
+    u128 t4 = 4 * t1 + t3, t5 = 4 * t0 + t2;
+    y[0] = t3 + t5; y[1] = t5; y[2] = t2 + t4; y[3] = t4;
 }
 static void ext_mds(gl_t *s) {                   /* suggested_mds.rs:59-103 */
-    gl_t x[12];
-    memcpy(x, s, sizeof(x));
-    block_mul(x); block_mul(x + 4); block_mul(x + 8);
+    u128 y[12];
+    block_mul(s, y); block_mul(s + 4, y + 4); block_mul(s + 8, y + 8);
     for (int j = 0; j < 4; j++) {
-        gl_t sum = gl_add(gl_add(x[j], x[4 + j]), x[8 + j]);
-        for (int b = 0; b < 3; b++) s[4 * b + j] = gl_add(x[4 * b + j], sum);
+        u128 sum = y[j] + y[4 + j] + y[8 + j];                      /* < 2^70 */
+        for (int b = 0; b < 3; b++) s[4 * b + j] = gl_reduce128(y[4 * b + j] + sum);
     }
 }
 static void full_round(gl_t *s, int r) {         /* state_generic_impl.rs:158-168 */
@@ -43,9 +44,9 @@ static void full_round(gl_t *s, int r) {         /* state_generic_impl.rs:158-16
 }
 static void partial_round(gl_t *s, int r) {      /* state_generic_impl.rs:171-219 */
     s[0] = pow7(gl_add(s[0], gl_canon(RC[12 * r])));
-    gl_t sum = 0;
-    for (int i = 0; i < 12; i++) sum = gl_add(sum, s[i]);
-    for (int i = 0; i < 12; i++) s[i] = gl_add(gl_mul(s[i], (gl_t)1 << SH[i]), sum);
+    u128 sum = 0;
+    for (int i = 0; i < 12; i++) sum += s[i];                           /* < 2^68 */
+    for (int i = 0; i < 12; i++) s[i] = gl_reduce128(((u128)s[i] << SH[i]) + sum);   /* < 2^79 */
 }
 void orc_poseidon2_permutation(uint64_t *s) {     /* state_generic_impl.rs:221-233 */
     for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
