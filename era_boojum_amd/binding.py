@@ -65,6 +65,11 @@ _SIGNATURES = {
     "bj_comm_rccl_destroy": (None, [C.c_void_p]),
     "bj_comm_rccl_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bj_gate_program_generated": (C.c_int, [C.c_void_p]),
+    "bj_gate_program_canonical_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_gate_program_emit_body": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bj_gate_program_jit_source": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bj_gate_program_jit_compile_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "bj_gate_jit_status": (C.c_int, [C.c_char_p, C.c_size_t]),
     "bj_gate_program_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint,
                                        C.c_uint, C.c_size_t, C.c_void_p]),
     "bj_setup_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -117,6 +122,9 @@ def exported_symbols():
 _lib = None
 
 
+ABI_VERSION = 3
+
+
 def load_library():
     """dlopen libboojum_hip.so; raises (never falls back) if it has not been built."""
     global _lib
@@ -130,6 +138,9 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if lib.bj_abi_version() != ABI_VERSION:     # struct layouts below are those of BJ_ABI_VERSION in include/boojum_hip.h
+            raise BoojumHipError("%s has ABI version %d, this binding was written for %d: rebuild (python -m era_boojum_amd.build)"
+                                 % (path, lib.bj_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

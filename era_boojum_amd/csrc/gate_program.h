@@ -1,22 +1,26 @@
 // Internal: device-side form of a bj_gate_program (seam S3), shared by gate_program.hip and prover.hip.
 #pragma once
 #include "ctx.h"
+#include "gate_body_rt.h"
 
+// slots of the interpreter's private (scratch-memory) variant; the canonical form of gate_canon.h needs far fewer for every
+// evaluator of the reference (13 for a 12 x 12 matrix gate, ~40 for the Poseidon2 flattened capture); a program whose
+// schedule needs more than BJ_GATE_PROGRAM_MAX_SLOTS live values at once is refused
 #define BJ_GATE_PROGRAM_MAX_TEMPORARIES 160
+#define BJ_GATE_PROGRAM_MAX_SLOTS 1024
 
 namespace bj {
-struct DevRelation {
-    uint32_t op, dst, a, b;   // a, b: kind << 28 | index
-};
+struct JitKernel;             // gate_jit.hip: a kernel compiled at run time from the canonical program
 struct DevProgram {
-    void *block = nullptr;    // one allocation: values | relations | writes
+    void *block = nullptr;    // one allocation: values | relations
     gl::u64 *d_values = nullptr;
     DevRelation *d_rel = nullptr;
-    uint32_t *d_writes = nullptr;
-    unsigned n_rel = 0, n_writes = 0, n_tmp = 0;
+    unsigned n_rel = 0, n_writes = 0, n_tmp = 0;   // n_rel counts the OP_WRITE pseudo relations; n_tmp: slots
     bool reads_witness = false;   // the program has BJ_IDX_WITNESS_POLY operands
-    uint64_t hash = 0, check = 0;   // two fingerprints of the program's content: select a generated kernel when one exists
-    int upload(bj_ctx *ctx, const bj_gate_program *p);   // validates, packs and copies the program
+    unsigned var_extent = 0, const_extent = 0, wit_extent = 0;
+    uint64_t fp[2] = {0, 0};      // structural fingerprint (gate_canon.h): selects a generated kernel when one exists
+    const JitKernel *jit = nullptr;   // compiled at upload when no generated kernel exists (owned by the process-wide cache)
+    int upload(bj_ctx *ctx, const bj_gate_program *p);   // canonicalises, packs and copies the program
     void release();
 };
 // highest variable / constant column index (relative to the repetition) the program reads, + 1; 0 if it reads none

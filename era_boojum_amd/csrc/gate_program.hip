@@ -4,6 +4,8 @@
 // here: lane = LDE point, the program (relations, constants, writes) is wave-uniform and comes through the scalar cache,
 // temporaries live in a per-lane array.  Contribution to the quotient:  T += selector * sum_rep sum_t alpha * term.
 #include "ctx.h"
+#include "gate_canon.h"
+#include "gate_jit.h"
 #include "gate_program.h"
 #include "gate_program_dev.h"
 #include <algorithm>
@@ -14,6 +16,9 @@ using gl::u64;
 using gl::u32;
 
 namespace bj {
+void launch_quotient_poseidon2_flattened(const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
+                                         unsigned path_len, const unsigned char *path, const u64 *d_alphas, size_t Q,
+                                         u64 *d_out0, u64 *d_out1, hipStream_t s);
 
 namespace {
 constexpr int MAX_TMP = BJ_GATE_PROGRAM_MAX_TEMPORARIES;
@@ -21,14 +26,15 @@ constexpr int MAX_TMP = BJ_GATE_PROGRAM_MAX_TEMPORARIES;
 using namespace gpdev;
 
 // SLOTS > 0: the temporaries live in LDS as [slot][lane] (conflict-free, no HBM-backed scratch traffic: a private array
-// indexed by a run-time slot number goes to scratch memory, two loads and a store per recorded operation); after slot
-// renaming almost every evaluator needs <= 16 slots.  SLOTS == 0: the private array, for the few large programs.
-template <int SLOTS>
+// indexed by a run-time slot number goes to scratch memory, two loads and a store per recorded operation); in canonical form
+// (gate_canon.h) almost every evaluator needs <= 16 slots.  SLOTS == 0: a private array of PRIV slots, for the few large ones.
+// The program is the canonical schedule: OP_WRITE pseudo relations hand a term over as soon as its value exists.
+template <int SLOTS, int PRIV>
 __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
     __shared__ u64 lds_tmp[SLOTS ? SLOTS : 1][256];
     const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= a.Q) return;
-    u64 priv[SLOTS ? 1 : MAX_TMP];
+    u64 priv[SLOTS ? 1 : PRIV];
     struct Tmp {     // tmp[idx] as an lvalue over either storage
         u64 *p;
         unsigned stride;
@@ -67,18 +73,18 @@ __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
                 case BJ_OP_NEGATE: res = gl::neg(x); break;
                 case BJ_OP_MUL: res = gl::mul(x, fetch(R.b, vb, cb)); break;
                 case BJ_OP_SQUARE: res = gl::sqr(x); break;
-                default: res = inv_pow(x); break;
+                case BJ_OP_INVERSE: res = inv_pow(x); break;
+                default: {   // canon::OP_WRITE: x is term R.dst of this repetition
+                    const size_t k = (size_t)r * a.n_writes + R.dst;
+                    if (a.terms) a.terms[k * a.Q + I] = x;
+                    if (a.alphas) {
+                        s0.fma(x, a.alphas[2 * k]);
+                        s1.fma(x, a.alphas[2 * k + 1]);
+                    }
+                    continue;
+                }
             }
             tmp[R.dst] = res;
-        }
-        for (unsigned t = 0; t < a.n_writes; t++) {
-            const u64 term = fetch(a.writes[t], vb, cb);
-            if (a.terms) a.terms[((size_t)r * a.n_writes + t) * a.Q + I] = term;
-            if (a.alphas) {
-                const size_t k = (size_t)r * a.n_writes + t;
-                s0.fma(term, a.alphas[2 * k]);
-                s1.fma(term, a.alphas[2 * k + 1]);
-            }
         }
     }
     if (a.alphas) {
@@ -87,47 +93,6 @@ __global__ void __launch_bounds__(256) gate_program_kernel(ProgArgs a) {
     }
 }
 }  // namespace
-
-// The program as a stream of 32-bit words, section lengths first (era_boojum_amd/gate_codegen.py walks the same way).  Two
-// independent 64-bit fingerprints of that stream select a generated kernel: FNV-1a is the key of the switch, the second one is
-// compared on a hit, so a program that merely collides with a known one under FNV-1a still runs in the interpreter.
-template <typename F>
-static void walk_program(const bj_gate_program *p, F mix) {
-    mix(p->num_relations);
-    mix(p->num_writes);
-    for (uint32_t i = 0; i < p->num_relations; i++) {
-        const bj_gate_relation &R = p->relations[i];
-        const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
-        mix(R.op); mix(R.dst); mix(R.a.kind); mix(R.a.index);
-        mix(binary ? R.b.kind : 0u); mix(binary ? R.b.index : 0u);
-    }
-    mix(p->num_values);
-    for (uint32_t i = 0; i < p->num_values; i++) {
-        const u64 v = gl::canon(p->values[i]);
-        mix((uint32_t)v); mix((uint32_t)(v >> 32));
-    }
-    for (uint32_t t = 0; t < p->num_writes; t++) { mix(p->writes[t].kind); mix(p->writes[t].index); }
-    mix(p->num_temporaries);
-}
-uint64_t gate_program_hash(const bj_gate_program *p) {
-    uint64_t h = 0xcbf29ce484222325ULL;
-    walk_program(p, [&](uint32_t w) {
-        for (int b = 0; b < 4; b++) {
-            h ^= (w >> (8 * b)) & 0xFFu;
-            h *= 0x100000001b3ULL;
-        }
-    });
-    return h;
-}
-uint64_t gate_program_check(const bj_gate_program *p) {
-    uint64_t h = 0x9E3779B97F4A7C15ULL;
-    walk_program(p, [&](uint32_t w) {
-        h ^= w;
-        h *= 0xFF51AFD7ED558CCDULL;
-        h ^= h >> 32;
-    });
-    return h;
-}
 
 void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigned *const_extent, unsigned *wit_extent) {
     unsigned v = 0, c = 0, w = 0;
@@ -147,56 +112,43 @@ void gate_program_extent(const bj_gate_program *p, unsigned *var_extent, unsigne
     if (wit_extent) *wit_extent = w;
 }
 
+// Whatever numbering and order the host's list has (the reference hands over one fresh temporary per operation from a
+// process-wide counter, gpu_synthesizer/mod.rs:210-352), the device sees the canonical schedule of gate_canon.h: slots by
+// live range, and a fingerprint of the evaluator's function that finds a generated kernel or names the one compiled here.
 int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
-    if (!p || !p->relations || !p->writes || p->num_writes == 0)
-        return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: null / empty program");
-    if (p->num_temporaries > (unsigned)MAX_TMP)
-        return fail(ctx, BJ_ERR_UNSUPPORTED, "gate program: %u temporaries (at most %d)", p->num_temporaries, MAX_TMP);
-    auto check = [&](const bj_gate_index &ix) -> bool {
-        switch (ix.kind) {
-            case BJ_IDX_VARIABLE_POLY:
-            case BJ_IDX_WITNESS_POLY:
-            case BJ_IDX_CONSTANT_POLY: return ix.index < (1u << 20);
-            case BJ_IDX_TEMPORARY: return ix.index < p->num_temporaries;
-            case BJ_IDX_CONSTANT_VALUE: return ix.index < p->num_values && p->values;
-            default: return false;
-        }
+    canon::Program C;
+    std::string err;
+    if (int rc = canon::canonicalize(p, &C, &err)) return fail(ctx, rc, "%s", err.c_str());
+    if (C.num_slots > (unsigned)BJ_GATE_PROGRAM_MAX_SLOTS)
+        return fail(ctx, BJ_ERR_UNSUPPORTED, "gate program: %u values live at once (at most %d)", C.num_slots, BJ_GATE_PROGRAM_MAX_SLOTS);
+    auto pack = [&](const canon::Operand &x) -> uint32_t {
+        return (x.kind << 28) | (x.kind == BJ_IDX_TEMPORARY ? C.slot_of[x.index] : x.index);
     };
-    std::vector<DevRelation> rel(p->num_relations);
-    for (uint32_t i = 0; i < p->num_relations; i++) {
-        const bj_gate_relation &R = p->relations[i];
-        if (R.op < BJ_OP_ADD || R.op > BJ_OP_INVERSE || R.dst >= p->num_temporaries || !check(R.a))
-            return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: bad relation %u", i);
-        const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
-        if (binary && !check(R.b)) return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: bad second operand in relation %u", i);
-        rel[i] = DevRelation{R.op, R.dst, (R.a.kind << 28) | R.a.index, binary ? (R.b.kind << 28) | R.b.index : 0u};
+    std::vector<DevRelation> rel(C.nodes.size());
+    for (size_t i = 0; i < C.nodes.size(); i++) {
+        const canon::Node &n = C.nodes[i];
+        const bool binary = n.op == BJ_OP_ADD || n.op == BJ_OP_SUB || n.op == BJ_OP_MUL;
+        rel[i] = DevRelation{n.op, n.dst, pack(n.a), binary ? pack(n.b) : 0u};
     }
-    std::vector<u32> wr(p->num_writes);
-    for (uint32_t t = 0; t < p->num_writes; t++) {
-        if (!check(p->writes[t])) return fail(ctx, BJ_ERR_INVALID_ARG, "gate program: bad write %u", t);
-        wr[t] = (p->writes[t].kind << 28) | p->writes[t].index;
-    }
-    std::vector<u64> vals(p->num_values ? p->num_values : 1, 0);
-    for (uint32_t i = 0; i < p->num_values; i++) vals[i] = gl::canon(p->values[i]);
-    n_rel = p->num_relations;
-    n_tmp = p->num_temporaries;
-    {
-        unsigned ve = 0, ce = 0, we = 0;
-        gate_program_extent(p, &ve, &ce, &we);
-        reads_witness = we != 0;
-    }
-    hash = gate_program_hash(p);
-    this->check = gate_program_check(p);
-    n_writes = p->num_writes;
-    const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + wr.size() * 4 + 64;
+    std::vector<u64> vals = C.values;
+    if (vals.empty()) vals.push_back(0);
+    n_rel = (unsigned)rel.size();
+    n_tmp = C.num_slots;
+    n_writes = C.num_terms;
+    var_extent = C.var_extent; const_extent = C.const_extent; wit_extent = C.wit_extent;
+    reads_witness = C.wit_extent != 0;
+    fp[0] = C.fp[0];
+    fp[1] = C.fp[1];
+    const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + 64;
     if (hipMalloc(&block, bytes) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "gate program: allocation failed");
     char *base = (char *)block;
     d_values = (u64 *)base;
     d_rel = (DevRelation *)(base + vals.size() * 8);
-    d_writes = (u32 *)(base + vals.size() * 8 + (rel.size() ? rel.size() : 1) * sizeof(DevRelation));
     int rc = bj_memcpy_h2d(ctx, d_values, vals.data(), vals.size() * 8);
-    if (!rc && !rel.empty()) rc = bj_memcpy_h2d(ctx, d_rel, rel.data(), rel.size() * sizeof(DevRelation));
-    if (!rc) rc = bj_memcpy_h2d(ctx, d_writes, wr.data(), wr.size() * 4);
+    if (!rc) rc = bj_memcpy_h2d(ctx, d_rel, rel.data(), rel.size() * sizeof(DevRelation));
+    // no build-time kernel for this function: compile one now (gate_jit.hip); the interpreter remains the fallback when the
+    // run-time compiler is not installed or BJ_GATE_NO_JIT is set
+    if (!rc && !gate_aot_known(fp[0], fp[1]) && !gate_is_poseidon2_flattened(fp[0], fp[1])) jit = jit_gate_kernel(ctx, C);
     return rc;
 }
 void DevProgram::release() {
@@ -211,7 +163,7 @@ static ProgArgs make_prog_args(const DevProgram &P, const u64 *d_vars, size_t va
     ProgArgs a{};
     a.wits = d_wits; a.rep_wit_stride = rep_wit_stride;
     a.vars = d_vars; a.var_stride = var_stride; a.consts = d_consts; a.const_stride = const_stride;
-    a.rel = P.d_rel; a.values = P.d_values; a.writes = P.d_writes; a.n_rel = P.n_rel; a.n_writes = P.n_writes;
+    a.rel = P.d_rel; a.values = P.d_values; a.n_rel = P.n_rel; a.n_writes = P.n_writes;
     a.path_len = path_len;
     for (unsigned b = 0; b < 8; b++) a.path[b] = b < path_len ? path[b] : 0;
     a.reps = reps; a.rep_var_stride = rep_var_stride; a.rep_const_stride = rep_const_stride;
@@ -229,7 +181,7 @@ void launch_gate_programs(const GateLaunch *gates, unsigned n, const u64 *d_vars
     if (!no_aot && !no_fuse)
         for (unsigned i = 0; i < n; i++) {
             const GateLaunch &G = gates[i];
-            if (gate_aot_known(G.program->hash, G.program->check) && !G.program->reads_witness && G.rep_var_stride && G.reps &&
+            if (gate_aot_known(G.program->fp[0], G.program->fp[1]) && !G.program->reads_witness && G.rep_var_stride && G.reps &&
                 fused.size() < (size_t)gpdev::BJ_FUSED_MAX)
                 fused.push_back(i);
         }
@@ -241,8 +193,8 @@ void launch_gate_programs(const GateLaunch *gates, unsigned n, const u64 *d_vars
             const GateLaunch &G = gates[i];
             args.push_back(make_prog_args(*G.program, d_vars, var_stride, d_consts, const_stride, G.path_len, G.path, G.reps,
                                           G.rep_var_stride, G.rep_const_stride, G.d_alphas, Q, d_out0, d_out1, nullptr, nullptr, 0));
-            hs.push_back(G.program->hash);
-            cs.push_back(G.program->check);
+            hs.push_back(G.program->fp[0]);
+            cs.push_back(G.program->fp[1]);
         }
         done_fused = launch_gate_aot_fused(hs.data(), cs.data(), args.data(), (unsigned)args.size(), (unsigned)((Q + 255) / 256), s);
     }
@@ -263,22 +215,32 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
     if (!Q) return;
     const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
     static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr;
-    if (!no_aot && launch_gate_aot(P.hash, P.check, a, grid.x, s)) return;   // a generated straight-line kernel exists for this program
+    if (!no_aot && launch_gate_aot(P.fp[0], P.fp[1], a, grid.x, s)) return;   // a build-time generated straight-line kernel
+    // the reference's own capture of the Poseidon2 flattened gate: the hand-written evaluator (quotient mode, one repetition)
+    if (!no_aot && d_alphas && !d_terms && reps == 1 && gate_is_poseidon2_flattened(P.fp[0], P.fp[1])) {
+        launch_quotient_poseidon2_flattened(d_vars, var_stride, d_consts, const_stride, path_len, path, d_alphas, Q, d_out0, d_out1, s);
+        return;
+    }
+    if (P.jit && launch_jit_gate(P.jit, a, grid.x, s)) return;                // compiled from this very op list at upload
     if (P.n_tmp <= 8)
-        hipLaunchKernelGGL(gate_program_kernel<8>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((gate_program_kernel<8, 1>), grid, block, 0, s, a);
     else if (P.n_tmp <= 16)
-        hipLaunchKernelGGL(gate_program_kernel<16>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((gate_program_kernel<16, 1>), grid, block, 0, s, a);
     else if (P.n_tmp <= 32)
-        hipLaunchKernelGGL(gate_program_kernel<32>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((gate_program_kernel<32, 1>), grid, block, 0, s, a);
+    else if (P.n_tmp <= MAX_TMP)
+        hipLaunchKernelGGL((gate_program_kernel<0, MAX_TMP>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL(gate_program_kernel<0>, grid, block, 0, s, a);
+        hipLaunchKernelGGL((gate_program_kernel<0, BJ_GATE_PROGRAM_MAX_SLOTS>), grid, block, 0, s, a);
 }
 
 }  // namespace bj
 
 extern "C" int bj_gate_program_generated(const bj_gate_program *program) {
-    if (!program || !program->relations || !program->writes) return 0;
-    return bj::gate_aot_known(bj::gate_program_hash(program), bj::gate_program_check(program)) ? 1 : 0;
+    bj::canon::Program C;
+    std::string err;
+    if (bj::canon::canonicalize(program, &C, &err)) return 0;
+    return (bj::gate_aot_known(C.fp[0], C.fp[1]) || bj::gate_is_poseidon2_flattened(C.fp[0], C.fp[1])) ? 1 : 0;
 }
 
 extern "C" int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint64_t *d_vars, size_t var_stride,

@@ -1,13 +1,17 @@
-"""Gate op lists for seam S3 (include/boojum_hip.h, bj_gate_program): a small tracing builder that records the relations
-of a gate formula the way the reference's gpu_synthesizer does (GpuSynthesizerFieldLike + GPUVariablesContext,
-src/gpu_synthesizer/mod.rs:136-352): write the evaluator once with `+ - *`, get the op list.
+"""Gate op lists for seam S3 (include/boojum_hip.h, bj_gate_program): what the reference's gpu_synthesizer records when it runs
+a GateConstraintEvaluator over GpuSynthesizerFieldLike (src/gpu_synthesizer/mod.rs:136-352, 354-444).
+
+`EvaluatorContext` is that recording field: every arithmetic call emits ONE relation into a fresh temporary, with the trait's
+default `mul_and_accumulate_into` (a product, then a sum: field_like.rs:71-75), `small_pow` (:78-106) and `pow_u64`.  The
+`evaluate_*` functions below are the `evaluate_once` bodies of src/cs/gates/*.rs written against it CALL BY CALL, so a
+program built here is the list a Rust host would hand over for that evaluator (up to the numbering of temporaries, which the
+library does not depend on: csrc/gate_canon.h).  gate_codegen.py generates the build-time kernels from exactly these lists.
 
     b = GateProgramBuilder()
-    a, bb, c, d = (b.var(i) for i in range(4))
-    q, l = b.const_poly(0), b.const_poly(1)
-    b.push(q * a * bb + l * c - d)          # FmaGateInBaseFieldWithoutConstant
+    evaluate_fma(b)                     # FmaGateInBaseFieldWithoutConstant
     program = b.build()
-"""
+
+A formula can also be written with `+ - *` on the traced values (tests do that for independent restatements)."""
 import ctypes as C
 
 OP_ADD, OP_DOUBLE, OP_SUB, OP_NEGATE, OP_MUL, OP_SQUARE, OP_INVERSE = 1, 2, 3, 4, 5, 6, 7
@@ -50,7 +54,37 @@ class _Val:
     def inverse(self): return self.b._emit(OP_INVERSE, self)
 
 
-class GateProgramBuilder:
+class EvaluatorContext:
+    """PrimeFieldLike for GpuSynthesizerFieldLike (gpu_synthesizer/mod.rs:232-352) + TraceSource / EvaluationDestination of
+    the capture (:55-101).  `x.op_assign(&y, ctx)` of the reference reads `x = c.op(x, y)` here.  Subclasses provide
+    `_emit(op, a, b=None) -> value`, `var / wit / const_poly / value` and `push`."""
+
+    def zero(self): return self.value(0)
+    def one(self): return self.value(1)
+    def minus_one(self): return self.value(P - 1)
+    def add(self, x, y): return self._emit(OP_ADD, x, y)
+    def sub(self, x, y): return self._emit(OP_SUB, x, y)
+    def mul(self, x, y): return self._emit(OP_MUL, x, y)
+    def square(self, x): return self._emit(OP_SQUARE, x)
+    def negate(self, x): return self._emit(OP_NEGATE, x)
+    def double(self, x): return self._emit(OP_DOUBLE, x)
+    def inverse(self, x): return self._emit(OP_INVERSE, x)
+
+    def mul_and_accumulate_into(self, acc, a, b):          # field_like.rs:71-75: tmp = a; tmp *= b; acc += tmp
+        return self.add(acc, self.mul(a, b))
+
+    def small_pow(self, x, n):                              # field_like.rs:78-106
+        if n == 3:
+            return self.mul(self.square(x), x)
+        if n == 5:
+            return self.mul(self.square(self.square(x)), x)
+        if n == 7:
+            pow2 = self.square(x)
+            return self.mul(self.mul(self.square(pow2), pow2), x)
+        raise NotImplementedError("small_pow(%d): the reference has 3, 5 and 7" % n)
+
+
+class GateProgramBuilder(EvaluatorContext):
     def __init__(self):
         self.relations, self.values, self.writes, self.n_tmp = [], [], [], 0
 
@@ -75,37 +109,10 @@ class GateProgramBuilder:
         self.writes.append((v.kind, v.index))
 
     def build(self):
-        """Temporaries are renamed onto as few slots as a linear scan needs (a slot is free again after the last relation
-        that reads it; what the writes name stays live): the interpreter has BJ_GATE_PROGRAM_MAX_TEMPORARIES of them, a
-        straight trace of a 12 x 12 matrix gate alone would use ~290."""
-        last_use = {}
-        for i, (op, dst, a, b) in enumerate(self.relations):
-            for k, ix in (a, b):
-                if k == IDX_TEMPORARY:
-                    last_use[ix] = i
-        for k, ix in self.writes:
-            if k == IDX_TEMPORARY:
-                last_use[ix] = len(self.relations)
-        slot_of, free, n_slots, relations = {}, [], 0, []
-
-        def rename(ref):
-            k, ix = ref
-            return (k, slot_of[ix]) if k == IDX_TEMPORARY else ref
-        for i, (op, dst, a, b) in enumerate(self.relations):
-            ra, rb = rename(a), rename(b)
-            for k, ix in {a, b}:                                # operands read for the last time here free their slot:
-                if k == IDX_TEMPORARY and last_use[ix] == i:   # the result may take it over (the interpreter reads first)
-                    free.append(slot_of[ix])
-            if dst not in last_use:                             # a result nobody reads (dead code of a trace)
-                last_use[dst] = i
-            slot = free.pop() if free else n_slots
-            n_slots = max(n_slots, slot + 1)
-            slot_of[dst] = slot
-            if last_use[dst] == i:
-                free.append(slot)
-            relations.append((op, slot, ra, rb))
-        writes = [rename(w) for w in self.writes]
-        return GateProgram(relations, self.values, writes, n_slots)
+        """One temporary per recorded relation, numbered densely in definition order — what rust/prove_hip.rs
+        `OwnedProgram::from_capture` makes of a GPUDataCapture.  Slot allocation by live range, common subexpressions and the
+        choice of a kernel are the library's business (csrc/gate_canon.h), whatever the numbering."""
+        return GateProgram(self.relations, self.values, self.writes, self.n_tmp)
 
 
 class GateProgram:
@@ -179,218 +186,282 @@ def _evaluate_columns(self, var_cols, con_cols, wit_cols=()):
 GateProgram.evaluate_columns = _evaluate_columns
 
 
-# ---- the evaluators of the SHA bench as op lists (the same formulas quotient.hip hard-codes), and a few more gates ----
-def fma_program():
-    b = GateProgramBuilder()
-    a, bb, c, d = (b.var(i) for i in range(4))
-    b.push(b.const_poly(0) * (a * bb) + b.const_poly(1) * c - d)     # fma_gate_without_constant.rs:96-126
-    return b.build()
+# ---- evaluate_once of the reference's evaluators, call by call (src/cs/gates/*.rs) ----
+def evaluate_fma(c):
+    """FmaGateInBaseWithoutConstantConstraintEvaluator, fma_gate_without_constant.rs:96-126."""
+    a, b, cc, d = (c.var(i) for i in range(4))
+    quadratic_term_coeff, linear_term_coeff = c.const_poly(0), c.const_poly(1)      # load_row_shared_constants :78-93
+    contribution = c.mul(cc, linear_term_coeff)
+    t = c.mul(a, b)
+    contribution = c.mul_and_accumulate_into(contribution, quadratic_term_coeff, t)
+    contribution = c.sub(contribution, d)
+    c.push(contribution)
 
 
-def reduction4_program():
-    b = GateProgramBuilder()
-    acc = b.var(0) * b.const_poly(0)
-    for k in range(1, 4):
-        acc = acc + b.var(k) * b.const_poly(k)
-    b.push(acc - b.var(4))                                           # reduction_gate.rs:103-126
-    return b.build()
-
-
-def constants_allocator_program():
-    b = GateProgramBuilder()
-    b.push(b.var(0) - b.const_poly(0))                               # constant_allocator.rs:107-126
-    return b.build()
-
-
-def selection_program():
-    b = GateProgramBuilder()
-    a, bb, sel, out = (b.var(i) for i in range(4))
-    b.push(a * sel + (1 - sel) * bb - out)                           # selection_gate.rs:86-112
-    return b.build()
-
-
-def dot_product4_program():
-    b = GateProgramBuilder()
-    acc = b.var(0) * b.var(1)
-    for i in range(1, 4):
-        acc = acc + b.var(2 * i) * b.var(2 * i + 1)
-    b.push(acc - b.var(8))                                           # dot_product_gate.rs:85-113
-    return b.build()
-
-
-def zero_check_program(use_witness_column_for_inversion=False):
-    """ZeroCheckGate (zero_check.rs:143-175); with use_witness_column_for_inversion the inverse lives in a non-copiable witness
-    column (variables_offset 2, witnesses_offset 1, zero_check.rs:76-91)."""
-    b = GateProgramBuilder()
-    inp, flag = b.var(0), b.var(1)
-    inv = b.wit(0) if use_witness_column_for_inversion else b.var(2)
-    b.push(flag + inp * inv - 1)                                     # zero_check.rs:143-175
-    b.push(inp * flag)
-    return b.build()
-
-
-def uintx_add_program():
-    b = GateProgramBuilder()
-    a, bb, cin, c, cout = (b.var(i) for i in range(5))
-    b.push(a + bb + cin - c - b.const_poly(0) * cout)                # uintx_add.rs:96-130
-    b.push(cout.square() - cout)
-    return b.build()
-
-
-def boolean_program():
-    b = GateProgramBuilder()
-    a = b.var(0)
-    b.push(a * (1 - a))                                              # boolean_allocator.rs:86-107
-    return b.build()
-
-
-def parallel_selection4_program():
-    b = GateProgramBuilder()
-    sel = b.var(0)
-    for i in range(4):
-        a, bb, r = b.var(3 * i + 1), b.var(3 * i + 2), b.var(3 * i + 3)
-        b.push(a * sel + (1 - sel) * bb - r)                         # parallel_selection.rs:92-120
-    return b.build()
-
-
-def u8x4_fma_program():
-    """U8x4FMAGate (u32_fma.rs:96-280): a*b + c + carry_in = low + 2^32 * high over 8-bit limbs."""
-    b = GateProgramBuilder()
-    v = [b.var(i) for i in range(26)]
-    a, bb, c, carry, low, high, pc0, pc1 = v[0:4], v[4:8], v[8:12], v[12:16], v[16:20], v[20:24], v[24], v[25]
-    sh = lambda i: 1 << (8 * i)
-    t = c[0] + c[1] * sh(1) + c[2] * sh(2) + c[3] * sh(3)
-    t = t + carry[0] + carry[1] * sh(1) + carry[2] * sh(2) + carry[3] * sh(3)
-    for i in range(4):
-        t = t - low[i] * sh(i)
-    t = t + a[0] * bb[0]
-    t = t + (a[1] * bb[0] + a[0] * bb[1]) * sh(1)
-    t = t + (a[2] * bb[0] + a[1] * bb[1] + a[0] * bb[2]) * sh(2)
-    t = t + (a[3] * bb[0] + a[2] * bb[1] + a[1] * bb[2] + a[0] * bb[3]) * sh(3)
-    t = t - pc0 * sh(4) - pc1 * sh(5)
-    b.push(t)
-    u = pc0 + pc1 * sh(1)
-    for i in range(4):
-        u = u - high[i] * sh(i)
-    u = u + (a[3] * bb[1] + a[2] * bb[2] + a[1] * bb[3])
-    u = u + (a[3] * bb[2] + a[2] * bb[3]) * sh(1)
-    u = u + (a[3] * bb[3]) * sh(2)
-    b.push(u)
-    return b.build()
-
-
-# ---- the remaining evaluators over general-purpose columns (src/cs/gates/*.rs), written once with the tracer ----
-def conditional_swap_program(n=1):
-    """ConditionalSwapGate<N> (conditional_swap.rs:96-140): selector, then (a, b, result_a, result_b) per pair."""
-    b = GateProgramBuilder()
-    sel = b.var(0)
+def evaluate_reduction(c, n=4):
+    """ReductionGateConstraintEvaluator<N>, reduction_gate.rs:103-126; the N coefficients are row-shared constants."""
+    contribution = c.zero()
     for i in range(n):
-        a, bb, ra, rb = (b.var(4 * i + k) for k in (1, 2, 3, 4))
-        b.push(bb * sel + (1 - sel) * a - ra)
-        b.push(a * sel + (1 - sel) * bb - rb)
-    return b.build()
+        contribution = c.mul_and_accumulate_into(contribution, c.var(i), c.const_poly(i))
+    contribution = c.sub(contribution, c.var(n))
+    c.push(contribution)
 
 
-def quadratic_combination_program(n=4):
-    """QuadraticCombinationGate<N> (quadratic_combination.rs:85-117): sum a_i * b_i = 0."""
-    b = GateProgramBuilder()
-    acc = b.var(0) * b.var(1)
+def evaluate_constants_allocator(c):
+    """ConstantAllocatorConstraintEvaluator, constant_allocator.rs:107-126."""
+    c.push(c.sub(c.var(0), c.const_poly(0)))
+
+
+def evaluate_boolean(c):
+    """BooleanConstraintEvaluator, boolean_allocator.rs:100-121."""
+    one = c.one()
+    a = c.var(0)
+    tmp = c.sub(one, a)
+    c.push(c.mul(a, tmp))
+
+
+def evaluate_selection(c):
+    """SelectionGateConstraintEvaluator, selection_gate.rs:100-128."""
+    a, b, selector, result = (c.var(i) for i in range(4))
+    contribution = c.mul(a, selector)
+    tmp = c.sub(c.one(), selector)
+    contribution = c.mul_and_accumulate_into(contribution, tmp, b)
+    contribution = c.sub(contribution, result)
+    c.push(contribution)
+
+
+def evaluate_parallel_selection(c, n=4):
+    """ParallelSelectionGateConstraintEvaluator<N>, parallel_selection.rs:106-136."""
+    selector = c.var(0)
+    for i in range(n):
+        a, b, result = c.var(3 * i + 1), c.var(3 * i + 2), c.var(3 * i + 3)
+        contribution = c.mul(a, selector)
+        tmp = c.sub(c.one(), selector)
+        contribution = c.mul_and_accumulate_into(contribution, tmp, b)
+        contribution = c.sub(contribution, result)
+        c.push(contribution)
+
+
+def evaluate_conditional_swap(c, n=1):
+    """ConditionalSwapGateConstraintEvaluator<N>, conditional_swap.rs:108-152."""
+    selector = c.var(0)
+    for i in range(n):
+        a, b, result_a, result_b = (c.var(4 * i + k) for k in (1, 2, 3, 4))
+        contribution = c.mul(b, selector)                  # if we swap - take B
+        tmp = c.sub(c.one(), selector)
+        contribution = c.mul_and_accumulate_into(contribution, tmp, a)
+        contribution = c.sub(contribution, result_a)
+        c.push(contribution)
+        contribution = c.mul(a, selector)                  # if we swap - take A
+        tmp = c.sub(c.one(), selector)
+        contribution = c.mul_and_accumulate_into(contribution, tmp, b)
+        contribution = c.sub(contribution, result_b)
+        c.push(contribution)
+
+
+def evaluate_dot_product(c, n=4):
+    """DotProductConstraintEvaluator<N>, dot_product_gate.rs:102-131."""
+    contribution = c.zero()
+    for idx in range(n):
+        contribution = c.mul_and_accumulate_into(contribution, c.var(2 * idx), c.var(2 * idx + 1))
+    contribution = c.sub(contribution, c.var(2 * n))
+    c.push(contribution)
+
+
+def evaluate_quadratic_combination(c, n=4):
+    """QuadraticCombinationConstraintEvaluator<N>, quadratic_combination.rs:97-129."""
+    contribution = c.mul(c.var(0), c.var(1))
     for i in range(1, n):
-        acc = acc + b.var(2 * i) * b.var(2 * i + 1)
-    b.push(acc)
-    return b.build()
+        tmp = c.mul(c.var(2 * i), c.var(2 * i + 1))
+        contribution = c.add(contribution, tmp)
+    c.push(contribution)
 
 
-def reduction_by_powers_program(n=4):
-    """ReductionByPowersGate<N> (reduction_by_powers_gate.rs:96-135): sum var_i * c^i = result, c row-shared."""
-    b = GateProgramBuilder()
-    c = b.const_poly(0)
-    acc, power = b.var(0) * 1, None
-    for i in range(1, n):
-        power = c if power is None else power * c
-        acc = acc + b.var(i) * power
-    b.push(acc - b.var(n))
-    return b.build()
+def evaluate_reduction_by_powers(c, n=4):
+    """ReductionByPowersGateConstraintEvaluator<N>, reduction_by_powers_gate.rs:103-138."""
+    reduction_constants = c.const_poly(0)
+    current_constant = c.one()
+    contribution = c.zero()
+    for idx in range(n):
+        if idx != 0:
+            current_constant = c.mul(current_constant, reduction_constants)
+        tmp = c.mul(c.var(idx), current_constant)
+        contribution = c.add(contribution, tmp)
+    contribution = c.sub(contribution, c.var(n))
+    c.push(contribution)
 
 
-def simple_non_linearity_program(n=7):
-    """SimpleNonlinearityGate<N> (simple_non_linearity_with_constant.rs:96-125): (x + c)^N = y."""
-    b = GateProgramBuilder()
-    t = b.var(0) + b.const_poly(0)
-    acc, base, e = None, t, n
-    while e:                                   # small_pow: square and multiply
-        if e & 1:
-            acc = base if acc is None else acc * base
-        e >>= 1
-        if e:
-            base = base.square()
-    b.push(acc - b.var(1))
-    return b.build()
+def evaluate_simple_non_linearity(c, n=7):
+    """SimpleNonlinearityGateConstraintEvaluator<N>, simple_non_linearity_with_constant.rs:100-125: (x + c)^N = y."""
+    x, y = c.var(0), c.var(1)
+    tmp = c.add(x, c.const_poly(0))
+    contribution = c.small_pow(tmp, n)
+    contribution = c.sub(contribution, y)
+    c.push(contribution)
 
 
-def u32_add_program():
-    """U32AddGate (u32_add.rs:85-125)."""
-    b = GateProgramBuilder()
-    a, bb, cin, c, cout = (b.var(i) for i in range(5))
-    b.push(a + bb + cin - c - b.value(1 << 32) * cout)
-    b.push(cout * cout - cout)
-    return b.build()
+def evaluate_zero_check(c, use_witness_column_for_inversion=False):
+    """ZeroCheckEvaluator, zero_check.rs:143-176; with use_witness_column_for_inversion the inverse lives in a non-copiable
+    witness column (variables_offset 2, witnesses_offset 1, :76-91)."""
+    one = c.one()
+    inp, flag = c.var(0), c.var(1)
+    inversion_witness = c.wit(0) if use_witness_column_for_inversion else c.var(2)
+    contribution = c.mul_and_accumulate_into(flag, inp, inversion_witness)
+    contribution = c.sub(contribution, one)
+    c.push(contribution)
+    c.push(c.mul(inp, flag))
 
 
-def u32_sub_program():
-    """U32SubGate (u32_sub.rs:85-125): a - b - borrow_in - c + 2^32 * borrow_out = 0."""
-    b = GateProgramBuilder()
-    a, bb, bin_, c, bout = (b.var(i) for i in range(5))
-    b.push(a - bb - bin_ - c + b.value(1 << 32) * bout)
-    b.push(bout * bout - bout)
-    return b.build()
+def _evaluate_add_with_carry(c, shift):
+    a, b, carry_in, cc, carry_out = (c.var(i) for i in range(5))
+    contribution = c.add(a, b)
+    contribution = c.add(contribution, carry_in)
+    contribution = c.sub(contribution, cc)
+    tmp = c.mul(shift, carry_out)
+    contribution = c.sub(contribution, tmp)
+    c.push(contribution)
+    contribution = c.mul(carry_out, carry_out)
+    contribution = c.sub(contribution, carry_out)
+    c.push(contribution)
 
 
-def u32_tri_add_carry_as_chunk_program():
-    """U32TriAddCarryAsChunkGate (u32_tri_add_carry_as_chunk.rs:100-190): three 4x8-bit operands, 8-bit result limbs, carry chunk."""
-    b = GateProgramBuilder()
-    sh = [1, 1 << 8, 1 << 16, 1 << 24]
-    acc = None
-    for op in range(3):
+def evaluate_uintx_add(c):
+    """UIntXAddConstraintEvaluator, uintx_add.rs:101-140: the shift 2^N is a row-shared constant."""
+    _evaluate_add_with_carry(c, c.const_poly(0))
+
+
+def evaluate_u32_add(c):
+    """U32AddConstraintEvaluator, u32_add.rs:93-131: the shift is the field constant 2^32."""
+    _evaluate_add_with_carry(c, c.value(1 << 32))
+
+
+def evaluate_u32_sub(c):
+    """U32SubConstraintEvaluator, u32_sub.rs:91-129: a - b - borrow_in - c + 2^32 * borrow_out = 0."""
+    a, b, borrow_in, cc, borrow_out = (c.var(i) for i in range(5))
+    contribution = c.sub(a, b)
+    contribution = c.sub(contribution, borrow_in)
+    contribution = c.sub(contribution, cc)
+    tmp = c.mul(c.value(1 << 32), borrow_out)
+    contribution = c.add(contribution, tmp)
+    c.push(contribution)
+    contribution = c.mul(borrow_out, borrow_out)
+    contribution = c.sub(contribution, borrow_out)
+    c.push(contribution)
+
+
+def evaluate_u32_tri_add_carry_as_chunk(c):
+    """U32TriAddCarryAsChunkConstraintEvaluator, u32_tri_add_carry_as_chunk.rs:105-178 (global constants :78-88)."""
+    shift8, shift16, shift24, shift32 = (c.value(1 << k) for k in (8, 16, 24, 32))
+    one = c.one()
+    v = [c.var(i) for i in range(17)]
+    coeffs = [one, shift8, shift16, shift24]
+    contribution = c.zero()
+    for base in (0, 4, 8):                                  # a, b, c limbs
         for k in range(4):
-            t = b.var(4 * op + k) * sh[k]
-            acc = t if acc is None else acc + t
-    acc = acc - b.var(12)
-    for k in range(1, 4):
-        acc = acc - b.var(12 + k) * sh[k]
-    b.push(acc - b.var(16) * (1 << 32))
-    return b.build()
+            contribution = c.mul_and_accumulate_into(contribution, v[base + k], coeffs[k])
+    contribution = c.sub(contribution, v[12])
+    for k, sh in ((1, shift8), (2, shift16), (3, shift24)):
+        tmp = c.mul(v[12 + k], sh)
+        contribution = c.sub(contribution, tmp)
+    tmp = c.mul(v[16], shift32)
+    contribution = c.sub(contribution, tmp)
+    c.push(contribution)
 
 
-def fma_in_extension_program():
-    """FmaGateInExtensionWithoutConstant (fma_gate_in_extension_without_constant.rs:110-190): q * a * b + l * c = d over
-    F_p[u]/(u^2 - 7), all of a, b, c, d, q, l as (c0, c1) pairs; q, l row-shared constants."""
-    b = GateProgramBuilder()
-    a0, a1, b0, b1, c0, c1, d0, d1 = (b.var(i) for i in range(8))
-    q0, q1, l0, l1 = (b.const_poly(i) for i in range(4))
-    nr = b.value(7)
-    lin0 = c0 * l0 + (c1 * l1) * nr
-    lin1 = c0 * l1 + c1 * l0
-    in0 = a0 * b0 + (a1 * b1) * nr
-    in1 = a0 * b1 + a1 * b0
-    f0 = in0 * q0 + (in1 * q1) * nr
-    f1 = in0 * q1 + in1 * q0
-    b.push(f0 + lin0 - d0)
-    b.push(f1 + lin1 - d1)
-    return b.build()
+def evaluate_u8x4_fma(c):
+    """U8x4ConstraintEvaluator, u32_fma.rs:140-299 (global constants :73-125): a*b + c + carry_in = low + 2^32 * high."""
+    shift_8, shift_16, shift_24 = (c.value(1 << k) for k in (8, 16, 24))
+    minus_one = c.value(P - 1)
+    minus_shift_8, minus_shift_16, minus_shift_24, minus_shift_32, minus_shift_40 = (c.value(P - (1 << k)) for k in (8, 16, 24, 32, 40))
+    v = [c.var(i) for i in range(26)]
+    (a0, a1, a2, a3), (b0, b1, b2, b3), (c0, c1, c2, c3) = v[0:4], v[4:8], v[8:12]
+    (carry0, carry1, carry2, carry3), (low0, low1, low2, low3), (high0, high1, high2, high3) = v[12:16], v[16:20], v[20:24]
+    product_carry0, product_carry1 = v[24], v[25]
+    macc = c.mul_and_accumulate_into
+    contribution = c0                                                   # + c
+    contribution = macc(contribution, c1, shift_8)
+    contribution = macc(contribution, c2, shift_16)
+    contribution = macc(contribution, c3, shift_24)
+    contribution = c.add(contribution, carry0)                          # + carry_in
+    contribution = macc(contribution, carry1, shift_8)
+    contribution = macc(contribution, carry2, shift_16)
+    contribution = macc(contribution, carry3, shift_24)
+    contribution = macc(contribution, low0, minus_one)                  # - low
+    contribution = macc(contribution, low1, minus_shift_8)
+    contribution = macc(contribution, low2, minus_shift_16)
+    contribution = macc(contribution, low3, minus_shift_24)
+    contribution = macc(contribution, a0, b0)                           # 0..
+    tmp = c.mul(a1, b0)                                                 # 8..
+    tmp = macc(tmp, a0, b1)
+    contribution = macc(contribution, tmp, shift_8)
+    tmp = c.mul(a2, b0)                                                 # 16..
+    tmp = macc(tmp, a1, b1)
+    tmp = macc(tmp, a0, b2)
+    contribution = macc(contribution, tmp, shift_16)
+    tmp = c.mul(a3, b0)                                                 # 24..
+    tmp = macc(tmp, a2, b1)
+    tmp = macc(tmp, a1, b2)
+    tmp = macc(tmp, a0, b3)
+    contribution = macc(contribution, tmp, shift_24)
+    contribution = macc(contribution, product_carry0, minus_shift_32)
+    contribution = macc(contribution, product_carry1, minus_shift_40)
+    c.push(contribution)
+    contribution = product_carry0                                       # range 32..64
+    contribution = macc(contribution, product_carry1, shift_8)
+    contribution = macc(contribution, high0, minus_one)                 # - high
+    contribution = macc(contribution, high1, minus_shift_8)
+    contribution = macc(contribution, high2, minus_shift_16)
+    contribution = macc(contribution, high3, minus_shift_24)
+    tmp = c.mul(a3, b1)                                                 # 32..
+    tmp = macc(tmp, a2, b2)
+    tmp = macc(tmp, a1, b3)
+    contribution = c.add(contribution, tmp)
+    tmp = c.mul(a3, b2)                                                 # 40..
+    tmp = macc(tmp, a2, b3)
+    contribution = macc(contribution, tmp, shift_8)
+    tmp = c.mul(a3, b3)                                                 # 48..
+    contribution = macc(contribution, tmp, shift_16)
+    c.push(contribution)
 
 
-def matrix_multiplication_program(matrix):
-    """MatrixMultiplicationGate<N> (matrix_multiplication_gate.rs:110-140): result = M * input, M a global constant."""
+def evaluate_fma_in_extension(c):
+    """FmaGateInExtensionWithoutConstantConstraintEvaluator, fma_gate_in_extension_without_constant.rs:116-200: q * a * b + l * c
+    = d over F_p[u]/(u^2 - 7); a, b, c, d in variables, q, l row-shared constants, all as (c0, c1) pairs."""
+    a_c0, a_c1, b_c0, b_c1, c_c0, c_c1, d_c0, d_c1 = (c.var(i) for i in range(8))
+    q_c0, q_c1, l_c0, l_c1 = (c.const_poly(i) for i in range(4))
+    non_residue = c.value(7)
+    macc = c.mul_and_accumulate_into
+    linear_c0 = c.mul(c_c0, l_c0)
+    t = c.mul(c_c1, l_c1)
+    linear_c0 = macc(linear_c0, t, non_residue)
+    linear_c1 = c.mul(c_c0, l_c1)
+    linear_c1 = macc(linear_c1, c_c1, l_c0)
+    inner_c0 = c.mul(a_c0, b_c0)
+    t = c.mul(a_c1, b_c1)
+    inner_c0 = macc(inner_c0, t, non_residue)
+    inner_c1 = c.mul(a_c0, b_c1)
+    inner_c1 = macc(inner_c1, a_c1, b_c0)
+    final_c0 = c.mul(inner_c0, q_c0)
+    t = c.mul(inner_c1, q_c1)
+    final_c0 = macc(final_c0, t, non_residue)
+    final_c1 = c.mul(inner_c0, q_c1)
+    final_c1 = macc(final_c1, inner_c1, q_c0)
+    final_c0 = c.add(final_c0, linear_c0)
+    final_c1 = c.add(final_c1, linear_c1)
+    c.push(c.sub(final_c0, d_c0))
+    c.push(c.sub(final_c1, d_c1))
+
+
+def evaluate_matrix_multiplication(c, matrix):
+    """MatrixMultiplicationEvaluator<N>, matrix_multiplication_gate.rs:98-125: result = M * input, M a global constant."""
     n = len(matrix)
-    b = GateProgramBuilder()
-    for r in range(n):
-        acc = None
-        for c in range(n):
-            t = b.var(c) * int(matrix[r][c])
-            acc = t if acc is None else acc + t
-        b.push(acc - b.var(n + r))
-    return b.build()
+    inp = [c.var(i) for i in range(n)]
+    result = [c.var(n + i) for i in range(n)]
+    for idx, a in enumerate(result):
+        term = c.zero()
+        for b, coeff in zip(inp, matrix[idx]):
+            term = c.mul_and_accumulate_into(term, b, c.value(int(coeff)))
+        c.push(c.sub(term, a))
 
 
 def poseidon2_round_constants():
@@ -404,13 +475,116 @@ def poseidon2_round_constants():
     return [vals[12 * r: 12 * r + 12] for r in range(30)]
 
 
-def poseidon2_flattened_program():
-    """Poseidon2FlattenedGate<8, 12, 4> without witness columns (src/cs/gates/poseidon2.rs:165-410): the permutation over
-    130 variables — 12 inputs, 12 outputs, and a fresh variable for every S-box input from the second full round on
-    ("degree reset") — 118 relations.  ~3.4 k recorded operations on ~150 live slots."""
+POSEIDON2_M4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]     # poseidon2/params.rs:8-33
+POSEIDON2_INNER_SHIFTS = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]            # :35-36
+
+
+def poseidon2_external_matrix():
+    """EXTERNAL_MDS_MATRIX (poseidon2/params.rs:63-94): block circulant circ(2 M4, M4, M4)."""
+    return [[POSEIDON2_M4[r % 4][col % 4] * (2 if r // 4 == col // 4 else 1) for col in range(12)] for r in range(12)]
+
+
+def poseidon2_inner_matrix():
+    """INNER_ROUNDS_MATRIX (poseidon2/params.rs:96-105): all ones, diagonal 2^shift + 1."""
+    return [[(1 << POSEIDON2_INNER_SHIFTS[r]) + 1 if r == col else 1 for col in range(12)] for r in range(12)]
+
+
+def evaluate_poseidon2_flattened(c, num_witness_columns_used=0):
+    """Poseidon2RoundFunctionFlattenedEvaluator<F, 8, 12, 4, Poseidon2Goldilocks>, poseidon2.rs:166-391: the permutation over 12
+    inputs, 12 outputs and a fresh cell ("degree reset") for every S-box input from the second full round on — witness columns
+    first while they last, then copiable ones.  Both linear layers are recorded as the reference records them: dense 12 x 12
+    products with the matrices as global constants (:114-147), 288 relations each, ~9.5 k relations in all."""
     rc = poseidon2_round_constants()
-    m4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
-    shifts = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]
+    full_rc = rc[:4] + rc[26:]                              # full_round_constants()[round]
+    partial_rc = [rc[4 + r][0] for r in range(22)]          # inner_round_constants()[round]
+    external_matrix = [[c.value(x) for x in row] for row in poseidon2_external_matrix()]
+    inner_matrix = [[c.value(x) for x in row] for row in poseidon2_inner_matrix()]
+    off = {"var": 24, "wit": 0}
+
+    def next_cell():
+        if off["wit"] < num_witness_columns_used:
+            off["wit"] += 1
+            return c.wit(off["wit"] - 1)
+        off["var"] += 1
+        return c.var(off["var"] - 1)
+
+    def matmul(matrix, old_state):
+        out = []
+        for i in range(12):
+            tmp = c.zero()
+            for src, coeff in zip(old_state, matrix[i]):
+                tmp = c.mul_and_accumulate_into(tmp, src, coeff)
+            out.append(tmp)
+        return out
+
+    def reset_degree(state):
+        for i in range(12):
+            cell = next_cell()
+            c.push(c.sub(state[i], cell))
+            state[i] = cell
+
+    state = [c.var(i) for i in range(12)]
+    output = [c.var(12 + i) for i in range(12)]
+    for rnd in range(4):
+        if rnd != 0:
+            reset_degree(state)
+        else:
+            state = matmul(external_matrix, state)
+        for idx in range(12):
+            state[idx] = c.small_pow(c.add(state[idx], c.value(full_rc[rnd][idx])), 7)
+        state = matmul(external_matrix, state)
+    for rnd in range(22):
+        state[0] = c.add(state[0], c.value(partial_rc[rnd]))
+        cell = next_cell()
+        c.push(c.sub(state[0], cell))
+        state[0] = c.small_pow(cell, 7)
+        state = matmul(inner_matrix, state)
+    for k in range(4):
+        reset_degree(state)
+        for idx in range(12):
+            state[idx] = c.small_pow(c.add(state[idx], c.value(full_rc[4 + k][idx])), 7)
+        state = matmul(external_matrix, state)
+    for src, dst in zip(state, output):
+        c.push(c.sub(dst, src))
+
+
+def _program(evaluate, *args, **kw):
+    b = GateProgramBuilder()
+    evaluate(b, *args, **kw)
+    return b.build()
+
+
+def fma_program(): return _program(evaluate_fma)
+def reduction4_program(): return _program(evaluate_reduction, 4)
+def constants_allocator_program(): return _program(evaluate_constants_allocator)
+def selection_program(): return _program(evaluate_selection)
+def dot_product4_program(): return _program(evaluate_dot_product, 4)
+def zero_check_program(use_witness_column_for_inversion=False): return _program(evaluate_zero_check, use_witness_column_for_inversion)
+def uintx_add_program(): return _program(evaluate_uintx_add)
+def boolean_program(): return _program(evaluate_boolean)
+def parallel_selection4_program(): return _program(evaluate_parallel_selection, 4)
+def u8x4_fma_program(): return _program(evaluate_u8x4_fma)
+def conditional_swap_program(n=1): return _program(evaluate_conditional_swap, n)
+def quadratic_combination_program(n=4): return _program(evaluate_quadratic_combination, n)
+def reduction_by_powers_program(n=4): return _program(evaluate_reduction_by_powers, n)
+def simple_non_linearity_program(n=7): return _program(evaluate_simple_non_linearity, n)
+def u32_add_program(): return _program(evaluate_u32_add)
+def u32_sub_program(): return _program(evaluate_u32_sub)
+def u32_tri_add_carry_as_chunk_program(): return _program(evaluate_u32_tri_add_carry_as_chunk)
+def fma_in_extension_program(): return _program(evaluate_fma_in_extension)
+def matrix_multiplication_program(matrix): return _program(evaluate_matrix_multiplication, matrix)
+
+
+def poseidon2_flattened_program(num_witness_columns_used=0):
+    """The reference's own capture of the gate (~9.5 k relations)."""
+    return _program(evaluate_poseidon2_flattened, num_witness_columns_used)
+
+
+def poseidon2_flattened_compact_program():
+    """The same 118 terms from the structured linear layers (out = M4 (x_b + sum x_b); x_i 2^s_i + sum x): ~3.4 k relations.  A
+    restatement for checking the capture above and for the CPU oracle's column-wise evaluation, not what a host sends."""
+    rc = poseidon2_round_constants()
+    m4, shifts = POSEIDON2_M4, POSEIDON2_INNER_SHIFTS
     b = GateProgramBuilder()
 
     def ext(st):

@@ -43,6 +43,7 @@ class GateDesc:
     path: list = field(default_factory=list)   # selector path, True = constant, False = 1 - constant
     program: object = None   # op list for kind GATE_PROGRAM (and, optionally, for the hand-written kinds)
     wit_stride: int = 0      # per_chunk_offset.witnesses_offset: non-copiable witness columns per repetition
+    params: object = None    # the evaluator's own parameters (MatrixMultiplicationGate: the matrix)
 
 
 def sha_bench_gates(num_gp_vars=60, num_constant_cols=4):
@@ -78,6 +79,21 @@ def witness_gates(num_gp_vars=60, num_constant_cols=4, num_witness_cols=5):
     reps = min(num_gp_vars // 2, num_witness_cols)
     zc = GateDesc(GATE_PROGRAM, "ZeroCheckGate[witness]", 2, 0, 2, reps, 2, 0, 2, True, program=GP.zero_check_program(True), wit_stride=1)
     return g[:3] + [zc] + g[3:]
+
+
+HOST_MATRIX = [[(7 * r + 3 * k + 1) * 65537 % 99991 + 1 for k in range(12)] for r in range(12)]
+
+
+def host_gates(num_gp_vars=60, num_constant_cols=4, matrix=None):
+    """The bench's gates plus an evaluator the library cannot have been built with: MatrixMultiplicationGate<F, 12, PAR> with the
+    host's own matrix as its global constant (matrix_multiplication_gate.rs:75-125) — 288 recorded relations that exist only in
+    the op list handed over at setup, so its kernel is compiled at run time (csrc/gate_jit.hip)."""
+    from . import gate_program as GP
+    matrix = matrix or HOST_MATRIX
+    g = sha_bench_gates(num_gp_vars, num_constant_cols)
+    mm = GateDesc(GATE_PROGRAM, "MatrixMultiplicationGate[host]", 1, 0, 24, num_gp_vars // 24, 24, 0, 12, True,
+                  program=GP.matrix_multiplication_program(matrix), params=matrix)
+    return g[:3] + [mm] + g[3:]
 
 
 def recursion_gates(num_gp_vars=130, num_constant_cols=8, poseidon2_as_op_list=False):
@@ -316,6 +332,17 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         elif g.name in ("BoundedBooleanConstraintGate", "BooleanConstraintGate"):     # over general-purpose columns: a bit per repetition
             for r in range(g.reps):
                 variables[r * g.var_stride, rows] = rng.integers(0, 2, size=m).astype(np.uint64)
+        elif g.name.startswith("MatrixMultiplicationGate"):        # result = M * input, M the evaluator's global constant
+            for r in range(g.reps):
+                base = r * g.var_stride
+                x = [rand_f(m) for _ in range(12)]
+                for k in range(12):
+                    variables[base + k, rows] = x[k]
+                for i in range(12):
+                    acc = np.zeros(m, dtype=np.uint64)
+                    for k in range(12):
+                        acc = F.add(acc, F.mul(x[k], np.uint64(int(g.params[i][k]) % P)))
+                    variables[base + 12 + i, rows] = acc
         elif g.name == "SelectionGate":
             for r in range(g.reps):
                 base = r * g.var_stride
@@ -521,8 +548,8 @@ def check_satisfied(c: Circuit):
             rows = np.flatnonzero(m)
             prog = g.program
             if prog is None:
-                from .gate_program import poseidon2_flattened_program
-                prog = poseidon2_flattened_program()
+                from .gate_program import poseidon2_flattened_compact_program
+                prog = poseidon2_flattened_compact_program()
             for r in range(g.reps):
                 vcols = [var[r * g.var_stride + k][rows] for k in range(g.principal_width)]
                 ccols = [consts[k][rows] for k in range(d + r * g.const_stride, consts.shape[0])]

@@ -42,7 +42,8 @@ typedef enum bj_status {
  * reference's `Worker` (src/worker/mod.rs:5-87, a rayon pool) + `P::Context` at the call sites. */
 typedef struct bj_ctx bj_ctx;
 
-#define BJ_ABI_VERSION 1
+/* 2: bj_gate_desc.wit_stride, bj_comm.all_gather_stream (round 2); 3: op lists in any numbering, run-time compiled gates */
+#define BJ_ABI_VERSION 3
 int bj_abi_version(void);
 int bj_device_count(void);
 const char *bj_status_string(int status);
@@ -256,9 +257,11 @@ int bj_fri_query(bj_ctx *ctx, const bj_fri *f, size_t oracle, size_t index, uint
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Whole prover (seam S1).  Replaces CSReferenceAssembly::prove_cpu_basic (src/cs/implementations/prover.rs:153-168)
- * and the prover-side part of get_full_setup (src/cs/implementations/setup.rs:1273-1300) for the circuit class of the
- * reference's SHA-256 bench: general-purpose gates selected by a selector tree, specialized lookups with a shared
- * constant table id, Poseidon2 tree hasher + Poseidon2 transcript, no witness columns, PoW off.
+ * and the prover-side part of get_full_setup (src/cs/implementations/setup.rs:1273-1300).  Circuit class: gates over
+ * general-purpose columns selected by a selector tree (the SHA-256 bench's four hand-written, any other evaluator as its
+ * gpu_synthesizer op list), gates over specialized columns, specialized lookups with a shared constant table id, witness
+ * (non-copiable) columns; tree hasher Poseidon2 / Blake2s / Keccak-256 with the matching transcript (and the bench script's
+ * Poseidon2 tree + Poseidon transcript pairing); Blake2s proof of work up to 32 bits.
  * ------------------------------------------------------------------------------------------------------------- */
 typedef enum bj_gate_kind {
     BJ_GATE_CONSTANT_ALLOCATOR = 1, /* a - c                      src/cs/gates/constant_allocator.rs:107-126          */
@@ -298,7 +301,8 @@ typedef struct bj_gate_program {
     uint32_t num_values;
     const bj_gate_index *writes; /* num_terms entries */
     uint32_t num_writes;
-    uint32_t num_temporaries; /* <= 160; era_boojum_amd/gate_program.py renames a trace onto the slots it needs */
+    uint32_t num_temporaries; /* every relations[i].dst < num_temporaries; any numbering (a temporary may be written once, as the
+                               * reference does, or reused): slots are assigned by the library */
 } bj_gate_program;
 
 typedef struct bj_gate_desc {
@@ -313,9 +317,35 @@ typedef struct bj_gate_desc {
     const bj_gate_program *program; /* BJ_GATE_PROGRAM only, NULL otherwise */
 } bj_gate_desc;
 
-/* 1 if the library carries a generated straight-line kernel for exactly this program (era_boojum_amd/gate_codegen.py emits one
- * for every evaluator it knows, keyed by a hash of the op list), 0 if it will run in the interpreter.  Host-only, no GPU. */
+/* What the library does with an op list, in this order: (1) it is brought into canonical form (era_boojum_amd/csrc/gate_canon.h:
+ * DAG with common subexpressions merged, slots by live range, a structural fingerprint that does not depend on the numbering
+ * of temporaries or on the order of independent relations) — so a GPUDataCapture goes in as the reference records it, one
+ * fresh temporary per operation from its process-wide counter (gpu_synthesizer/mod.rs:210-352), renumbered densely or not;
+ * (2) if the fingerprint is that of an evaluator the library was built with (every evaluator of src/cs/gates/, traced call by
+ * call in era_boojum_amd/gate_program.py), its build-time straight-line kernel runs — the reference's capture of
+ * Poseidon2FlattenedGate selects the hand-written evaluator; (3) otherwise a straight-line kernel is compiled from the op
+ * list at bj_setup_create with hiprtc and cached per process (and on disk when BJ_GATE_JIT_CACHE names a directory);
+ * (4) without hiprtc, or with BJ_GATE_NO_JIT set, an interpreter kernel runs the canonical schedule.  Same terms every way. */
+
+/* 1 if the library carries a build-time kernel for this program's function (2 above), 0 otherwise.  Host-only, no GPU. */
 int bj_gate_program_generated(const bj_gate_program *program);
+
+/* Canonical form of a program: fp[2] = structural fingerprint, *num_slots = values live at once in the canonical schedule,
+ * *num_ops = operations after merging, extents3 = {variable, constant, witness} columns one repetition reads.  Any out pointer
+ * may be NULL.  BJ_ERR_INVALID_ARG for a malformed list (use of an unwritten temporary, bad operand).  Host-only. */
+int bj_gate_program_canonical_info(const bj_gate_program *program, uint64_t fp[2], uint32_t *num_slots, uint32_t *num_ops,
+                                   uint32_t *extents3);
+/* The straight-line statements of the canonical program (what both the build-time generator and the run-time compiler emit),
+ * NUL-terminated into out[cap]; returns the size needed including the terminator (call with out = NULL to ask), 0 on error. */
+size_t bj_gate_program_emit_body(const bj_gate_program *program, char *out, size_t cap);
+/* The complete HIP source the run-time compiler is given for this program; same calling convention. */
+size_t bj_gate_program_jit_source(const bj_gate_program *program, char *out, size_t cap);
+/* Compile that source for `arch` (NULL: "gfx950") without loading it: BJ_OK, BJ_ERR_UNSUPPORTED when hiprtc is not installed,
+ * BJ_ERR_INVALID_ARG with the compiler's log in log[log_cap].  Host-only (works without a GPU). */
+int bj_gate_program_jit_compile_check(const bj_gate_program *program, const char *arch, char *log, size_t log_cap);
+/* Number of gate kernels this process obtained at run time (compiled or read from BJ_GATE_JIT_CACHE); a one-line status or
+ * the reason of the last failure into out[cap]. */
+int bj_gate_jit_status(char *out, size_t cap);
 
 /* Evaluate a gate program at n_points points (stand-alone, for parity tests of S3): d_terms[(rep*num_writes + t)*n_points + i]
  * = term t of repetition rep at point i.  d_vars / d_consts: columns with the given strides, constants WITHOUT a selector
@@ -418,9 +448,9 @@ int bj_setup_create(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_si
  * exchange only: cap fragments, the quotient evaluations (when a rank owns fewer than quotient_degree cosets), the first
  * folded FRI layer and the query openings.  Main-domain work (iNTTs, copy-permutation and lookup polynomials, openings at
  * z from the rank's own first coset) is replicated, so every rank ends with the same transcript state and the SAME proof,
- * bit for bit the one a single GPU produces.  The library does not link a communication library: the host hands in an
- * all-gather over device buffers (era_boojum_amd/binding.py wraps torch.distributed: nccl = RCCL over xGMI in production,
- * gloo in the tests).  Requirements: world | fri_lde_factor, world | cap_size, quotient_degree <= fri_lde_factor. */
+ * bit for bit the one a single GPU produces.  The all-gather is the library's own (bj_comm_rccl_create below: ncclAllGather
+ * of RCCL on the proof's stream, librccl dlopen'ed) or one the host hands in through bj_comm (era_boojum_amd/binding.py wraps
+ * torch.distributed that way: gloo in the tests).  Requirements: world | fri_lde_factor, world | cap_size, quotient_degree <= fri_lde_factor. */
 typedef struct bj_comm {
     unsigned rank, world;
     /* every rank contributes `bytes` at d_send; on return d_recv holds world*bytes, rank-major.  Called with the

@@ -98,9 +98,9 @@ def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec, wits_q=No
     def program_of(g):
         if getattr(g, "program", None) is not None:
             return g.program
-        from era_boojum_amd.gate_program import poseidon2_flattened_program
+        from era_boojum_amd.gate_program import poseidon2_flattened_compact_program
         assert g.name == "Poseidon2FlattenedGate"
-        return poseidon2_flattened_program()
+        return poseidon2_flattened_compact_program()      # the same 118 terms in 2.4 k column operations instead of 9.6 k
 
     def weighted(prog, vcols, ccols, alphas, aoff, wcols=()):
         s0, s1 = np.zeros(Qn, dtype=np.uint64), np.zeros(Qn, dtype=np.uint64)

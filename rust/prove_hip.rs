@@ -48,6 +48,11 @@ unsafe impl Send for HipCtx {}
 
 impl HipCtx {
     pub fn new(device: i32) -> Result<Self, String> {
+        // struct layouts (bj_gate_desc, bj_comm, ...) are those of the header these bindings were generated from
+        let abi = unsafe { bj_abi_version() };
+        if abi != BJ_ABI_VERSION as i32 {
+            return Err(format!("libboojum_hip reports ABI version {abi}, boojum_hip_sys.rs was generated for {BJ_ABI_VERSION}"));
+        }
         let mut raw = std::ptr::null_mut();
         let rc = unsafe { bj_ctx_create(device, &mut raw) };
         if rc != BJ_OK {
@@ -102,8 +107,11 @@ fn index_of(ix: &Index<F>, values: &mut Vec<u64>) -> bj_gate_index {
 }
 
 /// One `GPUDataCapture` (gpu_synthesizer/mod.rs:354-444) as the arrays of a `bj_gate_program`.  The capture numbers its
-/// temporaries globally (one counter per process); they are renumbered densely here, which also keeps them inside the
-/// interpreter's register budget (160 live values, era_boojum_amd/gate_program.py does the same renaming by live range).
+/// temporaries globally (one fresh number per operation from a counter per process); they are renumbered densely here only
+/// to keep `num_temporaries` small.  Nothing else is needed on this side: the library brings every list into a canonical
+/// form (csrc/gate_canon.h — slots by live range, common subexpressions merged, a structural fingerprint independent of
+/// numbering and relation order), picks its build-time kernel for the evaluators of src/cs/gates/ by that fingerprint and
+/// compiles one at `bj_setup_create` for any other capture.
 pub struct OwnedProgram {
     relations: Vec<bj_gate_relation>,
     values: Vec<u64>,

@@ -56,7 +56,6 @@ CASES = [  # program, formula, variables, constants, a satisfying assignment (or
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_traced_program_equals_the_reference_formula(case):
     prog, formula, nv, nc, sat = CASES[case]
-    assert prog.num_temporaries <= 160                     # BJ_GATE_PROGRAM_MAX_TEMPORARIES
     for _ in range(20):
         v, c = rv(nv), rv(nc)
         assert prog.evaluate(v, c) == formula(v, c)
@@ -71,17 +70,29 @@ def test_traced_program_equals_the_reference_formula(case):
             assert prog.evaluate(v, c) == [0]
 
 
-def test_slot_renaming_keeps_the_semantics_and_shrinks_the_register_file():
+def _canonical_info(prog):
+    import ctypes as C
+    import era_boojum_amd as E
+    lib = E.load_library()
+    fp, ns, no, ext = (C.c_uint64 * 2)(), C.c_uint32(), C.c_uint32(), (C.c_uint32 * 3)()
+    rc = lib.bj_gate_program_canonical_info(C.byref(prog.struct), fp, C.byref(ns), C.byref(no), ext)
+    assert rc == 0, rc
+    return (fp[0], fp[1]), ns.value, no.value, tuple(ext)
+
+
+def test_the_library_assigns_slots_by_live_range_whatever_the_numbering():
     b = G.GateProgramBuilder()
     xs = [b.var(i) for i in range(6)]
     acc = xs[0] * xs[1]
     for i in range(200):                                   # a long chain: every intermediate dies at once
         acc = acc * xs[i % 6] + xs[(i + 1) % 6]
-    keep = xs[2] * xs[3]                                   # a term computed early and written late stays live
+    keep = xs[2] * xs[3]                                   # a term computed early and written late
     b.push(acc)
     b.push(keep - acc)
     prog = b.build()
-    assert len(prog.relations) == 403 and prog.num_temporaries <= 4
+    assert len(prog.relations) == 403 and prog.num_temporaries == 403        # one temporary per relation, like the reference
+    fp, slots, ops, ext = _canonical_info(prog)
+    assert slots <= 3 and ops == 403 and ext == (6, 0, 0)
     v = rv(6)
     acc = v[0] * v[1]
     for i in range(200):
@@ -93,11 +104,15 @@ def test_poseidon2_flattened_gate_equals_the_golden_pinned_evaluator():
     """The 118-relation gate of the recursion circuits (poseidon2.rs:165-410) as a traced op list against
     oracle/gates.py::ev_poseidon2_flattened, whose formulas the reference's own proof pins (tests/test_oracle_fixture.py)."""
     from oracle import gates as OG
-    prog = G.poseidon2_flattened_program()
-    assert prog.num_terms == 118 and prog.num_temporaries <= 160 and len(prog.relations) < 3000
+    prog, compact = G.poseidon2_flattened_program(), G.poseidon2_flattened_compact_program()
+    assert prog.num_terms == 118 and 9000 < len(prog.relations) < 10000       # dense 12 x 12 layers, as the reference records them
+    assert compact.num_terms == 118 and len(compact.relations) < 3000
     for _ in range(3):
         v = rv(130)
-        assert prog.evaluate(v, []) == [t[0] for t in OG.ev_poseidon2_flattened([(x, 0) for x in v], [])]
+        want = [t[0] for t in OG.ev_poseidon2_flattened([(x, 0) for x in v], [])]
+        assert prog.evaluate(v, []) == want and compact.evaluate(v, []) == want
+    fp, slots, ops, ext = _canonical_info(prog)
+    assert slots <= 64 and ops < 6000 and ext == (130, 0, 0)                  # x*1 and 0+x gone, shared prefix sums merged
 
 
 def test_oracle_prover_handles_op_list_and_specialized_gates():
@@ -120,8 +135,8 @@ def test_oracle_prover_handles_op_list_and_specialized_gates():
 
 
 def test_generated_kernels_cover_the_known_programs_and_the_committed_file_is_current():
-    """csrc/gate_aot.hip is what gate_codegen.generate() emits today, and the library recognises exactly the known programs by
-    their content hash (computed in python by gate_codegen.program_hash and in C++ by DevProgram::upload — the same walk)."""
+    """csrc/gate_aot.hip is what gate_codegen.generate() emits today, and the library recognises the known programs by the
+    structural fingerprint of their canonical form (csrc/gate_canon.cpp: the generator asks the same code)."""
     import ctypes as C
     import os
     import era_boojum_amd as E
@@ -131,39 +146,12 @@ def test_generated_kernels_cover_the_known_programs_and_the_committed_file_is_cu
     lib = E.load_library()
     for name, prog in GC.known_programs().items():
         assert lib.bj_gate_program_generated(C.byref(prog.struct)) == 1, name
-    assert lib.bj_gate_program_generated(C.byref(G.matrix_multiplication_program(MATRIX).struct)) == 0     # host-chosen matrix
-    assert lib.bj_gate_program_generated(C.byref(G.poseidon2_flattened_program().struct)) == 0            # has its own kind
+        assert _canonical_info(prog)[0] == GC.program_fingerprint(prog)       # helper library == product library
+    assert lib.bj_gate_program_generated(C.byref(G.matrix_multiplication_program(MATRIX).struct)) == 0     # host-chosen matrix: compiled at run time
+    assert lib.bj_gate_program_generated(C.byref(G.poseidon2_flattened_program().struct)) == 1            # -> the hand-written evaluator
+    assert lib.bj_gate_program_generated(C.byref(G.poseidon2_flattened_program(12).struct)) == 0          # other cell placement: compiled
     b = G.GateProgramBuilder()
     b.push(b.var(0) * b.var(1) - b.var(2) + 5)
     assert lib.bj_gate_program_generated(C.byref(b.build().struct)) == 0                                   # a host's own gate
 
 
-def test_captures_in_the_references_own_order_and_numbering():
-    """Op lists as `GPUDataCapture::from_evaluator` records them (tests/reference_capture.py: the call order of evaluate_once,
-    fresh temporaries from a process-wide counter), converted the way rust/prove_hip.rs converts them, give the golden-pinned
-    formulas of oracle/gates.py."""
-    import random
-    import reference_capture as RC
-    from oracle import gates as OG
-    rnd = random.Random(5)
-    e = lambda x: (x % P, 0)
-    for cap_fn, ev, nv, nc, nw in ((RC.capture_fma, OG.ev_fma, 4, 2, 0), (RC.capture_zero_check, OG.ev_zero_check, 3, 0, 0),
-                                   (RC.capture_uintx_add, OG.ev_uintx_add, 5, 1, 0),
-                                   (lambda: RC.capture_zero_check(True), OG.ev_zero_check_witness, 2, 0, 1)):
-        cap = cap_fn()
-        tmps = [dst[1] for dst, _ in cap.relations]
-        assert min(tmps) > 900 and len(set(tmps)) == len(tmps)            # global counter: sparse, never reused
-        prog = RC.to_program(cap)
-        assert prog.num_temporaries == len(cap.relations)
-        for _ in range(20):
-            var = [rnd.randrange(P) for _ in range(nv)]
-            con = [rnd.randrange(P) for _ in range(nc)]
-            wit = [rnd.randrange(P) for _ in range(nw)]
-            want = ev([e(v) for v in var], [e(c) for c in con], [e(w) for w in wit]) if nw else ev([e(v) for v in var], [e(c) for c in con])
-            assert prog.evaluate(var, con, wit) == [t[0] for t in want]
-    # the tracer of era_boojum_amd/gate_program.py and the capture agree term by term (different op order and slot numbering)
-    for cap_fn, mine in ((RC.capture_fma, G.fma_program()), (RC.capture_uintx_add, G.uintx_add_program()),
-                         (RC.capture_zero_check, G.zero_check_program())):
-        prog = RC.to_program(cap_fn())
-        var, con = [rnd.randrange(P) for _ in range(8)], [rnd.randrange(P) for _ in range(4)]
-        assert prog.evaluate(var, con) == mine.evaluate(var, con)

@@ -1,0 +1,113 @@
+"""-m gpu: seam S3 with what the reference emits (src/gpu_synthesizer/mod.rs:210-444).  Every evaluator's capture in the
+reference's own call order and numbering (tests/reference_capture.py: sparse temporaries from a process-wide counter) runs on
+the device — through its build-time kernel, the kernel compiled at run time from the op list, or the interpreter — and gives
+the independent formulas' terms; a proof whose circuit carries a gate the library was not built with (a host's own matrix)
+equals the oracle prover's proof, with and without the run-time compiler."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import era_boojum_amd as E
+from era_boojum_amd import proof_format, synthetic as S
+from gpu_util import DevBuf, ctx, rand_gl, P
+from oracle import prover as OP
+from oracle import verifier as OV
+import reference_capture as RC
+import test_gate_canon as TC
+
+pytestmark = pytest.mark.gpu
+
+
+def jit_status():
+    buf = C.create_string_buffer(512)
+    n = E.load_library().bj_gate_jit_status(buf, 512)
+    return n, buf.value.decode()
+
+
+@pytest.mark.parametrize("name", sorted(TC.CAPTURES))
+def test_capture_order_lists_on_the_device(name):
+    thunk, nv, nc, nw = TC.CAPTURES[name]
+    prog = RC.to_program_raw(thunk())                       # the reference's own sparse numbers, not even renumbered
+    reps = 1 if nv > 100 else 3
+    n_points = 256 if nv > 100 else 600
+    rng = np.random.default_rng(nv * 31 + nc)
+    var = rand_gl(rng, (max(1, nv) * reps, n_points), noncanonical=True)
+    con = rand_gl(rng, (max(1, nc), n_points), noncanonical=True)
+    d_var, d_con, d_out = DevBuf(var), DevBuf(con), DevBuf(nelems=reps * prog.num_terms * n_points)
+    if nw:      # the stand-alone evaluator takes no witness columns: covered through a whole proof in test_gpu_gate_program.py
+        with pytest.raises(E.BoojumHipError, match="witness"):
+            ctx().gate_program_eval(prog, d_var.ptr, n_points, d_con.ptr, n_points, reps, nv, 0, n_points, d_out.ptr)
+        return
+    before = jit_status()[0]
+    ctx().gate_program_eval(prog, d_var.ptr, n_points, d_con.ptr, n_points, reps, nv, 0, n_points, d_out.ptr)
+    got = d_out.get((reps, prog.num_terms, n_points))
+    for i in range(0, n_points, 41 if nv > 100 else 37):
+        for r in range(reps):
+            v = [int(x) % P for x in var[r * nv:(r + 1) * nv, i]]
+            c = [int(x) % P for x in con[:nc, i]]
+            assert [int(x) for x in got[r, :, i]] == TC.want_terms(name, v, c, []), (name, i, r)
+    if name == "matrix_multiplication_host_matrix" and not os.environ.get("BJ_GATE_NO_JIT"):
+        n, status = jit_status()
+        assert n >= max(1, before), status                  # compiled (or cached) at run time, not interpreted
+    for d in (d_var, d_con, d_out):
+        d.free()
+
+
+def _prove_host_gate_circuit():
+    c = S.sha_shaped_circuit(10, seed=5, table_bits=2, gates=S.host_gates(), mix=(0.05, 0.3, 0.3, 0.2))
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    buf, _ = gsetup.prove()
+    cap = gsetup.cap()
+    gsetup.close()
+    return c, buf, cap
+
+
+def test_proof_with_a_hosts_own_gate_equals_the_oracle_proof(tmp_path):
+    """MatrixMultiplicationGate with a matrix only the host knows: no build-time kernel can exist.  The HIP proof (gate kernel
+    compiled at bj_setup_create) equals the oracle prover's proof, the verifier restatement accepts it, and a process with
+    BJ_GATE_NO_JIT=1 (the interpreter on the canonical schedule) produces the same bytes."""
+    from test_gpu_prover import _compare
+    c, buf, cap = _prove_host_gate_circuit()
+    n, status = jit_status()
+    if not os.environ.get("BJ_GATE_NO_JIT"):
+        assert n >= 1, status
+    osetup = OP.Setup(c, 8, 16, threads=8)
+    assert np.array_equal(cap, osetup.cap)
+    po = OP.prove(c, osetup, 8, 16, security_level=30, threads=8)
+    pg = proof_format.parse(buf, security_level=30)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg, verbose=True)
+    out = os.path.join(str(tmp_path), "proof.npy")
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; torch.cuda.init();"
+            "import test_gpu_gate_capture as T; np.save(%r, T._prove_host_gate_circuit()[1])") % (os.path.dirname(here), here, out)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BJ_GATE_NO_JIT="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load(out), buf)
+
+
+def test_recursion_class_circuit_from_capture_order_lists_only():
+    """The circuit of the golden proof's class with EVERY evaluator handed over as the reference would capture it (sparse
+    numbering, evaluate_once order; the Poseidon2 flattened gate as its 9.6 k-relation list): each list finds its build-time
+    kernel / the hand-written Poseidon2 evaluator, and the proof is the one the hand-wired kinds give, byte for byte."""
+    a = S.recursion_like_circuit(10, seed=9)
+    b = S.recursion_like_circuit(10, seed=9, poseidon2_as_op_list=True)
+    lib = E.load_library()
+    names = {"U8x4FMAGate": "u8x4_fma", "Poseidon2FlattenedGate": "poseidon2_flattened", "DotProductGate<4>": "dot_product4",
+             "ZeroCheckGate": "zero_check", "UIntXAddGate": "uintx_add", "SelectionGate": "selection",
+             "ParallelSelectionGate<4>": "parallel_selection4", "FmaGateInBaseFieldWithoutConstant": "fma",
+             "ReductionGate<4>": "reduction4", "ConstantsAllocatorGate": "constants_allocator"}
+    for g in b.gates:
+        if g.name in names:
+            g.program = RC.to_program_raw(TC.CAPTURES[names[g.name]][0]())
+            g.kind = S.GATE_PROGRAM
+            assert lib.bj_gate_program_generated(C.byref(g.program.struct)) == 1, g.name
+    sa, sb = E.ProverSetup(ctx(), a, 2, 32, 30), E.ProverSetup(ctx(), b, 2, 32, 30)
+    pa, _ = sa.prove()
+    pb, _ = sb.prove()
+    assert np.array_equal(pa, pb)
+    sa.close(); sb.close()

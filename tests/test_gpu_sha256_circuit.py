@@ -84,6 +84,27 @@ def test_hip_proof_at_2p18_rows_equals_oracle_proof():
     gsetup.close()
 
 
+def test_hip_proof_at_2p20_rows_equals_oracle_proof_under_both_bench_transcripts():
+    """BASELINE config 3 (cfg3): the real SHA-256 circuit at 2^20 rows (SHA-256 of ~139 kB), the bench's parameters (LDE 8, cap
+    16, security 100, no PoW), full prove incl. Poseidon2 Merkle trees and FRI: the HIP proof equals the oracle prover's proof
+    — every cap, opening, FRI layer, final monomial and all query openings — under the golden-pinned Poseidon2 transcript and
+    under the bench script's Poseidon one (prover.rs:153-168 is the function replaced).  ~1.5 minutes of oracle time."""
+    c = S.sha256_circuit(S.bench_message(139000, seed=13))
+    assert c.log_n == 20
+    osetup = OP.Setup(c, 8, 16, threads=64)
+    for transcript, kind in (("poseidon2", 1), ("poseidon", 2)):
+        po = OP.prove(c, osetup, 8, 16, security_level=100, threads=64, transcript_kind=kind)
+        gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript=transcript)
+        assert np.array_equal(gsetup.cap(), osetup.cap)
+        buf, _ = gsetup.prove()
+        pg = proof_format.parse(buf, security_level=100)
+        _compare(pg, po)
+        if kind == 1:
+            assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg)
+        gsetup.close()
+        del po, pg
+
+
 def test_prove_from_memcopy_dumps():
     """A Rust host's `SetupBaseStorage` / `WitnessVec` / `DenseVariablesCopyHint` dumps (era_boojum_amd/memcopy_format.py)
     give the same proof as the in-memory circuit."""
