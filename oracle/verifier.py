@@ -74,6 +74,32 @@ def vk_from_reference_geometry(geometry, setup_cap, general_gates, specialized_g
     return vk
 
 
+def _program_terms_ext(prog, var, con, wit):
+    """An op list (relations: (op, dst, (kind, index), (kind, index)); kinds 0 variable, 1 witness, 2 constant column, 3 temporary, 4
+    field constant; ops 1 add, 2 double, 3 sub, 4 negate, 5 mul, 6 square, 7 inverse — Relation / Index of gpu_synthesizer/mod.rs:113-133)
+    evaluated over F_p^2 values."""
+    tmp = {}
+
+    def get(ref):
+        k, i = ref
+        if k == 0: return var[i]
+        if k == 1: return wit[i]
+        if k == 2: return con[i]
+        if k == 3: return tmp[i]
+        return (prog.values[i] % P, 0)
+    for op, dst, a, b in prog.relations:
+        x = get(a)
+        if op == 1: r = eadd(x, get(b))
+        elif op == 2: r = eadd(x, x)
+        elif op == 3: r = esub(x, get(b))
+        elif op == 4: r = esub((0, 0), x)
+        elif op == 5: r = emul(x, get(b))
+        elif op == 6: r = emul(x, x)
+        else: r = einv(x)
+        tmp[dst] = r
+    return [get(w) for w in prog.writes]
+
+
 def _gate_terms_at(vk, var, con, wit=()):
     """[(selector, [terms...])] with var/con/wit = F_p^2 values of the variable / constant / witness polys at z."""
     out = []
@@ -100,6 +126,10 @@ def _gate_terms_at(vk, var, con, wit=()):
                 terms.append(esub(t, var[vb + 4]))
             else:                # any other evaluator, by name: the golden-pinned formulas of oracle/gates.py
                 from oracle.gates import EVALUATORS
+                if g.name not in EVALUATORS:     # a host's own evaluator: its op list over F_p^2 (the verifier's view of a capture)
+                    ws = getattr(g, "wit_stride", 0)
+                    terms.extend(_program_terms_ext(g.program, var[vb:], con[cb:], wit[r * ws:] if ws else ()))
+                    continue
                 width, fn = EVALUATORS[g.name][0], EVALUATORS[g.name][5]
                 ws = getattr(g, "wit_stride", 0)
                 if ws:       # the evaluator reads witness columns, relative to its repetition (per_chunk_offset.witnesses_offset)

@@ -14,7 +14,14 @@ from oracle import gates as OG
 import reference_capture as RC
 
 P = G.P
-lib = E.load_library()
+
+
+class _Lib:      # resolved at first use: the GPU tests import this module and must get torch's HIP runtime loaded first (gpu_util.ctx)
+    def __getattr__(self, name):
+        return getattr(E.load_library(), name)
+
+
+lib = _Lib()
 
 
 def info(prog):
