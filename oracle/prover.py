@@ -63,8 +63,9 @@ def lookup_polys(lookup_vars, table_id, tables, mult, reps, w, log_n, beta, gamm
 
 
 def quotient(vars_q, consts_q, sigmas_q, z_q, partials_q, A_q, B_q, mult_q, tables_q, circuit, log_q, alphas, beta, gamma,
-             lbeta, lgamma, threads=1):
-    """All inputs are [cols][q*n] restrictions of the LDEs to the first q cosets; returns T = numerator / (x^n - 1)."""
+             lbeta, lgamma, threads=1, coset_begin=0, coset_count=0):
+    """All inputs are [cols][q*n] restrictions of the LDEs to the first q cosets; returns T = numerator / (x^n - 1).  With
+    coset_count: only the cosets [coset_begin, coset_begin + coset_count) of those q, inputs [cols][coset_count*n]."""
     V, Q = vars_q.shape
     gf = gates_flat(circuit.gates)
     out = np.zeros((2, Q), dtype=np.uint64)
@@ -77,8 +78,9 @@ def quotient(vars_q, consts_q, sigmas_q, z_q, partials_q, A_q, B_q, mult_q, tabl
                        C.c_size_t(circuit.lookup_width), C.c_size_t(circuit.num_gp_vars), C.c_size_t(circuit.table_id_col),
                        gf.ctypes.data_as(C.POINTER(C.c_int)), C.c_size_t(len(circuit.gates)),
                        _p(_arr(circuit.non_residues)), C.c_size_t(circuit.quotient_degree), C.c_uint(circuit.log_n),
-                       C.c_uint(log_q), C.c_uint(0), _p(_arr(alphas).reshape(-1)), C.c_size_t(len(alphas)),
-                       _p(_arr(beta)), _p(_arr(gamma)), _p(_arr(lbeta)), _p(_arr(lgamma)), _p(out), C.c_int(threads))
+                       C.c_uint(log_q), C.c_uint(coset_begin), _p(_arr(alphas).reshape(-1)), C.c_size_t(len(alphas)),
+                       _p(_arr(beta)), _p(_arr(gamma)), _p(_arr(lbeta)), _p(_arr(lgamma)), _p(out), C.c_int(threads),
+                       C.c_size_t(coset_count))
     return out
 
 

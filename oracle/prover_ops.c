@@ -96,7 +96,9 @@ void orc_lookup_polys(const uint64_t *lookup_vars, const uint64_t *table_id, con
 }
 
 /* Quotient numerator / vanishing over the first q cosets of the LDE.  Every *_lde array is [cols][Q], Q = q*n, flat
- * index I = coset*n + i with i bit-reversed.  alphas: [n_alpha][2] in the reference's order
+ * index I = coset*n + i with i bit-reversed.  With coset_count != 0 the arrays hold only the cosets [coset_begin,
+ * coset_begin + coset_count) of those q (stride coset_count*n) and out_q is [2][coset_count*n]: the quotient is pointwise and
+ * z(omega x) stays inside a coset, so a caller short of memory evaluates it coset by coset (oracle/prover_streaming.py).  alphas: [n_alpha][2] in the reference's order
  * (lookup terms | specialized gate terms (none) | general purpose gate terms | (z-1)*L1 | copy-permutation chain).
  * gates: per gate 12 ints {kind, path_len, reps, var_stride, const_stride, num_terms, path[0..5]}. */
 typedef struct { int kind, path_len, reps, var_stride, const_stride, num_terms, path[6]; } orc_gate;
@@ -105,11 +107,12 @@ void orc_quotient(const uint64_t *vars, size_t V, const uint64_t *consts, size_t
                   const uint64_t *z, const uint64_t *partials, size_t n_partials, const uint64_t *lookA,
                   const uint64_t *lookB, const uint64_t *mult, const uint64_t *tables, size_t lookup_reps,
                   size_t lookup_w, size_t lookup_var_offset, size_t table_id_col, const int *gates_flat, size_t n_gates,
-                  const uint64_t *non_res, size_t chunk, unsigned log_n, unsigned log_q, unsigned log_lde_total,
+                  const uint64_t *non_res, size_t chunk, unsigned log_n, unsigned log_q, unsigned coset_begin,
                   const uint64_t *alphas, size_t n_alphas, const uint64_t *beta2, const uint64_t *gamma2,
-                  const uint64_t *lbeta2, const uint64_t *lgamma2, uint64_t *out_q, int threads) {
-    size_t n = (size_t)1 << log_n, q = (size_t)1 << log_q, Q = q * n;
-    (void)log_lde_total;
+                  const uint64_t *lbeta2, const uint64_t *lgamma2, uint64_t *out_q, int threads, size_t coset_count) {
+    size_t n = (size_t)1 << log_n, q = (size_t)1 << log_q;
+    if (coset_count == 0) { coset_begin = 0; coset_count = q; }
+    const size_t Q = coset_count * n;          /* stride of the arrays and number of points evaluated here */
     const orc_gate *gates = (const orc_gate *)gates_flat;
     gl2_t beta = gl2_make(beta2[0], beta2[1]), gamma = gl2_make(gamma2[0], gamma2[1]);
     gl2_t lbeta = gl2_make(lbeta2[0], lbeta2[1]), lgamma = gl2_make(lgamma2[0], lgamma2[1]);
@@ -128,8 +131,8 @@ void orc_quotient(const uint64_t *vars, size_t V, const uint64_t *consts, size_t
     gl_t wQ = gl_omega(log_Q);
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (size_t I = 0; I < Q; I++) {
-        size_t coset = I >> log_n, i_br = I & (n - 1);
-        gl_t x = gl_mul(GL_GEN, gl_pow(wQ, bitrev64(I, log_Q)));
+        size_t coset = I >> log_n, i_br = I & (n - 1);   /* coset: local to the arrays */
+        gl_t x = gl_mul(GL_GEN, gl_pow(wQ, bitrev64((size_t)coset_begin * n + I, log_Q)));
         gl2_t acc = gl2_make(0, 0);
         /* ---- gates over general purpose columns: sum_g sel_g * sum_t alpha_t * term_t ---- */
         size_t aoff = 0;

@@ -89,7 +89,7 @@ def test_hip_proof_at_2p20_rows_equals_oracle_proof_under_both_bench_transcripts
     16, security 100, no PoW), full prove incl. Poseidon2 Merkle trees and FRI: the HIP proof equals the oracle prover's proof
     — every cap, opening, FRI layer, final monomial and all query openings — under the golden-pinned Poseidon2 transcript and
     under the bench script's Poseidon one (prover.rs:153-168 is the function replaced).  ~1.5 minutes of oracle time."""
-    c = S.sha256_circuit(S.bench_message(139000, seed=13))
+    c = S.sha256_circuit(S.bench_message(S.message_len_for_log_n(20), seed=13))
     assert c.log_n == 20
     osetup = OP.Setup(c, 8, 16, threads=64)
     for transcript, kind in (("poseidon2", 1), ("poseidon", 2)):
@@ -103,6 +103,32 @@ def test_hip_proof_at_2p20_rows_equals_oracle_proof_under_both_bench_transcripts
             assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg)
         gsetup.close()
         del po, pg
+
+
+def test_hip_proof_at_2p22_rows_caps_and_openings_equal_the_oracle():
+    """BASELINE config 4's size, the bench's own workload (cfg4): the real SHA-256 circuit at 2^22 rows (SHA-256 of 557 kB,
+    bench parameters).  The full oracle prover would hold ~200 GB of LDEs; its coset-streaming restatement
+    (oracle/prover_streaming.py, checked against it on CPU) recomputes everything that enters the transcript before DEEP / FRI:
+    the witness, second-stage and quotient oracle caps over all 2^25 leaves each, all 241 values at z, z*omega and 0, and two
+    cosets' worth of the setup cap.  Whatever lies behind those — every iNTT / LDE coset, every leaf hash, the grand product,
+    the lookup polynomials, the quotient on 2^24 points, the barycentric openings — is thereby compared value for value at
+    the bench size; the rounds after them are compared at 2^20 above and accepted by the verifier restatement here.  ~4 minutes
+    of oracle time."""
+    from oracle import prover_streaming as PS
+    c = S.sha256_circuit(S.bench_message(S.message_len_for_log_n(22)))
+    assert c.log_n == 22
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript="poseidon2")
+    buf, _ = gsetup.prove()
+    cap = gsetup.cap()
+    gsetup.close()
+    pg = proof_format.parse(buf, security_level=100)
+    po = PS.commitments_and_openings(c, cap, 8, 16, threads=64, transcript_kind=1, check_setup_cosets=(0, 5))
+    for k in ("public_inputs", "witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z", "values_at_z_omega",
+              "values_at_0"):
+        assert pg[k] == po[k], k
+    for cs, frag in po["setup_cap_fragments"].items():
+        assert np.array_equal(frag, cap[2 * cs:2 * cs + 2]), "setup cap nodes of coset %d" % cs
+    assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg)
 
 
 def test_prove_from_memcopy_dumps():

@@ -75,3 +75,19 @@ def test_fri_lde_2_config_like_the_golden_proof():
     setup = OP.Setup(c, 2, 4, threads=4)
     proof = OP.prove(c, setup, 2, 4, security_level=20, threads=4)
     assert OV.verify(OV.VerificationKey(c, setup.cap, 2, 4), proof, verbose=True)
+
+
+def test_coset_streaming_restatement_equals_the_full_prover(small_case):
+    """oracle/prover_streaming.py (every LDE one coset at a time: what lets the 2^22-row bench circuit be checked within a
+    test's memory) gives the caps and openings of oracle/prover.py, under both algebraic transcripts."""
+    from oracle import prover_streaming as PS
+    c, setup, proof, aux, vk = small_case
+    for kind in (1, 2):
+        want = proof if kind == 1 else OP.prove(c, setup, 8, 16, security_level=30, threads=4, transcript_kind=2)
+        got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, transcript_kind=kind, check_setup_cosets=(0, 3, 7))
+        for k in ("public_inputs", "witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z", "values_at_z_omega",
+                  "values_at_0"):
+            assert got[k] == want[k], (kind, k)
+        for cs, frag in got["setup_cap_fragments"].items():
+            assert np.array_equal(frag, setup.cap[2 * cs:2 * cs + 2])
+    assert got["challenges"]["z"] != aux["z"]      # the other transcript draws other challenges: the comparison above is not vacuous
