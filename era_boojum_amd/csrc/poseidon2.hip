@@ -191,7 +191,10 @@ __device__ __forceinline__ u64 shl_plus(u64 a, u64 sum_lo, u64 sum_hi) {
 }
 
 }  // namespace bj
-#include "p2_asm.inc"   // generated (tools/gen_p2_asm.py): poseidon2_permutation_asm, the scheduled instruction stream
+#ifndef BJ_P2_ASM_INC     // tools/p2_variants.py builds the same library around other schedules of the stream
+#define BJ_P2_ASM_INC "p2_asm.inc"
+#endif
+#include BJ_P2_ASM_INC    // generated (tools/gen_p2_asm.py): poseidon2_permutation_asm, the scheduled instruction stream
 namespace bj {
 
 // state in: any u64 words; state out: weak words (canonicalise what leaves the sponge with gl::canon)

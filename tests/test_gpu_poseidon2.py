@@ -211,3 +211,63 @@ def test_permutation_takes_the_rare_branches_of_its_products():
         ctx().poseidon2_permute(d.ptr, batch.shape[0])
         assert np.array_equal(d.get(batch.shape), np.tile(want, (reps, 1)))
         d.free()
+
+
+def _ext_layer_carry_words(state, rc):
+    """Which output words of the first external layer wrap in the fold of their low / high plane sums (tools/gen_p2_asm.py
+    `combine`: T = A + B.hi * EPS, then T.hi + B.lo >= 2^32) — a model of the planes, not of the field arithmetic."""
+    M = _ext_matrix()
+    hit = []
+    for i in range(12):
+        A = sum(M[i][j] * (state[j] & 0xFFFFFFFF) for j in range(12)) + (rc[i] & 0xFFFFFFFF)
+        B = sum(M[i][j] * (state[j] >> 32) for j in range(12)) + (rc[i] >> 32)
+        T = A + (B >> 32) * 0xFFFFFFFF
+        if (T >> 32) + (B & 0xFFFFFFFF) >= 1 << 32:
+            hit.append(i)
+    return hit
+
+
+def test_permutation_takes_the_out_of_line_carry_of_the_linear_layers():
+    """The linear layers fold (low-plane sum, high-plane sum) into one word with ONE add on the high word; where that add wraps
+    (about 2^-25 per word in an external layer on random data) a wave-uniform branch adds 2^64 mod p out of line.  States are
+    built so that the first layer wraps in chosen words — all of them, single ones, lone lanes of a wave — and the model above
+    confirms they do; the partial rounds take their stubs on random data (2^-18 per word) in every large test."""
+    P = O.P
+    rc0 = [int(x) % P for x in O.poseidon_round_constants()[0]]
+    rng = np.random.default_rng(11)
+    M = _ext_matrix()
+    states = []
+    for rep in range(8):                                    # for every output word i: high halves solved so that B_i.lo = 2^32 - 1 - small
+        for i in range(12):
+            hi = [int(rng.integers(0, 1 << 32)) for _ in range(12)]
+            lo = [0xFFFFFFFF if rep % 2 == 0 else int(rng.integers(1 << 31, 1 << 32)) for _ in range(12)]
+            js = next(j for j in range(12) if M[i][j] % 2 == 1)            # an odd entry is invertible mod 2^32
+            rest = sum(M[i][j] * hi[j] for j in range(12) if j != js) + (rc0[i] >> 32)
+            want_lo = (0xFFFFFFFF - int(rng.integers(0, 8))) & 0xFFFFFFFF
+            hi[js] = (want_lo - rest) * pow(M[i][js], -1, 1 << 32) % (1 << 32)
+            st = [(h << 32) | l for h, l in zip(hi, lo)]
+            assert i in _ext_layer_carry_words(st, rc0)
+            states.append(st)
+    words = set()
+    for st in states:
+        words.update(_ext_layer_carry_words(st, rc0))
+    assert len(words) == 12                                 # every word's stub is reached by some state
+    st = np.array(states, dtype=np.uint64)
+    want = np.stack([O.poseidon2_permutation(np.array([x % P for x in s], dtype=np.uint64)) for s in states])
+    filler = rng.integers(0, P, size=(64 * 40, 12), dtype=np.uint64)
+    want_filler = np.stack([O.poseidon2_permutation(s) for s in filler])
+    for reps in (1, 33):
+        batch = np.tile(st, (reps, 1))
+        d = DevBuf(batch)
+        ctx().poseidon2_permute(d.ptr, batch.shape[0])
+        assert np.array_equal(d.get(batch.shape), np.tile(want, (reps, 1)))
+        d.free()
+    lone = filler.copy()                                    # one wrapping lane in otherwise random waves
+    expect = want_filler.copy()
+    for w in range(0, 40, 3):
+        lone[64 * w + (7 * w) % 64] = st[(5 * w) % len(states)]
+        expect[64 * w + (7 * w) % 64] = want[(5 * w) % len(states)]
+    d = DevBuf(lone)
+    ctx().poseidon2_permute(d.ptr, lone.shape[0])
+    assert np.array_equal(d.get(lone.shape), expect)
+    d.free()

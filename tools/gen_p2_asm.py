@@ -25,6 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "era_boojum_amd", "csrc", "p2_asm.inc")
 RC_INC = os.path.join(ROOT, "era_boojum_amd", "csrc", "poseidon_rc.inc")
 
+WAYS = int(os.environ.get("BJ_P2_WAYS", "2"))            # S-boxes interleaved in a full round (2, 3 or 4; v[24:71] holds four sets)
+assert WAYS in (2, 3, 4)
+COMBINE_INLINE = os.environ.get("BJ_P2_COMBINE", "") == "inline"
 SH = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]           # internal matrix 1 + diag(2^SH)  (poseidon2/params.rs:38-39)
 P = (1 << 64) - (1 << 32) + 1
 
@@ -160,13 +163,27 @@ class Gen:
     # ------------------------------------------------------------------------------------------------ folding a (low, high) pair of sums
     def combine(self, A, B, out, k01, mask):
         """out <- weak(A + B * 2^32) for 64-bit sums A, B < 2^48 held in pairs v[A:A+1], v[B:B+1]; k01: a 32-bit temporary.
-        B * 2^32 = B.hi * 2^64 + B.lo * 2^32 == B.hi * EPS + B.lo * 2^32: T = A + B.hi * EPS (no carry), then one add on
-        the high word; "+EPS" where that wrapped (the wrapped value is < 2^49: no second carry)."""
+        B * 2^32 = B.hi * 2^64 + B.lo * 2^32 == B.hi * EPS + B.lo * 2^32: T = A + B.hi * EPS (no carry, T.hi < 2^17), then one
+        add on the high word.  That add wraps only when B.lo >= 2^32 - T.hi: once in ~2^18 (partial rounds) to ~2^25 (external
+        layers) words, so the "+EPS" of a wrapped word (then < 2^49: no second carry) lives out of line behind a wave-uniform
+        branch — 2 VALU instructions per word instead of 4 (BJ_P2_COMBINE=inline restores the branch-free form)."""
+        if COMBINE_INLINE:
+            return [
+                Ins("v_mad_u64_u32 %s, vcc, v%d, -1, %s" % (vp(A), B + 1, vp(A))),
+                Ins("v_add_co_u32 v%d, %s, v%d, v%d" % (A + 1, sp(mask), A + 1, B), defs=[mask]),
+                Ins("v_cndmask_b32 v%d, 0, 1, %s" % (k01, sp(mask)), uses=[mask]),
+                Ins("v_mad_u64_u32 %s, vcc, v%d, -1, %s" % (vp(out), k01, vp(A))),
+            ]
+        back, stub = self.label("cb"), self.label("cf")
+        self.stubs += ["%s:" % stub, "s_nop 1", "v_cndmask_b32 v%d, 0, -1, %s" % (k01, sp(mask)),
+                       "v_add_co_u32 v%d, vcc, v%d, v%d" % (out, out, k01), "s_nop 1",
+                       "v_addc_co_u32 v%d, vcc, 0, v%d, vcc" % (out + 1, out + 1), "s_branch %s" % back]
         return [
-            Ins("v_mad_u64_u32 %s, vcc, v%d, -1, %s" % (vp(A), B + 1, vp(A))),
-            Ins("v_add_co_u32 v%d, %s, v%d, v%d" % (A + 1, sp(mask), A + 1, B), defs=[mask]),
-            Ins("v_cndmask_b32 v%d, 0, 1, %s" % (k01, sp(mask)), uses=[mask]),
-            Ins("v_mad_u64_u32 %s, vcc, v%d, -1, %s" % (vp(out), k01, vp(A))),
+            Ins("v_mad_u64_u32 %s, vcc, v%d, -1, %s" % (vp(out), B + 1, vp(A))),
+            Ins("v_add_co_u32 v%d, %s, v%d, v%d" % (out + 1, sp(mask), out + 1, B), defs=[mask]),
+            Ins("s_cmp_lg_u64 %s, 0" % sp(mask)),
+            Ins("s_cbranch_scc1 %s" % stub, glue=True),
+            Ins("%s:" % back, glue=True),
         ]
 
     # ------------------------------------------------------------------------------------------------ external layer
@@ -231,10 +248,10 @@ class Gen:
     # ------------------------------------------------------------------------------------------------ rounds
     def full_round(self):
         self.load_rc(12)                          # constants the layer at the end of this round adds (arrive during the S-boxes)
-        for k in range(0, 12, 2):
-            a = self.sbox(k, 24, (S_MASK, S_MASK + 2, S_MASK + 4))
-            b = self.sbox(k + 1, 36, (S_MASK + 6, S_MASK + 8, S_MASK + 10))
-            self.emit(interleave([a, b]))
+        ways = WAYS                               # S-box chains issued round-robin: 12 temporaries and 3 mask pairs each
+        for k in range(0, 12, ways):
+            chains = [self.sbox(k + i, 24 + 12 * i, (S_MASK + 6 * i, S_MASK + 6 * i + 2, S_MASK + 6 * i + 4)) for i in range(ways)]
+            self.emit(interleave(chains))
         self.raw("s_waitcnt lgkmcnt(0)")
         self.ext_layer()
 
@@ -365,13 +382,15 @@ __device__ __forceinline__ void poseidon2_permutation_asm(gl::u64 (&s)[12]) {
     return src
 
 
-def main():
+def main(out=None):
+    out = out or OUT
     src = generate()
-    if not os.path.exists(OUT) or open(OUT).read() != src:
-        with open(OUT, "w") as f:
+    if not os.path.exists(out) or open(out).read() != src:
+        with open(out, "w") as f:
             f.write(src)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(main())
+    import sys
+    print(main(sys.argv[1] if len(sys.argv) > 1 else None))
