@@ -128,11 +128,19 @@ def main():
             # every rank contributes 1 KiB of its own pattern and checks the gathered block.  Whatever happens on a rank, ALL
             # ranks meet in one all-reduce (MIN) and keep the transport only if every one of them succeeded.
             ok_local, err = 0, None
-            try:
-                box = [E.binding.rccl_unique_id() if rank == 0 else None]
-            except Exception as e:
-                box, err = [None], e
-            dist.broadcast_object_list(box, src=0)
+            # bj_comm_rccl_create is itself a collective (ncclCommInitRank): no rank may enter it while another cannot, so the
+            # ranks first agree that librccl loads everywhere
+            avail = torch.tensor([E.load_library().bj_rccl_available()], dtype=torch.int32, device=dev)
+            dist.all_reduce(avail, op=dist.ReduceOp.MIN)
+            box = [None]
+            if int(avail.item()) == 1:
+                try:
+                    box = [E.binding.rccl_unique_id() if rank == 0 else None]
+                except Exception as e:
+                    box, err = [None], e
+                dist.broadcast_object_list(box, src=0)
+            else:
+                err = "librccl could not be loaded on every rank"
             if box[0] is not None:
                 try:
                     comm = E.RcclComm(ctx, box[0], rank, world)
@@ -169,12 +177,13 @@ def main():
     barrier()
     comm0 = (comm.calls, comm.bytes) if sharded else (0, 0)
     t0 = time.perf_counter()
-    leaf_ms, stage_acc, proof_buf = [], {}, None
+    leaf_ms, stage_acc, proof_buf, comm_ms_acc = [], {}, None, 0.0
     for _ in range(args.steps):
         proof_buf, stages = step()
         if os.environ.get('BJ_BENCH_DEBUG'):
             print({k: round(v, 1) for k, v in stages.items()}, file=sys.stderr)
         leaf_ms.append(stages.pop("witness_tree_leaf_kernel"))
+        comm_ms_acc += setup.last_comm["ms_in_collectives"]
         for k, v in stages.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
@@ -239,6 +248,15 @@ def main():
                      "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},
         "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},
     }
+    if sharded:      # what a scaling record needs to explain itself: per proof on rank 0, and the slowest rank's time in collectives
+        cm = torch.tensor([comm_ms_acc / args.steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        cmax = cm.clone()
+        dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+        out["comm"] = {"calls_per_proof": int(comm_calls), "mb_received_per_rank_per_proof": round(comm_mb, 2),
+                        "ms_in_collectives_rank0": round(float(cm[0]), 3), "ms_in_collectives_max_rank": round(float(cmax[0]), 3),
+                        "note": "time between the start and the end of each all-gather on the proof's stream (transfer + waiting for "
+                                "the slowest peer), summed over a proof; replicated main-domain work is ~21 ms per rank (DESIGN.md §6)",
+                        "transport": transport}
 
     # ---- the drop-in call with a host witness (bj_prove): PCIe transfer of the 93 columns inside the timed region
     if world == 1 and not args.no_host_witness:

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "bj_quotient_copy_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "bj_rccl_available": (C.c_int, []),
     "bj_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "bj_comm_rccl_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "bj_comm_rccl_destroy": (None, [C.c_void_p]),
@@ -83,6 +84,7 @@ _SIGNATURES = {
     "bj_proof_size_u64": (C.c_size_t, [C.c_void_p]),
     "bj_proof_serialize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_proof_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_proof_comm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
     "bj_transcript_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "bj_transcript_destroy": (None, [C.c_void_p]),
@@ -737,6 +739,9 @@ class ProverSetup:
         self._ctx._check(self._lib.bj_proof_serialize(h, _np_ptr(buf)))
         ms = (C.c_float * 8)()
         self._lib.bj_proof_stage_ms(h, ms)
+        cms, calls, recv = C.c_float(), C.c_size_t(), C.c_size_t()
+        self._lib.bj_proof_comm_stats(h, C.byref(cms), C.byref(calls), C.byref(recv))
+        self.last_comm = {"ms_in_collectives": float(cms.value), "calls": int(calls.value), "bytes_received": int(recv.value)}
         self._lib.bj_proof_destroy(h)
         stages = dict(zip(STAGE_NAMES, [float(x) for x in ms][:7]))
         stages["witness_tree_leaf_kernel"] = float(ms[7])

@@ -183,6 +183,9 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->wit_stage) (void)hipFree(ctx->wit_stage);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (auto &pair : ctx->comm_ev)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->copy_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);

@@ -75,6 +75,8 @@ int gather_blocking(void *user, const void *d_send, void *d_recv, size_t bytes) 
 
 extern "C" {
 
+int bj_rccl_available(void) { return api().handle ? 1 : 0; }
+
 int bj_rccl_unique_id(void *out_id) {
     if (!out_id) return BJ_ERR_INVALID_ARG;
     Api &a = api();

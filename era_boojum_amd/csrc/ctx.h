@@ -37,6 +37,12 @@ struct bj_ctx {
     size_t wit_stage_elems = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev[64] = {};
+    // collectives of the sharded proof in flight: an event pair around each (created on first use, reused), summed into
+    // bj_proof_comm_stats when the proof has drained — what a scaling run needs to tell waiting-for-peers from computing
+    hipEvent_t comm_ev[48][2] = {};
+    unsigned comm_n = 0;          // pairs recorded by the proof in flight
+    size_t comm_bytes = 0;        // bytes received by this rank in them
+    float comm_host_ms = 0;       // synchronous host-callback transport: wall time inside the callbacks
 };
 
 namespace bj {

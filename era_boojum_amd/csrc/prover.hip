@@ -95,6 +95,9 @@ struct bj_setup {
 struct bj_proof {
     std::vector<u64> data;
     float stage_ms[8] = {0};
+    float comm_ms = 0;             // sharded proofs: time between the start and the end of every collective on this rank, summed
+    unsigned comm_calls = 0;
+    size_t comm_bytes = 0;         // bytes received from the other ranks
 };
 
 namespace {
@@ -149,15 +152,30 @@ int all_gather(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_recv, siz
             BJ_HIP(ctx, hipMemcpyAsync(d_recv, d_send, elems * 8, hipMemcpyDeviceToDevice, ctx->stream));
         return BJ_OK;
     }
+    ctx->comm_bytes += elems * 8 * (sh.world - 1);
     if (sh.comm.all_gather_stream) {   // stream-ordered transport (in-library RCCL): no synchronisation on either side
+        hipEvent_t *ev = nullptr;
+        if (ctx->in_proof && ctx->comm_n < 48) {
+            ev = ctx->comm_ev[ctx->comm_n];
+            if (!ev[0]) (void)hipEventCreate(&ev[0]);
+            if (!ev[1]) (void)hipEventCreate(&ev[1]);
+            if (ev[0] && ev[1]) (void)hipEventRecord(ev[0], ctx->stream);
+        }
         if (int rc = sh.comm.all_gather_stream(sh.comm.user, d_send, d_recv, elems * 8, ctx->stream))
             return fail(ctx, BJ_ERR_HIP, "sharded prover: the stream-ordered all_gather failed (%d)", rc);
+        if (ev && ev[0] && ev[1]) {
+            (void)hipEventRecord(ev[1], ctx->stream);
+            ctx->comm_n++;
+        }
         return BJ_OK;
     }
     if (!sh.comm.all_gather) return fail(ctx, BJ_ERR_INVALID_ARG, "sharded prover: no all_gather callback");
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
     if (int rc = sh.comm.all_gather(sh.comm.user, d_send, d_recv, elems * 8))
         return fail(ctx, BJ_ERR_HIP, "sharded prover: the host's all_gather callback failed (%d)", rc);
+    ctx->comm_host_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ctx->in_proof) ctx->comm_n += 0x10000;   // high half: synchronous calls
     return BJ_OK;
 }
 
@@ -442,6 +460,13 @@ int bj_proof_serialize(const bj_proof *p, uint64_t *out) {
     std::memcpy(out, p->data.data(), p->data.size() * 8);
     return BJ_OK;
 }
+int bj_proof_comm_stats(const bj_proof *p, float *ms_in_collectives, size_t *calls, size_t *bytes_received) {
+    if (!p) return BJ_ERR_INVALID_ARG;
+    if (ms_in_collectives) *ms_in_collectives = p->comm_ms;
+    if (calls) *calls = p->comm_calls;
+    if (bytes_received) *bytes_received = p->comm_bytes;
+    return BJ_OK;
+}
 int bj_proof_stage_ms(const bj_proof *p, float *out8) {
     if (!p || !out8) return BJ_ERR_INVALID_ARG;
     std::memcpy(out8, p->stage_ms, sizeof(p->stage_ms));
@@ -523,7 +548,12 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     }
     struct InProof {   // temporaries of the ABI calls below come out of the arena while this is alive
         bj_ctx *c;
-        explicit InProof(bj_ctx *x) : c(x) { c->in_proof = true; }
+        explicit InProof(bj_ctx *x) : c(x) {
+            c->in_proof = true;
+            c->comm_n = 0;
+            c->comm_bytes = 0;
+            c->comm_host_ms = 0;
+        }
         ~InProof() { c->in_proof = false; }
     } in_proof(ctx);
     struct HasherGuard {
@@ -1136,6 +1166,17 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         }
     }
     proof->stage_ms[6] = timer.lap();
+    {   // the proof has drained (its bytes are on the host): the collectives' event pairs can be read
+        float ms = ctx->comm_host_ms;
+        const unsigned n_stream = ctx->comm_n & 0xFFFFu;
+        for (unsigned i = 0; i < n_stream; i++) {
+            float e = 0;
+            if (hipEventElapsedTime(&e, ctx->comm_ev[i][0], ctx->comm_ev[i][1]) == hipSuccess) ms += e;
+        }
+        proof->comm_ms = ms;
+        proof->comm_calls = n_stream + (ctx->comm_n >> 16);
+        proof->comm_bytes = ctx->comm_bytes;
+    }
     guard.ok = true;
     *out = proof;
     return BJ_OK;

@@ -461,6 +461,10 @@ typedef struct bj_comm {
      * once — stream order replaces both synchronisations.  bj_comm_rccl_create sets it. */
     int (*all_gather_stream)(void *user, const void *d_send, void *d_recv, size_t bytes, void *hip_stream);
 } bj_comm;
+/* 1 if librccl could be loaded in this process (dlopen; BJ_RCCL_LIB overrides the name), 0 otherwise.  bj_comm_rccl_create is
+ * a collective: a host agrees on this flag across its processes FIRST (any channel), so that no rank enters the collective
+ * while another one cannot. */
+int bj_rccl_available(void);
 /* The in-library transport: RCCL (ncclAllGather over xGMI) on the context's stream, directly on the prover's buffers; librccl
  * is loaded at run time (BJ_RCCL_LIB overrides the search).  Rank 0 makes the id and hands its 128 bytes to the other ranks by
  * whatever channel the host has; every rank then calls bj_comm_rccl_create (collective) with its device current, and passes
@@ -495,6 +499,10 @@ int bj_proof_serialize(const bj_proof *p, uint64_t *out);
  * [2] quotient work and LDE + tree, [3] openings at z, [4] batched FRI opening computation (DEEP), [5] FRI, [6] queries;
  * [7] = duration of the witness-tree Poseidon2 leaf kernel alone, measured with HIP events on the launch stream */
 int bj_proof_stage_ms(const bj_proof *p, float *out8);
+/* Sharded proofs: how long this rank spent inside collectives (sum over the all-gathers of the time between their start and
+ * their end on the proof's stream: transfer + waiting for the slowest peer), how many there were and how many bytes arrived
+ * from the other ranks.  Zeroes for a single-GPU proof.  Any out pointer may be NULL. */
+int bj_proof_comm_stats(const bj_proof *p, float *ms_in_collectives, size_t *calls, size_t *bytes_received);
 
 #ifdef __cplusplus
 }
