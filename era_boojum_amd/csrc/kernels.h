@@ -36,6 +36,9 @@ void launch_ntt_strided4(const u64 *in, u64 *out, const u64 *tw, const u64 *roun
 // poseidon2.hip
 void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
                              size_t num_leaves, u64 *d_digests, hipStream_t s);
+// one absorption of up to eight columns per leaf; d_capacity [4][num_leaves] carries the sponge between the groups
+void launch_poseidon2_leaves_absorb(const u64 *d_base, size_t col_stride, unsigned n_cols, size_t num_leaves, u64 *d_capacity,
+                                    u64 *d_digests, bool first, bool last, hipStream_t s);
 void launch_poseidon2_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsigned n_srcs, unsigned log_e,
                                      size_t num_leaves, u64 *d_digests, hipStream_t s);
 void launch_poseidon2_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s);

@@ -276,6 +276,32 @@ poseidon2_leaves_kernel(const u64 *base, size_t col_stride, const u64 *const *co
     d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
+// ONE absorption of the same sponge, for leaves whose columns arrive in groups of eight (bj_prove: the witness comes over
+// PCIe while the first groups are already being extended and hashed): state[0..8] <- the group's elements (zero-padded in
+// the last group), state[8..12] <- what the previous group left in `capacity` ([4][num_leaves], zeros before the first
+// group), permute; the last group writes the digest, the others their capacity words.  Group by group this is exactly
+// poseidon2_leaves_kernel's loop (sponge.rs:224-346: overwrite mode, no length tag).
+__global__ void __launch_bounds__(256)
+poseidon2_leaves_absorb_kernel(const u64 *base, size_t col_stride, unsigned n_cols, size_t num_leaves, u64 *capacity,
+                               u64 *digests, int first, int last) {
+    size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= num_leaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = (unsigned)k < n_cols ? base[(size_t)k * col_stride + I] : 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[8 + k] = first ? 0 : capacity[(size_t)k * num_leaves + I];
+    poseidon2_permutation(s);
+    if (last) {
+        ulonglong2 *d = reinterpret_cast<ulonglong2 *>(digests + 4 * I);
+        d[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));
+        d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) capacity[(size_t)k * num_leaves + I] = s[8 + k];
+    }
+}
+
 // leaf j = sponge( src0[jE..(j+1)E) || src1[jE..(j+1)E) || ... )           (merkle_tree.rs:176-386, FRI oracles)
 __global__ void __launch_bounds__(256)
 poseidon2_leaves_chunked_kernel(const u64 *src0, const u64 *src1, unsigned n_srcs, unsigned log_e, size_t num_leaves,
@@ -447,6 +473,11 @@ void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *co
     unsigned tpb = 256;
     hipLaunchKernelGGL(poseidon2_leaves_kernel, dim3((unsigned)((num_leaves + tpb - 1) / tpb)), dim3(tpb), 0, s,
                        d_base, col_stride, d_col_ptrs, n_cols, num_leaves, d_digests);
+}
+void launch_poseidon2_leaves_absorb(const u64 *d_base, size_t col_stride, unsigned n_cols, size_t num_leaves, u64 *d_capacity,
+                                    u64 *d_digests, bool first, bool last, hipStream_t s) {
+    hipLaunchKernelGGL(poseidon2_leaves_absorb_kernel, dim3((unsigned)((num_leaves + 255) / 256)), dim3(256), 0, s, d_base,
+                       col_stride, n_cols, num_leaves, d_capacity, d_digests, first ? 1 : 0, last ? 1 : 0);
 }
 void launch_poseidon2_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsigned n_srcs, unsigned log_e,
                                      size_t num_leaves, u64 *d_digests, hipStream_t s) {

@@ -543,7 +543,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                     + 2 * Q + (sh.world > 1 ? 2 * Ln * (sh.world + 1) : 0) + (size_t)2 * q * N + tree_elems + 4 * n + 4 * N                       // T (+ gather staging), q_lde, q_tree, w, deep
                     + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
                     + 4 * N + (N * sh.world) / 2                                                   // FRI layers + trees, DEEP argument blocks
-                    + (sh.world > 1 ? 10 * n : 0);                                                 // sharded DEEP numerators: slices + gather staging
+                    + (sh.world > 1 ? 10 * n : 0)                                                  // sharded DEEP numerators: slices + gather staging
+                    + (hw ? 4 * N : 0);                                                            // host witness hashed in groups: the leaves' capacity words
         if ((rc = bj::arena_reset(ctx, need))) return rc;
     }
     struct InProof {   // temporaries of the ABI calls below come out of the arena while this is alive
@@ -598,6 +599,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
 
     // ---------------- round 1: witness LDE + tree (prover.rs:270-353) ----------------
     ArenaBuf wit_lde, wit_tree, mono, mono_s2;   // mono: witness monomials, mono_s2: stage-2 monomials (both kept for DEEP)
+    bool hashed_in_groups = false;               // bj_prove: the witness leaves were absorbed group by group under the transfer
     if ((rc = wit_lde.alloc(ctx, (size_t)nW * Ln))) return rc;
     if ((rc = mono.alloc(ctx, (size_t)nW * n))) return rc;
     if ((rc = mono_s2.alloc(ctx, (size_t)nS2 * n))) return rc;
@@ -609,8 +611,21 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         // all copies are queued on the copy stream at once (they run back to back at PCIe speed); the proof stream picks the
         // groups up as they land.  Column nW - 1 is the multiplicity column when there are lookups.
         if (!ctx->copy_stream) BJ_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-        const unsigned G = hw->group, n_groups = (nW + G - 1) / G;
-        if (n_groups > 64) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: more than 64 column groups");
+        // groups of G columns, at most 64 of them (one event each): a wide witness gets wider groups instead of an error.  With
+        // the Poseidon2 tree hasher and G a multiple of the sponge's rate, a group is also absorbed into the leaf sponges as soon
+        // as it is extended (the capacity words of every leaf wait in HBM between the groups), so that hashing — the dominant
+        // kernel — runs under the transfer of the later groups instead of after the last one has landed.
+        unsigned G = hw->group;
+        if ((nW + G - 1) / G > 64) G = (nW + 63) / 64;
+        const bool absorb = ctx->hasher == BJ_HASHER_POSEIDON2 && getenv("BJ_PROVE_NO_ABSORB") == nullptr;
+        if (absorb) G = (G + 7) / 8 * 8;
+        const unsigned n_groups = (nW + G - 1) / G;
+        ArenaBuf capacity;
+        if (absorb) {
+            if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
+            if ((rc = capacity.alloc(ctx, 4 * N))) return rc;
+            hashed_in_groups = true;
+        }
         for (unsigned g = 0; g < n_groups; g++) {
             if (!ctx->copy_ev[g]) BJ_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[g], hipEventDisableTiming));
             const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
@@ -623,6 +638,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                                            ctx->copy_stream));
             BJ_HIP(ctx, hipEventRecord(ctx->copy_ev[g], ctx->copy_stream));
         }
+        if (absorb) BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
         for (unsigned g = 0; g < n_groups && !rc; g++) {
             const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
             const unsigned v1 = c1 < VW ? c1 : VW;
@@ -632,14 +648,21 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             if (!rc)
                 rc = bj::lde_cosets_strided(ctx, mono.p + (size_t)c0 * n, n, wit_lde.p + (size_t)c0 * Ln, Ln, log_n, c1 - c0, S->log_L,
                                             S->c0, S->cl);
+            for (unsigned c = c0; absorb && !rc && c < c1; c += 8)
+                bj::launch_poseidon2_leaves_absorb(wit_lde.p + (size_t)c * Ln, Ln, c1 - c < 8 ? c1 - c : 8, N, capacity.p, wit_tree.p,
+                                                   c == 0, c + 8 >= nW, st);
         }
+        if (absorb) BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
     }
     if (rc) return rc;
-    if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
-    // witness tree; the leaf kernel (the dominant kernel of a proof) is bracketed by HIP events on the launch stream
-    BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
-    bj::launch_tree_leaves(ctx->hasher, wit_lde.p, Ln, nullptr, nW, N, wit_tree.p, st);
-    BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
+    if (!hashed_in_groups && (rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
+    // witness tree; the leaf kernel (the dominant kernel of a proof) is bracketed by HIP events on the launch stream (with a
+    // host witness hashed in groups the bracket spans the groups' transforms too: the roofline figure comes from bj_prove_dev)
+    if (!hashed_in_groups) {
+        BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
+        bj::launch_tree_leaves(ctx->hasher, wit_lde.p, Ln, nullptr, nW, N, wit_tree.p, st);
+        BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
+    }
     bj::launch_tree_node_layers(ctx->hasher, wit_tree.p, N, capl, st);
     BJ_CHECK_LAUNCH(ctx);
     std::vector<u64> wit_cap(4 * cap), s2_cap(4 * cap), q_cap(4 * cap);

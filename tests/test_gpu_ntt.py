@@ -197,3 +197,32 @@ def test_lde_at_bench_sizes_matches_oracle(log_n, log_lde, n_cols):
         assert np.array_equal(d_c.get(mono.shape), O.canonical(mono))
         d_c.free()
     d_m.free(); d_o.free()
+
+
+@pytest.mark.parametrize("log_n,n_cols", [(14, 5), (15, 3), (18, 3), (19, 2), (22, 2)])
+def test_lde_and_ntt_with_unaligned_buffers_and_odd_strides(log_n, n_cols):
+    """A host may hand over columns at any 8-byte address and stride: the 16-byte vector accesses of the coset-expanding front
+    pass (ntt_first4) then give way to the one-index-per-lane plan (ntt_first5 + the nine-round local pass for sizes with
+    14 + 4k rounds), which no aligned caller ever reaches.  Same values as the oracle, neighbours of the columns untouched."""
+    n, L = 1 << log_n, 8
+    rng = np.random.default_rng(4000 + log_n)
+    stride = n + 1                                           # odd column stride
+    buf = rand_gl(rng, (n_cols * stride + 1,), noncanonical=True)
+    mono = np.stack([buf[1 + c * stride: 1 + c * stride + n] for c in range(n_cols)])      # columns start 8 bytes off a 16-byte line
+    want = O.lde_batch(O.canonical(mono), 3, threads=8)
+    d_in = DevBuf(buf)
+    d_out = DevBuf(nelems=n_cols * L * n + 1)
+    ctx().lde_batch(d_in.ptr + 8, d_out.ptr + 8, log_n, n_cols, 3, col_stride=stride)
+    got = d_out.get((n_cols * L * n + 1,))[1:].reshape(n_cols, L, n)
+    assert np.array_equal(got, want)
+    assert np.array_equal(d_in.get(buf.shape), buf)          # out of place: the input (and the gaps between its columns) is intact
+    # the forward transform alone, in place on the odd-strided, offset columns
+    want_f = O.fft_batch(O.canonical(mono), 7, threads=8)
+    ctx().ntt_forward_batch(d_in.ptr + 8, d_in.ptr + 8, log_n, n_cols, col_stride=stride, coset=7)
+    after = d_in.get(buf.shape)
+    for c in range(n_cols):
+        assert np.array_equal(after[1 + c * stride: 1 + c * stride + n], want_f[c])
+        if c + 1 < n_cols:
+            assert after[1 + c * stride + n] == buf[1 + c * stride + n]                     # the gap element
+    assert after[0] == buf[0]
+    d_in.free(); d_out.free()
