@@ -14,11 +14,19 @@ def ctx():
         # PyTorch-ROCm ships its own libamdhip64; whichever copy is loaded first serves the whole process, and torch cannot
         # initialise on top of the system copy.  bench.py and the sharded workers import torch first — do the same here so
         # that tests which use torch.distributed in this process (TorchComm over RCCL) see the GPU.
+        import os
+        import sys
+        dbg = os.environ.get("BJ_TEST_DEBUG")
+        if dbg:
+            print("hip libraries mapped before torch:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "hip" in l or "hsa" in l}), file=sys.stderr)
         try:
             import torch
             torch.cuda.init()
-        except Exception:
-            pass
+        except Exception as e:
+            if dbg:
+                print("torch.cuda.init failed:", repr(e), file=sys.stderr)
+        if dbg:
+            print("hip libraries mapped after torch:", sorted({l.split()[-1] for l in open("/proc/self/maps") if "hip" in l or "hsa" in l}), file=sys.stderr)
         _ctx = E.Context(0)
     return _ctx
 

@@ -5,7 +5,16 @@ import era_boojum_amd as E
 from era_boojum_amd import synthetic as S, proof_format
 from oracle import verifier as OV
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-t = time.time(); c = S.recursion_like_circuit(log_n, seed=4, table_bits=2); print("gen %.1f s" % (time.time() - t))
+only_lists = len(sys.argv) > 2 and sys.argv[2] == "oplists"      # EVERY evaluator as the list the reference's gpu_synthesizer would capture
+t = time.time(); c = S.recursion_like_circuit(log_n, seed=4, table_bits=2, poseidon2_as_op_list=only_lists); print("gen %.1f s" % (time.time() - t))
+if only_lists:
+    from era_boojum_amd import gate_program as GP
+    for g in c.gates:
+        prog = {"ConstantsAllocatorGate": GP.constants_allocator_program, "FmaGateInBaseFieldWithoutConstant": GP.fma_program,
+                "ReductionGate<4>": GP.reduction4_program}.get(g.name)
+        if prog:
+            g.program, g.kind = prog(), S.GATE_PROGRAM
+    print("gates:", [(g.name, g.kind) for g in c.gates])
 import torch; torch.cuda.init()
 ctx = E.Context(0)
 for fri, cap in ((2, 32), (8, 16)):
