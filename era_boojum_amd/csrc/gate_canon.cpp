@@ -222,6 +222,15 @@ int canonicalize(const bj_gate_program *p, Program *out, std::string *err) {
         if (x.kind == K_NONE) return Operand{0, 0};
         return Operand{x.kind, (uint32_t)x.payload};
     };
+    // Sethi-Ullman numbers: how many values a subexpression keeps alive while it is computed.  The operand that needs more goes
+    // first, so a long accumulation (contribution = ((c0 + c1 s) + c2 s') + ...) is walked along its spine with one value
+    // waiting instead of one per level.  Nodes are created after their operands, so one forward sweep does it.
+    std::vector<uint32_t> need(B.nodes.size(), 1);
+    for (size_t i = 0; i < B.nodes.size(); i++) {
+        const RawNode &N = B.nodes[i];
+        const uint32_t la = N.a.kind == K_NODE ? need[N.a.payload] : 0, lb = N.b.kind == K_NODE ? need[N.b.payload] : 0;
+        need[i] = std::max<uint32_t>(1, la == lb ? la + (lb ? 1 : 0) : std::max(la, lb));
+    }
     struct Frame {
         uint32_t node;
         int stage;
@@ -236,17 +245,19 @@ int canonicalize(const bj_gate_program *p, Program *out, std::string *err) {
                 stack.pop_back();
                 continue;
             }
+            const bool b_first = N.a.kind == K_NODE && N.b.kind == K_NODE && need[N.b.payload] > need[N.a.payload];
+            const Op &first = b_first ? N.b : N.a, &second = b_first ? N.a : N.b;
             if (f.stage == 0) {
                 f.stage = 1;
-                if (N.a.kind == K_NODE && sched_of[N.a.payload] == UINT32_MAX) {
-                    stack.push_back(Frame{(uint32_t)N.a.payload, 0});
+                if (first.kind == K_NODE && sched_of[first.payload] == UINT32_MAX) {
+                    stack.push_back(Frame{(uint32_t)first.payload, 0});
                     continue;
                 }
             }
             if (f.stage == 1) {
                 f.stage = 2;
-                if (N.b.kind == K_NODE && sched_of[N.b.payload] == UINT32_MAX) {
-                    stack.push_back(Frame{(uint32_t)N.b.payload, 0});
+                if (second.kind == K_NODE && sched_of[second.payload] == UINT32_MAX) {
+                    stack.push_back(Frame{(uint32_t)second.payload, 0});
                     continue;
                 }
             }

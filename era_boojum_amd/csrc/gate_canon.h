@@ -9,8 +9,10 @@
 //     hash; x+0, x-0, x*1, x*0, x+x, x*x, 0-x and operations on two constants are rewritten; dead relations dropped);
 //   * a 128-bit structural fingerprint of the terms (Merkle hashes of the DAG) identifies the evaluator's FUNCTION: it is
 //     invariant under renumbering of temporaries, reordering of independent relations and the peepholes above;
-//   * a schedule (depth-first from the terms, each term emitted as soon as its value exists) and a linear-scan slot
-//     allocation over it: a 288-relation matrix gate needs 13 slots, the ~9.5 k-relation Poseidon2 flattened capture ~40.
+//   * a schedule (depth-first from the terms, the operand with the larger Sethi-Ullman number first, each term emitted as
+//     soon as its value exists) and a linear-scan slot allocation over it: the 72 relations of U8x4FMAGate need 3 slots, a
+//     288-relation matrix gate 2 to 25 (the dense external Poseidon2 matrix shares its products across rows), the
+//     ~9.6 k-relation Poseidon2 flattened capture 42.
 // Pure C++ (no HIP): built into libboojum_hip.so and, by build.py, into a host-only helper that gate_codegen.py uses to
 // emit csrc/gate_aot.hip — one implementation, so the fingerprints of the generated kernels are the library's by construction.
 #pragma once

@@ -181,7 +181,7 @@ void launch_gate_programs(const GateLaunch *gates, unsigned n, const u64 *d_vars
     if (!no_aot && !no_fuse)
         for (unsigned i = 0; i < n; i++) {
             const GateLaunch &G = gates[i];
-            if (gate_aot_known(G.program->fp[0], G.program->fp[1]) && !G.program->reads_witness && G.rep_var_stride && G.reps &&
+            if (gate_aot_fusable(G.program->fp[0], G.program->fp[1]) && !G.program->reads_witness && G.rep_var_stride && G.reps &&
                 fused.size() < (size_t)gpdev::BJ_FUSED_MAX)
                 fused.push_back(i);
         }

@@ -11,6 +11,7 @@ bool launch_gate_aot_fused(const uint64_t *fp0, const uint64_t *fp1, const gpdev
 // true if a generated kernel exists for the program with this fingerprint (and it was launched)
 bool launch_gate_aot(uint64_t fp0, uint64_t fp1, const gpdev::ProgArgs &a, unsigned blocks, hipStream_t s);
 bool gate_aot_known(uint64_t fp0, uint64_t fp1);
+bool gate_aot_fusable(uint64_t fp0, uint64_t fp1);   // known AND light enough for the fused sweep
 // the fingerprint of the reference's own capture of Poseidon2FlattenedGate<8,12,4> without witness columns
 // (src/cs/gates/poseidon2.rs:166-391): such a program is run by the hand-written evaluator of gate_poseidon2.hip
 bool gate_is_poseidon2_flattened(uint64_t fp0, uint64_t fp1);

@@ -23,3 +23,19 @@ def test_fused_gate_sweep_equals_per_gate_evaluation_on_the_host(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fused == per-gate" in out.stdout
+
+
+def test_fused_gate_sweep_keeps_its_occupancy():
+    """The fused sweep's register file is that of its heaviest body: a body that does not belong there (a 12 x 12 matrix gate
+    needs > 100 VGPRs) once halved the recursion-class quotient's speed.  gate_codegen.py admits light bodies only; the
+    compiler's own resource report for the generated file must stay at 6+ waves per SIMD (<= 80 VGPRs)."""
+    import os
+    import re
+    import subprocess
+    from era_boojum_amd import build as B
+    r = subprocess.run([B.HIPCC] + B.FLAGS + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(B.CSRC, "gate_aot.hip"), "-o", os.devnull],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"Function Name: \S*gate_aot_fused_kernel\S*.*?\n.*?\n.*?VGPRs: (\d+)", r.stderr, re.S)
+    assert m, "no resource report for the fused kernel"
+    assert int(m.group(1)) <= 80, "gate_aot_fused_kernel uses %s VGPRs" % m.group(1)

@@ -42,7 +42,7 @@ int main() {
         bool ok_geometry = true;
         for (int k = 0; k < n; k++) {
             int id;
-            do id = (int)(rnd() % NUM_BODIES); while (BODY_INFO[id].wit_extent);
+            do id = (int)(rnd() % NUM_FUSABLE); while (BODY_INFO[id].wit_extent);   // the sweep takes the light bodies only
             const BodyInfo &B = BODY_INFO[id];
             ProgArgs a{};
             a.vars = vars.data(); a.var_stride = Q; a.consts = consts.data(); a.const_stride = Q;
