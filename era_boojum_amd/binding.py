@@ -83,6 +83,9 @@ _SIGNATURES = {
     "bj_proof_destroy": (None, [C.c_void_p]),
     "bj_proof_size_u64": (C.c_size_t, [C.c_void_p]),
     "bj_proof_serialize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_setup_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_setup_create_from_dump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_prove_from_dumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "bj_proof_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_proof_comm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -674,16 +677,20 @@ class ProverSetup:
     (bj_setup_create_sharded)."""
 
     def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, comm=None,
-                 transcript="poseidon2"):
+                 transcript="poseidon2", setup_base_dump=None):
+        """setup_base_dump: the bytes of the reference's `SetupBaseStorage::write_into_buffer` (bj_setup_create_from_dump): the
+        columns, constant-column count, table-id column, selector paths, quotient degree and non-residues then come from the
+        dump / are computed by the library, and `circuit` only has to carry the geometry and the gate list."""
         self._ctx, self._lib, self.circuit = ctx, ctx._lib, circuit
         self._comm = comm
         self.fri_lde_factor, self.cap_size, self.security_level, self.pow_bits = fri_lde_factor, cap_size, security_level, pow_bits
         c = circuit
         gates = (_GateDesc * len(c.gates))()
+        from_dump = setup_base_dump is not None
         for i, g in enumerate(c.gates):
             gates[i].kind = g.kind
-            gates[i].path_len = len(g.path)
-            for b, bit in enumerate(g.path):
+            gates[i].path_len = 0 if from_dump else len(g.path)
+            for b, bit in enumerate([] if from_dump else g.path):
                 gates[i].path[b] = 1 if bit else 0
             gates[i].num_repetitions, gates[i].var_stride, gates[i].const_stride, gates[i].num_terms = \
                 g.reps, g.var_stride, g.const_stride, g.num_terms
@@ -702,8 +709,9 @@ class ProverSetup:
         cols = (C.c_uint * max(1, len(c.public_inputs)))(*[p[0] for p in c.public_inputs])
         rows = (C.c_uint * max(1, len(c.public_inputs)))(*[p[1] for p in c.public_inputs])
         self.num_witness_cols = int(getattr(c, "num_witness_cols", 0))
-        cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, self.num_witness_cols, c.num_constant_cols, c.lookup_width, c.lookup_reps, c.table_id_col,
-                      c.quotient_degree, len(c.gates), gates, nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
+        cc = _Circuit(c.log_n, c.num_vars, c.num_gp_vars, self.num_witness_cols, 0 if from_dump else c.num_constant_cols, c.lookup_width,
+                      c.lookup_reps, 0 if from_dump else c.table_id_col, 0 if from_dump else c.quotient_degree, len(c.gates), gates,
+                      None if from_dump else nr.ctypes.data_as(C.POINTER(C.c_uint64)), len(c.public_inputs),
                       cols, rows, len(spec_list), spec if spec_list else None)
         self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3, "keccak256": 4}[transcript]
         self.hasher_kind = {"blake2s": 2, "keccak256": 3}.get(transcript, 1)      # Transcript::CompatibleCap = TreeHasher::Output
@@ -712,6 +720,13 @@ class ProverSetup:
         con = np.ascontiguousarray(c.constants, dtype=np.uint64)
         tab = np.ascontiguousarray(c.tables, dtype=np.uint64)
         h = C.c_void_p()
+        if from_dump:
+            if comm is not None:
+                raise BoojumHipError("a setup from a dump is single-GPU")
+            blob = bytes(setup_base_dump)
+            ctx._check(self._lib.bj_setup_create_from_dump(ctx._h, C.byref(cc), blob, len(blob), C.byref(cfg), C.byref(h)))
+            self._h = h
+            return
         ctx._check(self._lib.bj_setup_create_sharded(ctx._h, C.byref(cc), _np_ptr(sig), _np_ptr(con),
                                                      _np_ptr(tab) if c.lookup_reps else None, C.byref(cfg),
                                                      C.byref(comm.struct) if comm is not None else None, C.byref(h)))
@@ -760,6 +775,13 @@ class ProverSetup:
         h = C.c_void_p()
         self._ctx._check(self._lib.bj_prove(self._ctx._h, self._h, _np_ptr(v), _np_ptr(m) if c.lookup_reps else None,
                                             _np_ptr(pv), C.byref(h)))
+        return self._finish(h)
+
+    def prove_from_dumps(self, witness_vec_dump, variables_hint_dump):
+        """bj_prove_from_dumps: the reference's `WitnessVec` and `DenseVariablesCopyHint` bytes in, the proof out."""
+        w, v = bytes(witness_vec_dump), bytes(variables_hint_dump)
+        h = C.c_void_p()
+        self._ctx._check(self._lib.bj_prove_from_dumps(self._ctx._h, self._h, w, len(w), v, len(v), C.byref(h)))
         return self._finish(h)
 
     def prove_dev(self, d_variables, d_multiplicities, public_values=None):

@@ -447,6 +447,15 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     return BJ_OK;
 }
 
+int bj_setup_shape(const bj_setup *s, unsigned *log_n, unsigned *num_vars, unsigned *num_witness_cols, unsigned *num_public_inputs) {
+    if (s && num_public_inputs) *num_public_inputs = (unsigned)s->pub_cols.size();
+    if (!s) return BJ_ERR_INVALID_ARG;
+    if (log_n) *log_n = s->log_n;
+    if (num_vars) *num_vars = s->V;
+    if (num_witness_cols) *num_witness_cols = s->Wc;
+    return BJ_OK;
+}
+
 int bj_setup_cap(const bj_setup *s, uint64_t *h_cap) {
     if (!s || !h_cap) return BJ_ERR_INVALID_ARG;
     std::memcpy(h_cap, s->cap.data(), s->cap.size() * 8);

@@ -479,6 +479,24 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *circuit, const uint64
 /* bj_prove / bj_prove_dev on a sharded setup are collective: every rank calls them with the same witness. */
 void bj_setup_destroy(bj_setup *s);
 int bj_setup_cap(const bj_setup *s, uint64_t *h_cap); /* vk.setup_merkle_tree_cap: cap_size*4 u64 */
+int bj_setup_shape(const bj_setup *s, unsigned *log_n, unsigned *num_vars, unsigned *num_witness_cols,
+                   unsigned *num_public_inputs); /* any out pointer may be NULL */
+
+/* ---- seam S1 without linking: the reference's own `MemcopySerializable` dumps (src/cs/implementations/fast_serialization.rs) ----
+ * A Rust host writes SetupBaseStorage (polynomial_storage.rs:77-126), WitnessVec (witness.rs:29-71) and DenseVariablesCopyHint
+ * (hints/mod.rs:10-61) with `write_into_buffer` and hands the bytes over; byte layouts: era_boojum_amd/csrc/dumps.hip (the
+ * reference holds no golden bytes for them: layouts follow the code, parity unpinned by vectors).
+ * bj_setup_create_from_dump: `circuit` carries what is code on the Rust side — geometry, the gates in gate_idx order (kind,
+ * repetitions, strides, terms, op list), public input locations.  Taken from the dump instead of the struct: the columns,
+ * num_constant_cols, table_id_col, every gate's selector path (TreeNode: left = the constant column), quotient_degree when the
+ * field is 0 (from the tree's depth + degree), non_residues when the pointer is NULL (make_non_residues, utils.rs:636-688). */
+int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void *setup_base, size_t setup_base_len,
+                              const bj_proof_config *config, bj_setup **out);
+/* witness_set_from_witness_vec (witness.rs:386-443) on the device — cell = all_values[hint & (2^48 - 1)], 0 where bit 63 marks a
+ * placeholder; multiplicities zero-extended to the trace (witness.rs:225-272); public input values read from their cells — then
+ * bj_prove_dev.  Circuits with non-copiable witness columns are refused (BJ_ERR_UNSUPPORTED). */
+int bj_prove_from_dumps(bj_ctx *ctx, const bj_setup *setup, const void *witness_vec, size_t witness_vec_len,
+                        const void *variables_hint, size_t variables_hint_len, bj_proof **out);
 
 /* WitnessSet (witness.rs:21-27) in: variables, then the non-copiable witness columns: [num_vars + num_witness_cols][n] natural
  * order, multiplicities [n] (NULL without lookups),

@@ -150,3 +150,40 @@ def test_prove_from_memcopy_dumps():
     assert np.array_equal(pa, pb)
     assert OV.verify(OV.VerificationKey(back, b.cap(), 8, 16), proof_format.parse(pb, security_level=30))
     a.close(); b.close()
+
+
+def test_dumps_through_the_c_abi():
+    """The same dumps straight into the library (bj_setup_create_from_dump / bj_prove_from_dumps, csrc/dumps.hip): the C++ reader
+    takes columns, selector paths (bincode TreeNode), table-id column and quotient degree from the SetupBaseStorage bytes,
+    computes the non-residues itself, materialises the cells from WitnessVec + DenseVariablesCopyHint on the device — and
+    produces the proof of the in-memory circuit, byte for byte.  Malformed dumps are refused with a message."""
+    import copy
+    from era_boojum_amd import memcopy_format as M
+    c, info = S.sha256_circuit(S.bench_message(700, seed=5), return_info=True)
+    total = sum(t.shape[0] for t in S.sha_tables())
+    setup_dump = M.write_setup_base(c)
+    wit_dump = M.write_witness_vec([(col, row) for col, row, _ in c.public_inputs], info["all_values"],
+                                   c.multiplicities[0, :total].astype(np.uint32))
+    hint_dump = M.write_variables_hint(info["var_ids"])
+    a = E.ProverSetup(ctx(), c, 8, 16, 30)
+    pa, _ = a.prove()
+    bare = copy.copy(c)                  # what a Rust host has as CODE: geometry + gate list; no paths, no degree, no non-residues
+    bare.gates = [copy.copy(g) for g in c.gates]
+    for g in bare.gates:
+        g.path = []
+    b = E.ProverSetup(ctx(), bare, 8, 16, 30, setup_base_dump=setup_dump)
+    assert np.array_equal(a.cap(), b.cap())
+    pb, _ = b.prove_from_dumps(wit_dump, hint_dump)
+    assert np.array_equal(pa, pb)
+    for bad, what in ((setup_dump[:-3], "TreeNode"), (setup_dump + b"\0", "trailing"), (setup_dump[:1000], "truncated")):
+        with pytest.raises(E.BoojumHipError, match=what):
+            E.ProverSetup(ctx(), bare, 8, 16, 30, setup_base_dump=bad)
+    with pytest.raises(E.BoojumHipError, match="WitnessVec"):
+        b.prove_from_dumps(wit_dump[:-2], hint_dump)
+    with pytest.raises(E.BoojumHipError, match="CopyHint"):
+        b.prove_from_dumps(wit_dump, hint_dump[:-8])
+    broken = bytearray(hint_dump)
+    broken[16:24] = (1 << 40).to_bytes(8, "little")      # a cell naming a variable beyond all_values
+    with pytest.raises(E.BoojumHipError, match="beyond all_values"):
+        b.prove_from_dumps(wit_dump, bytes(broken))
+    a.close(); b.close()
