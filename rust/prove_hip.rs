@@ -391,6 +391,30 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
     }
 }
 
+/// The same proof from the reference's own dumps — for a host that keeps the witness as `WitnessVec` + `DenseVariablesCopyHint`
+/// (what `CSReferenceAssembly` has before `witness_set_from_witness_vec`, witness.rs:386-443) or hands work to another process:
+/// `MemcopySerializable::write_into_buffer` bytes go straight into `bj_prove_from_dumps`, the cells are materialised on the GPU.
+/// `bj_setup_create_from_dump` is the setup-side counterpart (`SetupBaseStorage::write_into_buffer`): with it the `bj_circuit` only
+/// needs the geometry and the gate list, the library reads columns, selector tree, table-id column and quotient degree itself.
+pub fn prove_hip_from_dumps<H: TreeHasher<F>, EXT: FieldExtension<2, BaseField = F>>(
+    ctx: &HipCtx,
+    setup: &HipSetup,
+    witness_vec: &crate::cs::implementations::witness::WitnessVec<F>,
+    variables_hint: &crate::cs::implementations::hints::DenseVariablesCopyHint,
+    proof_config: ProofConfig,
+) -> Proof<F, H, EXT> {
+    use crate::cs::implementations::fast_serialization::MemcopySerializable;
+    let (mut w, mut h) = (Vec::new(), Vec::new());
+    witness_vec.write_into_buffer(&mut w).expect("WitnessVec serialises");
+    variables_hint.write_into_buffer(&mut h).expect("DenseVariablesCopyHint serialises");
+    let mut proof = std::ptr::null_mut();
+    ctx.check(unsafe { bj_prove_from_dumps(ctx.raw, setup.raw, w.as_ptr() as *const _, w.len(), h.as_ptr() as *const _, h.len(), &mut proof) });
+    let mut words = vec![0u64; unsafe { bj_proof_size_u64(proof) }];
+    ctx.check(unsafe { bj_proof_serialize(proof, words.as_mut_ptr()) });
+    unsafe { bj_proof_destroy(proof) };
+    proof_from_bjpf::<H, EXT>(&words, proof_config)
+}
+
 fn capture_principal_width(c: &GPUDataCapture) -> usize {
     let mut w = 0;
     let mut see = |ix: &Index<F>| {
