@@ -205,14 +205,17 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be collected from inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh) is used when it matches the launch shape
     traffic, traffic_src, valu = None, None, None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_2p22_leaf_traffic.json")))
-        if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
-            traffic = pm["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r02_pmc_bench_2p22_leaf_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc passes over this command"
-            valu = pm.get("valu") or None
-    except (OSError, KeyError, ValueError):
-        pass
+    for prof in ("r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
+            if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
+                traffic = pm["traffic_bytes_per_launch"]
+                traffic_src = ("NOT measured in this run: read from the committed profile profiles/%s = (2*FETCH_SIZE + WRITE_SIZE)*1024 of "
+                               "separate rocprofv3 --pmc passes over this command (tools/pmc_bench.sh)" % prof)
+                valu = pm.get("valu") or None
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     out = {
         "metric": "prover_constraints_per_sec",
         "value": round(value, 1),
@@ -242,7 +245,7 @@ def main():
                                if sharded else ("one GPU" if world == 1 else "one independent proof per rank (replicas), no data-path collective"),
                    "proof_bytes": int(proof_buf.size * 8)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu_pmc": valu,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu_pmc_from_committed_profile": valu,
                      "kernel": "bj::%s_leaves_kernel (witness tree: %d leaves x %d elements per launch)" % ({"blake2s": "blake2s", "keccak256": "keccak"}.get(args.transcript, "poseidon2"), leaves, W),
                      "kernel_ms": round(leaf_s * 1e3, 3), "algorithmic_bytes_per_launch": leaf_bytes,
                      "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},
@@ -294,16 +297,34 @@ def main():
                       "achieved": round(nb / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": round(nb / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nb,
                       "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
-        try:   # counters of the same two kernels from the committed rocprofv3 passes over tools/cfg2_ntt.py --cfg2-only
-            cs = json.load(open(os.path.join(ROOT, "profiles", "r02_cfg2_ntt_summary.json")))
-            out["ntt"]["pmc"] = {"source": "profiles/r02_cfg2_ntt_summary.json (tools/prof_cfg2.sh)",
-                                 "kernels": {k.split("(")[0].replace("void ", ""): {f: v[f] for f in
-                                             ("avg_ms", "SQ_INSTS_VALU", "cycles_per_valu_instruction_per_simd", "valu_busy_estimate",
-                                              "traffic_bytes", "traffic_over_algorithmic") if f in v}
-                                             for k, v in cs["kernels"].items()}}
-        except (OSError, KeyError, ValueError):
-            pass
+        for prof in ("r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
+            try:   # counters of the same two kernels from the committed rocprofv3 passes over tools/cfg2_ntt.py --cfg2-only
+                cs = json.load(open(os.path.join(ROOT, "profiles", prof)))
+                out["ntt"]["pmc_from_committed_profile"] = {
+                    "source": "NOT measured in this run: profiles/%s (tools/prof_cfg2.sh)" % prof,
+                    "kernels": {k.split("(")[0].replace("void ", ""): {f: v[f] for f in
+                                ("avg_ms", "SQ_INSTS_VALU", "cycles_per_valu_instruction_per_simd", "valu_busy_estimate",
+                                 "traffic_bytes", "traffic_over_algorithmic") if f in v} for k, v in cs["kernels"].items()}}
+                break
+            except (OSError, KeyError, ValueError):
+                pass
         del src, dst
+        # the same transforms at the size and shape the proof runs them: the witness round's LDE, 93 columns x 2^log_n x 8 cosets
+        # (coset-expanding front pass + strided + local pass), algorithmic bytes 8 n (1 + L) per column
+        if log_n >= 20:
+            lcols, L = 93, args.fri_lde
+            mono = torch.randint(0, 1 << 62, (lcols, n), dtype=torch.int64, device=dev)
+            lde = torch.empty((lcols, L, n), dtype=torch.int64, device=dev)
+            ctx.lde_batch(mono.data_ptr(), lde.data_ptr(), log_n, lcols, L.bit_length() - 1)
+            ctx.timer_start()
+            for _ in range(3):
+                ctx.lde_batch(mono.data_ptr(), lde.data_ptr(), log_n, lcols, L.bit_length() - 1)
+            lms = ctx.timer_stop_ms() / 3
+            lb = 8.0 * n * (1 + L) * lcols
+            out["ntt"]["lde_at_bench_size"] = {"workload": "LDE %d columns x 2^%d x %d cosets (the witness round's)" % (lcols, log_n, L),
+                                               "ms": round(lms, 3), "achieved": round(lb / lms / 1e6, 2), "unit": "GB/s",
+                                               "frac": round(lb / lms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": lb}
+            del mono, lde
 
     if rank == 0:
         # parity spot check of what was just timed: the oracle's verifier restatement must accept the timed proof
