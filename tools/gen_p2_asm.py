@@ -10,11 +10,12 @@ Here
     two S-boxes interleaved so that every SGPR wait state is covered by the other chain (no s_nop in full rounds);
   * the external linear layer circ(2*M4, M4, M4) runs on the low and the high 32-bit words separately as carry-free 64-bit
     sums (out = M4 * (x_b + sum_b x_b): 24 + 24 multiply-adds give the zero-extension for free, 48 v_lshl_add_u64 do M4),
-    the NEXT round's constants are added to the unreduced sums (one multiply-add per word half), and each output is folded
-    back to a weak 64-bit word once (3 half-rate + 1 full-rate instruction);
+    the NEXT round's constants are folded through the matrix at generation time (M x + c = M (x + M^-1 c): block 0's share rides
+    on the first multiply-add of the column sums, 16 multiply-adds per layer for the rest), and each output is folded back to a
+    weak 64-bit word by one multiply-add and one add whose rare carry is fixed out of line;
   * partial rounds: the S-box chain of word 0 is interleaved with the word sums of the other eleven;
   * rounds are loops around ONE copy of the full-round body (8.5 KB of code instead of 36 KB).
-State words live in v[0:23] (operands tied to physical registers), temporaries in v[24:71], scalars in s[36:95].
+State words live in v[0:23] (operands tied to physical registers), temporaries in v[24:71], scalars in s[36:101].
 
     python tools/gen_p2_asm.py      # rewrites era_boojum_amd/csrc/p2_asm.inc (also run by era_boojum_amd/build.py)
 """
@@ -25,18 +26,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "era_boojum_amd", "csrc", "p2_asm.inc")
 RC_INC = os.path.join(ROOT, "era_boojum_amd", "csrc", "poseidon_rc.inc")
 
-WAYS = int(os.environ.get("BJ_P2_WAYS", "2"))            # S-boxes interleaved in a full round (2, 3 or 4; v[24:71] holds four sets)
+WAYS = int(os.environ.get("BJ_P2_WAYS", "3"))            # S-boxes interleaved in a full round (2, 3 or 4; v[24:71] holds four sets): 3 measured best by ~1 %
 assert WAYS in (2, 3, 4)
 COMBINE_INLINE = os.environ.get("BJ_P2_COMBINE", "") == "inline"
 SH = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]           # internal matrix 1 + diag(2^SH)  (poseidon2/params.rs:38-39)
 P = (1 << 64) - (1 << 32) + 1
 
 # ---- scalar registers (all clobbered) ----
-S_RC = 40            # s[40:63]: the 12 round constants (lo, hi) of the layer being applied
+S_RC = 40            # s[40:71]: the constants of the layer being applied — an external layer's 32 words (see fold_ext_constants),
+                     # 12 (lo, hi) pairs for the one weak addition, one pair in a partial round
 S_PTR = 36           # s[36:37]: running pointer into P2_ASM_RC
 S_CNT, S_PHASE = 38, 39
-S_SHIFT = 64         # s[64:69]: 2^14, 2^11, 2^8, 2^9, 2^13, 2^12 (powers above 64 are not inline constants)
-S_MASK = 70          # s[70:95]: carry / borrow masks (pairs)
+S_SHIFT = 72         # s[72:77]: 2^14, 2^11, 2^8, 2^9, 2^13, 2^12 (powers above 64 are not inline constants)
+S_MASK = 78          # s[78:101]: carry / borrow masks (pairs)
+S_TOP = 101          # last scalar register the stream touches
 SHIFT_REG = {14: S_SHIFT, 11: S_SHIFT + 1, 8: S_SHIFT + 2, 9: S_SHIFT + 3, 13: S_SHIFT + 4, 12: S_SHIFT + 5}
 
 
@@ -188,7 +191,9 @@ class Gen:
 
     # ------------------------------------------------------------------------------------------------ external layer
     def ext_layer(self):
-        """state <- circ(2*M4, M4, M4) * state + the 12 constants in s[S_RC ...]  (suggested_mds.rs:21-103).
+        """state <- circ(2*M4, M4, M4) * state + 12 constants  (suggested_mds.rs:21-103).  The constants are folded THROUGH the
+        matrix (fold_ext_constants): out_b = M4 (x_b + sum_b x_b + D_b), D_0 rides on the first multiply-add of the column sums,
+        blocks 1 and 2 add D_b - D_0 to their z — 16 multiply-adds per layer instead of 24 after the matrix.
         Registers: U_j (low / high plane) in v24..v39, block temporaries in v40..v63, flags v64..v66."""
         U = lambda plane, j: 24 + 8 * plane + 2 * j
         seq = []
@@ -196,7 +201,8 @@ class Gen:
             for plane in range(2):
                 for b in range(3):
                     src = S(4 * b + j) + plane
-                    seq.append(Ins("v_mad_u64_u32 %s, vcc, v%d, 1, %s" % (vp(U(plane, j)), src, "0" if b == 0 else vp(U(plane, j)))))
+                    # the sum starts from block 0's folded constant D_0j (a {half, 0} scalar pair): free
+                    seq.append(Ins("v_mad_u64_u32 %s, vcc, v%d, 1, %s" % (vp(U(plane, j)), src, sp(S_RC + 2 * (2 * j + plane)) if b == 0 else vp(U(plane, j)))))
         self.emit(seq)
         for b in range(3):
             Z_ = lambda plane, j: 40 + 12 * plane + 2 * j        # z_j, later y_j (4 pairs per plane) ...
@@ -206,6 +212,8 @@ class Gen:
             for j in range(4):
                 for plane in range(2):
                     seq.append(Ins("v_mad_u64_u32 %s, vcc, v%d, 1, %s" % (vp(Z_(plane, j)), S(4 * b + j) + plane, vp(U(plane, j)))))
+                    if b:                        # blocks 1, 2: + (D_bj - D_0j), word halves apart
+                        seq.append(Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(Z_(plane, j)), S_RC + 16 + 8 * (b - 1) + 2 * j + plane, vp(Z_(plane, j)))))
             m4 = [[], []]
             for plane in range(2):
                 z = [Z_(plane, j) for j in range(4)]
@@ -223,10 +231,6 @@ class Gen:
                 ]
             seq += interleave(m4)
             y = lambda plane, j: [Z_(plane, 0), T0(plane), Z_(plane, 2), T1(plane)][j]
-            for j in range(4):                   # + the next round's constant, word halves apart
-                w = 4 * b + j
-                seq.append(Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(y(0, j)), S_RC + 2 * w, vp(y(0, j)))))
-                seq.append(Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(y(1, j)), S_RC + 2 * w + 1, vp(y(1, j)))))
             comb = [self.combine(y(0, j), y(1, j), S(4 * b + j), 64 + j, S_MASK + 2 * j) for j in range(4)]
             seq += interleave(comb)
             self.emit(seq)
@@ -247,7 +251,7 @@ class Gen:
 
     # ------------------------------------------------------------------------------------------------ rounds
     def full_round(self):
-        self.load_rc(12)                          # constants the layer at the end of this round adds (arrive during the S-boxes)
+        self.load_rc(16)                          # folded constants of the layer at the end of this round (arrive during the S-boxes)
         ways = WAYS                               # S-box chains issued round-robin: 12 temporaries and 3 mask pairs each
         for k in range(0, 12, ways):
             chains = [self.sbox(k + i, 24 + 12 * i, (S_MASK + 6 * i, S_MASK + 6 * i + 2, S_MASK + 6 * i + 4)) for i in range(ways)]
@@ -304,7 +308,7 @@ class Gen:
         self.raw("s_mov_b64 %s, %%[rc]" % sp(S_PTR))
         for e, r in SHIFT_REG.items():
             self.raw("s_mov_b32 s%d, 0x%x" % (r, 1 << e))
-        self.load_rc(12)                          # round 0's constants, added by the initial layer
+        self.load_rc(16)                          # round 0's constants, folded into the initial layer
         self.raw("s_waitcnt lgkmcnt(0)")
         self.ext_layer()
         self.raw("s_mov_b32 s%d, 0" % S_PHASE)
@@ -333,20 +337,59 @@ class Gen:
         self.raw("%s:" % end)
 
 
+M4 = [[5, 7, 1, 3], [4, 6, 1, 1], [1, 3, 5, 7], [1, 1, 4, 6]]
+
+
+def _solve(M, rhs):
+    n = len(M)
+    A = [[x % P for x in row] + [rhs[i] % P] for i, row in enumerate(M)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if A[r][c])
+        A[c], A[piv] = A[piv], A[c]
+        inv = pow(A[c][c], P - 2, P)
+        A[c] = [x * inv % P for x in A[c]]
+        for r in range(n):
+            if r != c and A[r][c]:
+                f = A[r][c]
+                A[r] = [(x - f * y) % P for x, y in zip(A[r], A[c])]
+    return [A[i][n] for i in range(n)]
+
+
+def fold_ext_constants(rc12):
+    """M_E x + rc = M_E (x + C) with C = M_E^-1 rc; in the block form of ext_layer, out_b = M4 (x_b + sum_b' x_b' + D_b) with
+    D_b = C_b + sum_b' C_b'.  Sixteen table entries: the eight 32-bit halves of D_0 (each as a {half, 0} pair: they are the
+    addend of the first multiply-add of the column sums, order (word j, plane)), then D_1 - D_0 and D_2 - D_0 (four words each)."""
+    ME = [[M4[i % 4][j % 4] * (2 if i // 4 == j // 4 else 1) for j in range(12)] for i in range(12)]
+    C = _solve(ME, rc12)
+    Ssum = [(C[j] + C[4 + j] + C[8 + j]) % P for j in range(4)]
+    D = [[(C[4 * b + j] + Ssum[j]) % P for j in range(4)] for b in range(3)]
+    chk = [(sum(M4[i][j] * (1000 + 4 * b + j + sum(1000 + 4 * bb + j for bb in range(3)) + D[b][j]) for j in range(4))) % P for b in range(3) for i in range(4)]
+    ref = [(sum(ME[r][k] * (1000 + k) for k in range(12)) + rc12[r]) % P for r in range(12)]
+    assert chk == ref
+    out = []
+    for j in range(4):
+        out += [D[0][j] & 0xFFFFFFFF, D[0][j] >> 32]
+    for b in (1, 2):
+        out += [(D[b][j] - D[0][j]) % P for j in range(4)]
+    return out
+
+
 def rc_table():
-    """The constants in the order the stream consumes them: 12 for the initial layer (round 0); after full round r the layer adds
-    round r+1's (word 0 only when a partial round follows, none after the last round); after partial round r word 0's constant of
-    round r+1 (none when a full round follows); the 12 of the first closing full round in between."""
+    """The constants in the order the stream consumes them: the folded 16 entries of the initial layer (round 0's constants); after
+    full round r the layer folds round r+1's (word 0 only when a partial round follows, none after the last round); after partial
+    round r word 0's constant of round r+1 (none when a full round follows); the 12 of the first closing full round in between
+    (added weakly, not through a layer)."""
     txt = open(RC_INC).read()
     rc = [int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]{16}", txt)]
     assert len(rc) == 360
-    R = lambda r: rc[12 * r:12 * r + 12]
-    t = R(0) + R(1) + R(2) + R(3) + [rc[12 * 4]] + [0] * 11
-    t += [rc[12 * r] for r in range(5, 26)] + [0]
+    R = lambda r: [x % P for x in rc[12 * r:12 * r + 12]]
+    F = fold_ext_constants
+    t = F(R(0)) + F(R(1)) + F(R(2)) + F(R(3)) + F([rc[12 * 4] % P] + [0] * 11)
+    t += [rc[12 * r] % P for r in range(5, 26)] + [0]
     t += R(26)
-    t += R(27) + R(28) + R(29) + [0] * 12
-    assert len(t) == 12 + 48 + 22 + 12 + 48
-    return [x % P for x in t]
+    t += F(R(27)) + F(R(28)) + F(R(29)) + F([0] * 12)
+    assert len(t) == 16 * 5 + 22 + 12 + 16 * 4
+    return t
 
 
 def generate():
@@ -357,10 +400,10 @@ def generate():
     rows = ",\n    ".join(", ".join("0x%016xULL" % v for v in tab[i:i + 4]) for i in range(0, len(tab), 4))
     outs = ", ".join('"={v[%d:%d]}"(s[%d])' % (2 * k, 2 * k + 1, k) for k in range(12))
     ins = ", ".join('"{v[%d:%d]}"(s[%d])' % (2 * k, 2 * k + 1, k) for k in range(12))
-    clob = ", ".join(['"v%d"' % r for r in range(24, 72)] + ['"s%d"' % r for r in range(36, 96)] + ['"vcc"', '"scc"'])
+    clob = ", ".join(['"v%d"' % r for r in range(24, 72)] + ['"s%d"' % r for r in range(36, S_TOP + 1)] + ['"vcc"', '"scc"'])
     n_ins = sum(1 for l in g.lines if not l.endswith(":"))
     src = '''// GENERATED by tools/gen_p2_asm.py — do not edit.  The Poseidon2 permutation as one scheduled gfx950 instruction stream
-// (%d instructions, %d of them s_nop; state in v[0:23], temporaries v[24:71], scalars s[36:95]).
+// (%d instructions, %d of them s_nop; state in v[0:23], temporaries v[24:71], scalars s[36:101]).
 #pragma once
 
 namespace bj {
