@@ -54,3 +54,27 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "liboracle", "oracle.h", "orc_"):
                     assert needle not in txt, (f, needle)
+
+
+def test_generated_sources_are_current():
+    """csrc/p2_asm.inc, csrc/gl_asm.inc and csrc/jit_headers.inc are generated (tools/gen_p2_asm.py, tools/gen_gl_asm.py,
+    era_boojum_amd/build.py::write_jit_headers) and committed so that a checkout builds with hipcc alone: the committed files must
+    be what the generators emit today — in particular the run-time compiler must get the same gl.h the library was built with."""
+    import importlib.util
+    from era_boojum_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    assert open(os.path.join(B.CSRC, "p2_asm.inc")).read() == load("gen_p2_asm").generate(), "run python tools/gen_p2_asm.py"
+    before = open(os.path.join(B.CSRC, "gl_asm.inc")).read()
+    load("gen_gl_asm").main()
+    assert open(os.path.join(B.CSRC, "gl_asm.inc")).read() == before, "csrc/gl_asm.inc was stale (regenerated now): commit it"
+    inc = open(B.JIT_HEADERS_INC).read()
+    B.write_jit_headers()
+    assert open(B.JIT_HEADERS_INC).read() == inc, "csrc/jit_headers.inc was stale (regenerated now): commit it"
+    for h in B.JIT_HEADERS:
+        assert open(os.path.join(B.CSRC, h)).read()[:2000] in inc.replace(')BJRAW"\n    R"BJRAW(', "")
