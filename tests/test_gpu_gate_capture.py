@@ -111,3 +111,29 @@ def test_recursion_class_circuit_from_capture_order_lists_only():
     pb, _ = sb.prove()
     assert np.array_equal(pa, pb)
     sa.close(); sb.close()
+
+
+def test_recursion_class_proof_from_capture_lists_equals_the_oracle_proof_at_2p14():
+    """Byte identity, not only "same as the hand-wired kinds": the recursion-class circuit (155 columns, eleven gate types, the
+    golden proof's FRI parameters: LDE 2, cap 32) at 2^14 rows with every evaluator handed over in the reference's capture order
+    and sparse numbering — fused sweep of the build-time kernels, the hand-written Poseidon2 evaluator reached through the
+    fingerprint of the 9.6 k-relation capture — against the oracle prover (numpy semantics of the same op lists, the compact
+    Poseidon2 restatement).  ~40 s of oracle time."""
+    from test_gpu_prover import _compare
+    c = S.recursion_like_circuit(14, seed=21, poseidon2_as_op_list=True)
+    names = {"U8x4FMAGate": "u8x4_fma", "Poseidon2FlattenedGate": "poseidon2_flattened", "DotProductGate<4>": "dot_product4",
+             "ZeroCheckGate": "zero_check", "UIntXAddGate": "uintx_add", "SelectionGate": "selection",
+             "ParallelSelectionGate<4>": "parallel_selection4", "FmaGateInBaseFieldWithoutConstant": "fma",
+             "ReductionGate<4>": "reduction4", "ConstantsAllocatorGate": "constants_allocator"}
+    osetup = OP.Setup(c, 2, 32, threads=16)
+    po = OP.prove(c, osetup, 2, 32, security_level=60, threads=16)      # the oracle takes kinds 1-3 natively, op lists by numpy
+    for g in c.gates:
+        if g.name in names:
+            g.program = RC.to_program_raw(TC.CAPTURES[names[g.name]][0]())
+            g.kind = S.GATE_PROGRAM
+    gsetup = E.ProverSetup(ctx(), c, 2, 32, 60)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=60)
+    _compare(pg, po)
+    gsetup.close()
