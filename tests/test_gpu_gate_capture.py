@@ -120,7 +120,7 @@ def test_recursion_class_proof_from_capture_lists_equals_the_oracle_proof_at_2p1
     fingerprint of the 9.6 k-relation capture — against the oracle prover (numpy semantics of the same op lists, the compact
     Poseidon2 restatement).  ~40 s of oracle time."""
     from test_gpu_prover import _compare
-    c = S.recursion_like_circuit(14, seed=21, poseidon2_as_op_list=True)
+    c = S.recursion_like_circuit(14, seed=21)      # the oracle evaluates the Poseidon2 gate from its compact restatement
     names = {"U8x4FMAGate": "u8x4_fma", "Poseidon2FlattenedGate": "poseidon2_flattened", "DotProductGate<4>": "dot_product4",
              "ZeroCheckGate": "zero_check", "UIntXAddGate": "uintx_add", "SelectionGate": "selection",
              "ParallelSelectionGate<4>": "parallel_selection4", "FmaGateInBaseFieldWithoutConstant": "fma",
