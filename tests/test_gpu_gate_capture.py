@@ -113,14 +113,15 @@ def test_recursion_class_circuit_from_capture_order_lists_only():
     sa.close(); sb.close()
 
 
-def test_recursion_class_proof_from_capture_lists_equals_the_oracle_proof_at_2p14():
+@pytest.mark.parametrize("log_n", [14, 18])
+def test_recursion_class_proof_from_capture_lists_equals_the_oracle_proof(log_n):
     """Byte identity, not only "same as the hand-wired kinds": the recursion-class circuit (155 columns, eleven gate types, the
-    golden proof's FRI parameters: LDE 2, cap 32) at 2^14 rows with every evaluator handed over in the reference's capture order
+    golden proof's FRI parameters: LDE 2, cap 32) at 2^14 and 2^18 rows with every evaluator handed over in the reference's capture order
     and sparse numbering — fused sweep of the build-time kernels, the hand-written Poseidon2 evaluator reached through the
     fingerprint of the 9.6 k-relation capture — against the oracle prover (numpy semantics of the same op lists, the compact
-    Poseidon2 restatement).  ~40 s of oracle time."""
+    Poseidon2 restatement).  ~1 minute of oracle time at 2^18."""
     from test_gpu_prover import _compare
-    c = S.recursion_like_circuit(14, seed=21)      # the oracle evaluates the Poseidon2 gate from its compact restatement
+    c = S.recursion_like_circuit(log_n, seed=21)      # the oracle evaluates the Poseidon2 gate from its compact restatement
     names = {"U8x4FMAGate": "u8x4_fma", "Poseidon2FlattenedGate": "poseidon2_flattened", "DotProductGate<4>": "dot_product4",
              "ZeroCheckGate": "zero_check", "UIntXAddGate": "uintx_add", "SelectionGate": "selection",
              "ParallelSelectionGate<4>": "parallel_selection4", "FmaGateInBaseFieldWithoutConstant": "fma",
