@@ -138,3 +138,28 @@ def test_recursion_class_proof_from_capture_lists_equals_the_oracle_proof(log_n)
     pg = proof_format.parse(buf, security_level=60)
     _compare(pg, po)
     gsetup.close()
+
+
+def test_run_time_compiled_kernels_are_cached_on_disk(tmp_path):
+    """BJ_GATE_JIT_CACHE=<dir>: the first process compiles the host's gate and leaves its code object there, the second one
+    loads it instead of compiling (bj_gate_jit_status tells) — same terms both times."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, ctypes as C, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch; torch.cuda.init();"
+            "import era_boojum_amd as E; from gpu_util import DevBuf, ctx; import reference_capture as RC, test_gate_canon as TC;"
+            "prog = RC.to_program(TC.CAPTURES['matrix_multiplication_host_matrix'][0]());"
+            "var = np.arange(24 * 64, dtype=np.uint64).reshape(24, 64) * np.uint64(0x9E3779B97F4A7C15);"
+            "d_var, d_out = DevBuf(var), DevBuf(nelems=12 * 64);"
+            "ctx().gate_program_eval(prog, d_var.ptr, 64, d_var.ptr, 64, 1, 24, 0, 64, d_out.ptr);"
+            "buf = C.create_string_buffer(256); n = E.load_library().bj_gate_jit_status(buf, 256);"
+            "print('STATUS', n, buf.value.decode()); np.save(sys.argv[1], d_out.get((12, 64)))") % (os.path.dirname(here), here)
+    outs = []
+    for k in range(2):
+        out = os.path.join(str(tmp_path), "terms%d.npy" % k)
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, BJ_GATE_JIT_CACHE=str(tmp_path)), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((np.load(out), [l for l in r.stdout.splitlines() if l.startswith("STATUS")][0]))
+    assert any(f.endswith(".hsaco") for f in os.listdir(str(tmp_path)))
+    assert "1 gate kernels compiled" in outs[0][1] and "0 loaded" in outs[0][1]
+    assert "0 gate kernels compiled" in outs[1][1] and "1 loaded" in outs[1][1]
+    assert np.array_equal(outs[0][0], outs[1][0])
