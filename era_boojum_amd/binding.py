@@ -85,7 +85,8 @@ _SIGNATURES = {
     "bj_proof_serialize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_setup_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_setup_create_from_dump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
-    "bj_prove_from_dumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bj_prove_from_dumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                      C.POINTER(C.c_void_p)]),
     "bj_proof_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_proof_comm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -777,11 +778,13 @@ class ProverSetup:
                                             _np_ptr(pv), C.byref(h)))
         return self._finish(h)
 
-    def prove_from_dumps(self, witness_vec_dump, variables_hint_dump):
-        """bj_prove_from_dumps: the reference's `WitnessVec` and `DenseVariablesCopyHint` bytes in, the proof out."""
+    def prove_from_dumps(self, witness_vec_dump, variables_hint_dump, witness_hint_dump=None):
+        """bj_prove_from_dumps: the reference's `WitnessVec` and `DenseVariablesCopyHint` (+ `DenseWitnessCopyHint`) bytes in, the
+        proof out."""
         w, v = bytes(witness_vec_dump), bytes(variables_hint_dump)
+        x = bytes(witness_hint_dump) if witness_hint_dump is not None else None
         h = C.c_void_p()
-        self._ctx._check(self._lib.bj_prove_from_dumps(self._ctx._h, self._h, w, len(w), v, len(v), C.byref(h)))
+        self._ctx._check(self._lib.bj_prove_from_dumps(self._ctx._h, self._h, w, len(w), v, len(v), x, len(x) if x else 0, C.byref(h)))
         return self._finish(h)
 
     def prove_dev(self, d_variables, d_multiplicities, public_values=None):

@@ -232,13 +232,15 @@ int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void
 }
 
 int bj_prove_from_dumps(bj_ctx *ctx, const bj_setup *setup, const void *witness_vec, size_t witness_vec_len,
-                        const void *variables_hint, size_t variables_hint_len, bj_proof **out) {
+                        const void *variables_hint, size_t variables_hint_len, const void *witness_hint, size_t witness_hint_len,
+                        bj_proof **out) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!setup || !witness_vec || !variables_hint || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_from_dumps: null argument");
     unsigned log_n = 0, num_vars = 0, num_witness_cols = 0, num_public = 0;
     if (int rc = bj_setup_shape(setup, &log_n, &num_vars, &num_witness_cols, &num_public)) return rc;
-    if (num_witness_cols)
-        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_prove_from_dumps: circuits with non-copiable witness columns (DenseWitnessCopyHint) are not read yet");
+    if ((num_witness_cols != 0) != (witness_hint != nullptr))
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_from_dumps: the setup has %u non-copiable witness columns: a DenseWitnessCopyHint "
+                        "dump is %s", num_witness_cols, num_witness_cols ? "required" : "not expected");
     const size_t n = (size_t)1 << log_n;
     Reader w(witness_vec, witness_vec_len);
     const uint64_t n_pub = w.u64v();
@@ -257,30 +259,37 @@ int bj_prove_from_dumps(bj_ctx *ctx, const bj_setup *setup, const void *witness_
     if (!w.ok || !values || (n_mult && !mult) || w.p != w.end)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "WitnessVec dump: truncated or trailing bytes");
     if (n_mult > n) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "WitnessVec dump: %llu multiplicities for %zu rows", (unsigned long long)n_mult, n);
-    Reader h(variables_hint, variables_hint_len);
-    const uint64_t hint_cols = h.u64v();
-    if (!h.ok || hint_cols != num_vars)
-        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "DenseVariablesCopyHint dump: %llu columns, the circuit has %u", (unsigned long long)hint_cols, num_vars);
-    std::vector<const unsigned char *> hint_col(num_vars);
-    for (unsigned c = 0; c < num_vars; c++) {
-        const uint64_t len = h.u64v();
-        if (!h.ok || len != n) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "DenseVariablesCopyHint dump: column %u has %llu cells, not %zu", c, (unsigned long long)len, n);
-        hint_col[c] = h.skip(n * 8);
-        if (!hint_col[c]) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "DenseVariablesCopyHint dump: truncated");
+    // DenseVariablesCopyHint, then DenseWitnessCopyHint (same layout, same indexing of all_values: witness.rs:445-490): the witness
+    // columns travel right behind the variable columns, as bj_prove_dev takes them
+    const unsigned total_cols = num_vars + num_witness_cols;
+    std::vector<const unsigned char *> hint_col(total_cols);
+    for (int which = 0; which < (num_witness_cols ? 2 : 1); which++) {
+        Reader h(which ? witness_hint : variables_hint, which ? witness_hint_len : variables_hint_len);
+        const char *what = which ? "DenseWitnessCopyHint" : "DenseVariablesCopyHint";
+        const unsigned want = which ? num_witness_cols : num_vars, first = which ? num_vars : 0;
+        const uint64_t hint_cols = h.u64v();
+        if (!h.ok || hint_cols != want)
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "%s dump: %llu columns, the circuit has %u", what, (unsigned long long)hint_cols, want);
+        for (unsigned c = 0; c < want; c++) {
+            const uint64_t len = h.u64v();
+            if (!h.ok || len != n) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "%s dump: column %u has %llu cells, not %zu", what, c, (unsigned long long)len, n);
+            hint_col[first + c] = h.skip(n * 8);
+            if (!hint_col[first + c]) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "%s dump: truncated", what);
+        }
+        if (h.p != h.end) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "%s dump: trailing bytes", what);
     }
-    if (h.p != h.end) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "DenseVariablesCopyHint dump: trailing bytes");
     // cells on the device: all_values once, the hint in groups of columns, one gather per group
     DeviceBlock d_values, d_hint, d_cells, d_mult, d_bad;
     const unsigned G = 8;
     BJ_HIP(ctx, hipMalloc(&d_values.p, (n_values ? n_values : 1) * 8));
     BJ_HIP(ctx, hipMalloc(&d_hint.p, (size_t)G * n * 8));
-    BJ_HIP(ctx, hipMalloc(&d_cells.p, (size_t)num_vars * n * 8));
+    BJ_HIP(ctx, hipMalloc(&d_cells.p, (size_t)total_cols * n * 8));
     BJ_HIP(ctx, hipMalloc(&d_mult.p, n * 8));
     BJ_HIP(ctx, hipMalloc(&d_bad.p, 4));
     BJ_HIP(ctx, hipMemsetAsync(d_bad.p, 0, 4, ctx->stream));
     if (n_values) BJ_HIP(ctx, hipMemcpyAsync(d_values.p, values, n_values * 8, hipMemcpyHostToDevice, ctx->stream));
-    for (unsigned c0 = 0; c0 < num_vars; c0 += G) {
-        const unsigned g = num_vars - c0 < G ? num_vars - c0 : G;
+    for (unsigned c0 = 0; c0 < total_cols; c0 += G) {
+        const unsigned g = total_cols - c0 < G ? total_cols - c0 : G;
         for (unsigned k = 0; k < g; k++)
             BJ_HIP(ctx, hipMemcpyAsync((u64 *)d_hint.p + (size_t)k * n, hint_col[c0 + k], n * 8, hipMemcpyHostToDevice, ctx->stream));
         const size_t count = (size_t)g * n;
@@ -291,7 +300,7 @@ int bj_prove_from_dumps(bj_ctx *ctx, const bj_setup *setup, const void *witness_
     BJ_CHECK_LAUNCH(ctx);
     unsigned bad = 0;
     BJ_HIP(ctx, hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
-    if (bad) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "DenseVariablesCopyHint dump: a cell names a variable beyond all_values");
+    if (bad) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "copy hint dump: a cell names a variable beyond all_values");
     // materialize_multiplicities_polynomials (witness.rs:225-272): the per-table counters, concatenated, zero-extended
     std::vector<u64> hm(n, 0);
     for (uint64_t i = 0; i < n_mult; i++) {

@@ -494,9 +494,11 @@ int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void
                               const bj_proof_config *config, bj_setup **out);
 /* witness_set_from_witness_vec (witness.rs:386-443) on the device — cell = all_values[hint & (2^48 - 1)], 0 where bit 63 marks a
  * placeholder; multiplicities zero-extended to the trace (witness.rs:225-272); public input values read from their cells — then
- * bj_prove_dev.  Circuits with non-copiable witness columns are refused (BJ_ERR_UNSUPPORTED). */
+ * bj_prove_dev.  witness_hint: the DenseWitnessCopyHint dump (hints/mod.rs:17-21; same layout and indexing) when the circuit has
+ * non-copiable witness columns, NULL / 0 otherwise. */
 int bj_prove_from_dumps(bj_ctx *ctx, const bj_setup *setup, const void *witness_vec, size_t witness_vec_len,
-                        const void *variables_hint, size_t variables_hint_len, bj_proof **out);
+                        const void *variables_hint, size_t variables_hint_len, const void *witness_hint, size_t witness_hint_len,
+                        bj_proof **out);
 
 /* WitnessSet (witness.rs:21-27) in: variables, then the non-copiable witness columns: [num_vars + num_witness_cols][n] natural
  * order, multiplicities [n] (NULL without lookups),

@@ -401,14 +401,30 @@ pub fn prove_hip_from_dumps<H: TreeHasher<F>, EXT: FieldExtension<2, BaseField =
     setup: &HipSetup,
     witness_vec: &crate::cs::implementations::witness::WitnessVec<F>,
     variables_hint: &crate::cs::implementations::hints::DenseVariablesCopyHint,
+    witness_hint: Option<&crate::cs::implementations::hints::DenseWitnessCopyHint>,     // circuits with non-copiable witness columns
     proof_config: ProofConfig,
 ) -> Proof<F, H, EXT> {
     use crate::cs::implementations::fast_serialization::MemcopySerializable;
-    let (mut w, mut h) = (Vec::new(), Vec::new());
+    let (mut w, mut h, mut x) = (Vec::new(), Vec::new(), Vec::new());
     witness_vec.write_into_buffer(&mut w).expect("WitnessVec serialises");
     variables_hint.write_into_buffer(&mut h).expect("DenseVariablesCopyHint serialises");
+    if let Some(wh) = witness_hint {
+        wh.write_into_buffer(&mut x).expect("DenseWitnessCopyHint serialises");
+    }
     let mut proof = std::ptr::null_mut();
-    ctx.check(unsafe { bj_prove_from_dumps(ctx.raw, setup.raw, w.as_ptr() as *const _, w.len(), h.as_ptr() as *const _, h.len(), &mut proof) });
+    ctx.check(unsafe {
+        bj_prove_from_dumps(
+            ctx.raw,
+            setup.raw,
+            w.as_ptr() as *const _,
+            w.len(),
+            h.as_ptr() as *const _,
+            h.len(),
+            if witness_hint.is_some() { x.as_ptr() as *const _ } else { std::ptr::null() },
+            x.len(),
+            &mut proof,
+        )
+    });
     let mut words = vec![0u64; unsafe { bj_proof_size_u64(proof) }];
     ctx.check(unsafe { bj_proof_serialize(proof, words.as_mut_ptr()) });
     unsafe { bj_proof_destroy(proof) };

@@ -397,3 +397,31 @@ def test_bounded_wrappers_are_the_inner_evaluator_with_fewer_repetitions():
     _compare(pg, po)
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
     gsetup.close()
+
+
+def test_dumps_with_witness_columns_through_the_c_abi():
+    """bj_prove_from_dumps with a DenseWitnessCopyHint: the non-copiable witness columns are materialised from the same
+    all_values by their own hint (witness.rs:445-490) and land behind the variables; same proof as the in-memory circuit."""
+    import copy
+    from era_boojum_amd import memcopy_format as M
+    c = S.sha_shaped_circuit(10, seed=5, table_bits=2, gates=S.witness_gates(60, 4, 5), mix=(0.05, 0.3, 0.3, 0.2), num_witness_cols=5)
+    a = E.ProverSetup(ctx(), c, 8, 16, 30)
+    pa, _ = a.prove()
+    V, n = c.variables.shape
+    all_values = np.concatenate([c.variables.reshape(-1), c.witness.reshape(-1)])
+    var_ids = np.arange(V * n, dtype=np.int64).reshape(V, n)
+    wit_ids = V * n + np.arange(5 * n, dtype=np.int64).reshape(5, n)
+    var_ids[c.variables == 0] = -1                         # empty cells: placeholders materialise as 0
+    wit_dump = M.write_witness_vec([(col, row) for col, row, _ in c.public_inputs], all_values,
+                                   c.multiplicities[0, :c.total_tables_len].astype(np.uint32))
+    bare = copy.copy(c)
+    bare.gates = [copy.copy(g) for g in c.gates]
+    for g in bare.gates:
+        g.path = []
+    b = E.ProverSetup(ctx(), bare, 8, 16, 30, setup_base_dump=M.write_setup_base(c))
+    assert np.array_equal(a.cap(), b.cap())
+    pb, _ = b.prove_from_dumps(wit_dump, M.write_variables_hint(var_ids), M.write_variables_hint(wit_ids))
+    assert np.array_equal(pa, pb)
+    with pytest.raises(E.BoojumHipError, match="DenseWitnessCopyHint"):
+        b.prove_from_dumps(wit_dump, M.write_variables_hint(var_ids))
+    a.close(); b.close()
