@@ -154,11 +154,14 @@ int bad(std::string *err, const char *fmt, unsigned x = 0, unsigned y = 0) {
 int canonicalize(const bj_gate_program *p, Program *out, std::string *err) {
     if (!p || !p->writes || p->num_writes == 0 || (p->num_relations && !p->relations))
         return bad(err, "gate program: null / empty program");
-    if (p->num_temporaries > (1u << 24) || p->num_relations > (1u << 24) || p->num_writes > (1u << 20))
-        return bad(err, "gate program: %u relations / %u temporaries: too large", p->num_relations, p->num_temporaries);
+    if (p->num_relations > (1u << 24) || p->num_writes > (1u << 20))
+        return bad(err, "gate program: %u relations / %u terms: too large", p->num_relations, p->num_writes);
     Builder B;
     B.nodes.reserve(p->num_relations);
-    std::vector<Op> cur(p->num_temporaries);   // the value each temporary holds right now (kind K_NONE: not written yet)
+    // the value each temporary holds right now; a map, not an array: the reference's process-wide counter makes the numbers of a
+    // capture start anywhere (num_temporaries may be millions for a list of ten relations)
+    std::unordered_map<uint32_t, Op> cur;
+    cur.reserve(p->num_relations);
     auto operand = [&](const bj_gate_index &ix, Op *o) -> bool {
         switch (ix.kind) {
             case BJ_IDX_VARIABLE_POLY:
@@ -167,10 +170,13 @@ int canonicalize(const bj_gate_program *p, Program *out, std::string *err) {
                 if (ix.index >= (1u << 20)) return false;
                 *o = Op{ix.kind, ix.index};
                 return true;
-            case BJ_IDX_TEMPORARY:
-                if (ix.index >= p->num_temporaries || cur[ix.index].kind == K_NONE) return false;
-                *o = cur[ix.index];
+            case BJ_IDX_TEMPORARY: {
+                if (ix.index >= p->num_temporaries) return false;
+                const auto it = cur.find(ix.index);
+                if (it == cur.end()) return false;       // read before any relation wrote it
+                *o = it->second;
                 return true;
+            }
             case BJ_IDX_CONSTANT_VALUE:
                 if (!p->values || ix.index >= p->num_values) return false;
                 *o = Builder::val(f_canon(p->values[ix.index]));
