@@ -219,3 +219,21 @@ def test_a_hosts_own_gate_compiles_at_run_time():
         if rc == -5:
             pytest.skip("hiprtc is not installed here: " + log.value.decode())
         assert rc == 0, log.value.decode()
+
+
+def test_random_malformed_lists_never_crash_the_canonicaliser():
+    """Random relations with out-of-range kinds, operations, temporaries, value indices and column numbers: every list is either
+    accepted (and then has a body) or refused with BJ_ERR_INVALID_ARG — bj_setup_create validates a host's op lists with this."""
+    rnd = random.Random(1)
+    accepted = 0
+    for _ in range(4000):
+        nrel, ntmp, nval = rnd.randrange(0, 12), rnd.randrange(0, 8), rnd.randrange(0, 3)
+        ref = lambda: (rnd.choice([0, 1, 2, 3, 4, 5, 9]), rnd.choice([0, 1, 2, 5, 1 << 19, 1 << 20, (1 << 32) - 1]))
+        rel = [(rnd.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 99]), rnd.randrange(0, 10), ref(), ref()) for _ in range(nrel)]
+        prog = G.GateProgram(rel, [rnd.randrange(1 << 64) for _ in range(nval)], [ref() for _ in range(rnd.randrange(0, 4))], ntmp)
+        prog.struct.num_values = nval
+        rc = lib.bj_gate_program_canonical_info(C.byref(prog.struct), None, None, None, None)
+        assert rc in (0, -1)
+        assert (rc == 0) == (lib.bj_gate_program_emit_body(C.byref(prog.struct), None, 0) > 0)
+        accepted += rc == 0
+    assert 0 < accepted < 4000
