@@ -84,6 +84,7 @@ _SIGNATURES = {
     "bj_proof_size_u64": (C.c_size_t, [C.c_void_p]),
     "bj_proof_serialize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_setup_shape": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bj_setup_dump_info": (C.c_int, [C.c_char_p, C.c_size_t, C.c_void_p]),
     "bj_setup_create_from_dump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_prove_from_dumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),

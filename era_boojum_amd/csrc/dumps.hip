@@ -170,24 +170,56 @@ struct DeviceBlock {
 
 extern "C" {
 
+// SetupBaseStorage bytes -> views into the dump (no copies); num_gates: how many gate indices the selector tree may name
+struct ParsedSetup {
+    PolyVec sig, con, tab;
+    std::vector<uint64_t> ids;
+    TreeWalk walk;
+};
+static bool parse_setup_dump(const void *setup_base, size_t setup_base_len, size_t num_gates, ParsedSetup *out, std::string *err) {
+    Reader r(setup_base, setup_base_len);
+    if (!read_poly_vec(r, &out->sig) || !read_poly_vec(r, &out->con) || !read_poly_vec(r, &out->tab))
+        return (*err = "SetupBaseStorage dump: truncated or ragged polynomial vectors"), false;
+    const uint64_t n_ids = r.u64v();
+    for (uint64_t i = 0; r.ok && i < n_ids && i < 64; i++) out->ids.push_back(r.u64v());
+    if (!r.ok || n_ids > 64) return (*err = "SetupBaseStorage dump: bad table_ids_column_idxes"), false;
+    out->walk.path.resize(num_gates);
+    out->walk.seen.assign(num_gates, 0);
+    std::vector<unsigned char> prefix;
+    if (!read_tree(r, prefix, &out->walk, 0)) return (*err = "SetupBaseStorage dump: " + out->walk.err), false;
+    if (r.p != r.end) return (*err = "SetupBaseStorage dump: " + std::to_string((size_t)(r.end - r.p)) + " trailing bytes"), false;
+    return true;
+}
+
+extern "C" int bj_setup_dump_info(const void *setup_base, size_t setup_base_len, uint64_t *info8) {
+    if (!setup_base || !info8) return BJ_ERR_INVALID_ARG;
+    ParsedSetup P;
+    std::string err;
+    if (!parse_setup_dump(setup_base, setup_base_len, 4096, &P, &err)) return BJ_ERR_INVALID_ARG;
+    size_t gates = 0, longest = 0;
+    for (size_t g = 0; g < P.walk.seen.size(); g++)
+        if (P.walk.seen[g]) {
+            gates = g + 1;
+            if (P.walk.path[g].size() > longest) longest = P.walk.path[g].size();
+        }
+    const uint64_t v[8] = {P.sig.n, P.sig.cols.size(), P.con.cols.size(), P.tab.cols.size(), P.ids.size(), P.ids.empty() ? 0 : P.ids[0],
+                           gates, P.walk.max_degree | ((uint64_t)longest << 32)};
+    memcpy(info8, v, sizeof v);
+    return BJ_OK;
+}
+
 int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void *setup_base, size_t setup_base_len,
                               const bj_proof_config *config, bj_setup **out) {
     if (int rc = bj::bind(ctx)) return rc;
     if (!circuit || !setup_base || !config || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_from_dump: null argument");
-    Reader r(setup_base, setup_base_len);
-    PolyVec sig, con, tab;
-    if (!read_poly_vec(r, &sig) || !read_poly_vec(r, &con) || !read_poly_vec(r, &tab))
-        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "SetupBaseStorage dump: truncated or ragged polynomial vectors");
-    const uint64_t n_ids = r.u64v();
-    std::vector<uint64_t> ids;
-    for (uint64_t i = 0; r.ok && i < n_ids && i < 64; i++) ids.push_back(r.u64v());
-    if (!r.ok || n_ids > 64) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "SetupBaseStorage dump: bad table_ids_column_idxes");
-    TreeWalk walk;
-    walk.path.resize(circuit->num_gates);
-    walk.seen.assign(circuit->num_gates, 0);
-    std::vector<unsigned char> prefix;
-    if (!read_tree(r, prefix, &walk, 0)) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "SetupBaseStorage dump: %s", walk.err.c_str());
-    if (r.p != r.end) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "SetupBaseStorage dump: %zu trailing bytes", (size_t)(r.end - r.p));
+    ParsedSetup P;
+    {
+        std::string err;
+        if (!parse_setup_dump(setup_base, setup_base_len, circuit->num_gates, &P, &err)) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "%s", err.c_str());
+    }
+    PolyVec &sig = P.sig, &con = P.con, &tab = P.tab;
+    std::vector<uint64_t> &ids = P.ids;
+    TreeWalk &walk = P.walk;
     const size_t n = sig.n;
     if (!bj::is_pow2(n) || (size_t)1 << circuit->log_n != n || (!con.cols.empty() && con.n != n) || (!tab.cols.empty() && tab.n != n))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "SetupBaseStorage dump: columns of %zu rows, the circuit says 2^%u", n, circuit->log_n);

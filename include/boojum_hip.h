@@ -492,6 +492,10 @@ int bj_setup_shape(const bj_setup *s, unsigned *log_n, unsigned *num_vars, unsig
  * field is 0 (from the tree's depth + degree), non_residues when the pointer is NULL (make_non_residues, utils.rs:636-688). */
 int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void *setup_base, size_t setup_base_len,
                               const bj_proof_config *config, bj_setup **out);
+/* What a SetupBaseStorage dump holds, without a device: info8 = {rows n, copy-permutation polynomials, constant columns, table
+ * columns, table-id columns, first table-id column, gate indices named by the selector tree (highest + 1), max (depth + degree)
+ * in the low word | longest selector path << 32}.  BJ_ERR_INVALID_ARG for bytes that do not parse.  Host-only. */
+int bj_setup_dump_info(const void *setup_base, size_t setup_base_len, uint64_t *info8);
 /* witness_set_from_witness_vec (witness.rs:386-443) on the device — cell = all_values[hint & (2^48 - 1)], 0 where bit 63 marks a
  * placeholder; multiplicities zero-extended to the trace (witness.rs:225-272); public input values read from their cells — then
  * bj_prove_dev.  witness_hint: the DenseWitnessCopyHint dump (hints/mod.rs:17-21; same layout and indexing) when the circuit has

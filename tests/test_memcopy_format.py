@@ -76,3 +76,42 @@ def test_prover_input_round_trip_of_the_sha256_circuit():
         (c.log_n, c.quotient_degree, c.table_id_col, c.num_constants_for_gates, c.total_tables_len, c.non_residues)
     assert [g.path for g in back.gates] == [g.path for g in c.gates]
     assert check_satisfied(back)
+
+
+def test_the_librarys_reader_agrees_and_survives_mangled_dumps():
+    """csrc/dumps.hip (what bj_setup_create_from_dump parses with) through its host-only entry point bj_setup_dump_info: the shape of
+    a dump written by memcopy_format.write_setup_base, and thousands of truncated / bit-flipped / spliced variants of it — each is
+    either refused or parsed to a shape, never read out of bounds (the reader checks every length against the buffer)."""
+    import ctypes as C
+    import random
+    import era_boojum_amd as E
+    from era_boojum_amd import memcopy_format as M, synthetic as S
+    lib = E.load_library()
+    c = S.sha_shaped_circuit(6, seed=3, table_bits=1)
+    dump = M.write_setup_base(c)
+    info = (C.c_uint64 * 8)()
+    assert lib.bj_setup_dump_info(dump, len(dump), info) == 0
+    n, n_sig, n_con, n_tab, n_ids, id0, gates, deg = list(info)
+    longest = max(len(g.path) for g in c.gates)
+    assert (n, n_sig, n_con, n_tab, n_ids, id0) == (c.n, c.num_vars, c.num_constant_cols, c.lookup_width + 1, 1, c.table_id_col)
+    assert gates == len(c.gates) and deg >> 32 == longest and (deg & 0xFFFFFFFF) == max(len(g.path) + g.degree for g in c.gates)
+    rnd = random.Random(7)
+    refused = 0
+    for _ in range(3000):
+        b = bytearray(dump)
+        kind = rnd.randrange(4)
+        if kind == 0:
+            b = b[:rnd.randrange(len(b))]
+        elif kind == 1:
+            for _ in range(rnd.randrange(1, 4)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            i = rnd.randrange(len(b) - 8)
+            b[i:i + 8] = rnd.choice([(1 << 64) - 1, 1 << 40, 0, len(b)]).to_bytes(8, "little")      # a hostile length field
+        else:
+            i, j = sorted(rnd.randrange(len(b)) for _ in range(2))
+            b = b[:i] + b[j:]
+        rc = lib.bj_setup_dump_info(bytes(b), len(b), info)
+        assert rc in (0, -1)
+        refused += rc != 0
+    assert refused > 1000
