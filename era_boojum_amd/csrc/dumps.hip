@@ -284,10 +284,12 @@ int bj_prove_from_dumps(bj_ctx *ctx, const bj_setup *setup, const void *witness_
         pub_col[i] = w.u64v();
         pub_row[i] = w.u64v();
     }
-    const uint64_t n_values = w.u64v();
-    const unsigned char *values = w.ok ? w.skip((size_t)n_values * 8) : nullptr;
+    const uint64_t n_values = w.u64v();      // lengths come from the dump: bound them by what is left of it before multiplying
+    const unsigned char *values = (w.ok && n_values <= (size_t)(w.end - w.p) / 8) ? w.skip((size_t)n_values * 8) : nullptr;
+    if (!values) w.ok = false;
     const uint64_t n_mult = w.u64v();
-    const unsigned char *mult = w.ok ? w.skip((size_t)n_mult * 4) : nullptr;
+    const unsigned char *mult = (w.ok && n_mult <= (size_t)(w.end - w.p) / 4) ? w.skip((size_t)n_mult * 4) : nullptr;
+    if (!mult) w.ok = false;
     if (!w.ok || !values || (n_mult && !mult) || w.p != w.end)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "WitnessVec dump: truncated or trailing bytes");
     if (n_mult > n) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "WitnessVec dump: %llu multiplicities for %zu rows", (unsigned long long)n_mult, n);
