@@ -307,12 +307,13 @@ class Context:
                                                     _np_ptr(nr), num_vars, chunk, log_n, log_lde, _np_ptr(self._e2(beta)),
                                                     _np_ptr(self._e2(gamma)), _np_ptr(al), num_points, first_point, d_out0, d_out1))
 
-    FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_lazy": 3, "square": 4, "inverse": 5, "ext2_mul": 6, "butterfly": 7, "addsub": 8}
+    FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_lazy": 3, "square": 4, "inverse": 5, "ext2_mul": 6, "butterfly": 7, "addsub": 8,
+                 "add_lazy": 9, "sub_lazy": 10, "ext2_mul_lazy": 11}
 
     def field_op(self, op, a, b=None):
         """bj_field_op_batch on host arrays (uploads, runs, downloads): elementwise Goldilocks / F_p^2 operators."""
         a = np.ascontiguousarray(a, dtype=np.uint64)
-        n = a.size // 2 if op in ("ext2_mul", "butterfly", "addsub") else a.size
+        n = a.size // 2 if op in ("ext2_mul", "ext2_mul_lazy", "butterfly", "addsub") else a.size
         da = self.upload(a)
         db = self.upload(np.ascontiguousarray(b, dtype=np.uint64)) if b is not None else None
         do = self.malloc(a.nbytes)

@@ -425,7 +425,7 @@ int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsi
 int bj_field_op_batch(bj_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n) {
     if (int rc = bind(ctx)) return rc;
     if (n == 0) return BJ_OK;
-    if (op < BJ_FIELD_ADD || op > BJ_FIELD_ADDSUB) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_field_op_batch: unknown operator");
+    if (op < BJ_FIELD_ADD || op > BJ_FIELD_EXT2_MUL_LAZY) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_field_op_batch: unknown operator");
     if ((op == BJ_FIELD_BUTTERFLY || op == BJ_FIELD_ADDSUB) && (n & 1))
         return fail(ctx, BJ_ERR_INVALID_ARG, "bj_field_op_batch: the butterfly operators take an even number of pairs");
     const bool unary = op == BJ_FIELD_SQUARE || op == BJ_FIELD_INVERSE || op == BJ_FIELD_ADDSUB;

@@ -218,6 +218,29 @@ __host__ __device__ __forceinline__ u64 mul(u64 a, u64 b) {
 }
 __host__ __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 
+// Sums and differences of WEAK residues (any u64 in, any u64 congruent to the result out): what the product chains of the
+// copy-permutation quotient run between their weak products, so that nothing is canonicalised inside a 184-product chain.
+//   a + b wraps 2^64 -> + EPS (= 2^64 mod p); that can wrap once more only when both operands are within 2^32 of 2^64, and
+//   then the result is below 2^32 and takes the second EPS without a third wrap.  Same with borrows for a - b.
+__host__ __device__ __forceinline__ u64 add_weak(u64 a, u64 b) {
+    u32 c1, c2, c3, c4;
+    u32 s0 = __builtin_addc(lo32(a), lo32(b), 0u, &c1);
+    u32 s1 = __builtin_addc(hi32(a), hi32(b), c1, &c2);
+    s0 = __builtin_addc(s0, c2 ? 0xFFFFFFFFu : 0u, 0u, &c3);
+    s1 = __builtin_addc(s1, 0u, c3, &c4);
+    const u64 r = pack(s0, s1);
+    return c4 ? r + EPS : r;
+}
+__host__ __device__ __forceinline__ u64 sub_weak(u64 a, u64 b) {
+    u32 b1, b2, b3, b4;
+    u32 d0 = __builtin_subc(lo32(a), lo32(b), 0u, &b1);
+    u32 d1 = __builtin_subc(hi32(a), hi32(b), b1, &b2);
+    d0 = __builtin_subc(d0, b2 ? 0xFFFFFFFFu : 0u, 0u, &b3);   // borrowed 2^64 = p + EPS: take EPS off again
+    d1 = __builtin_subc(d1, 0u, b3, &b4);
+    const u64 r = pack(d0, d1);
+    return b4 ? r - EPS : r;                                    // second borrow: the value was within 2^32 of 0 from below
+}
+
 }  // namespace gl
 #include "gl_asm.inc"   // generated: butterfly2_weak_asm, addsub2_weak_asm (tools/gen_gl_asm.py)
 namespace gl {
@@ -309,6 +332,12 @@ __host__ __device__ __forceinline__ e2 e2_mul(e2 a, e2 b) {  // Karatsuba, field
     u64 c1 = sub(sub(mul(add(a.c0, a.c1), add(b.c0, b.c1)), v0), v1);
     u64 seven_v1 = sub(mul_pow2(v1, 3), v1);
     return {add(v0, seven_v1), c1};
+}
+// the same product on weak residues, schoolbook: four weak products, two weak sums, 7 * a1 b1 as a fifth product — no
+// canonicalisation anywhere (Karatsuba's three products cost five canonical additions / subtractions on this VALU)
+__host__ __device__ __forceinline__ e2 e2_mul_weak(e2 a, e2 b) {
+    const u64 v1 = mul_weak(a.c1, b.c1);
+    return {add_weak(mul_weak(a.c0, b.c0), mul_weak(v1, 7)), add_weak(mul_weak(a.c0, b.c1), mul_weak(a.c1, b.c0))};
 }
 __host__ __device__ __forceinline__ e2 e2_sqr(e2 a) { return e2_mul(a, a); }
 __host__ __device__ __forceinline__ e2 e2_mul_base(e2 a, u64 s) { return {mul(a.c0, s), mul(a.c1, s)}; }

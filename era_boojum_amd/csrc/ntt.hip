@@ -443,7 +443,7 @@ void launch_canonicalize(u64 *d, size_t n, hipStream_t s) {
 
 // elementwise field operators on arbitrary u64 inputs (row a1/a2 of SURVEY §8 at operator level; field/goldilocks/mod.rs:188-255,
 // field/traits/field.rs:407-512); op: 0 add, 1 sub, 2 mul, 3 mul through the weak (lazy) product of the hash kernels,
-// 4 square, 5 inverse (0 -> 0), 6 F_p^2 multiplication on (a0,a1) x (b0,b1) with the second halves at +n,
+// 4 square, 5 inverse (0 -> 0), 9 / 10 weak sum / difference of the raw words, 11 weak F_p^2 product, 6 F_p^2 multiplication on (a0,a1) x (b0,b1) with the second halves at +n,
 // 7 the NTT butterfly (u, v) <- (u + v*w, u - v*w) with a = [u | v], b = w, 8 the same with w = 1
 __global__ void field_op_kernel(int op, const u64 *a, const u64 *b, u64 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -453,6 +453,12 @@ __global__ void field_op_kernel(int op, const u64 *a, const u64 *b, u64 *out, si
         gl::e2 r = gl::e2_mul(x, y);
         out[i] = r.c0;
         out[n + i] = r.c1;
+        return;
+    }
+    if (op == 11) {   // the same product on the RAW words (weak residues in, nothing canonicalised before the store)
+        const gl::e2 r = gl::e2_mul_weak(gl::e2{a[i], a[n + i]}, gl::e2{b[i], b[n + i]});
+        out[i] = gl::canon(r.c0);
+        out[n + i] = gl::canon(r.c1);
         return;
     }
     if (op == 7 || op == 8) {   // two lazy butterflies per thread, exactly as the NTT kernels run them (n even)
@@ -474,6 +480,8 @@ __global__ void field_op_kernel(int op, const u64 *a, const u64 *b, u64 *out, si
     case 2: r = gl::mul(x, y); break;
     case 3: r = gl::canon(gl::mul_weak(x, y)); break;
     case 4: r = gl::sqr(x); break;
+    case 9: r = gl::canon(gl::add_weak(x, y)); break;
+    case 10: r = gl::canon(gl::sub_weak(x, y)); break;
     default: r = gl::inv(gl::canon(x)); break;
     }
     out[i] = r;

@@ -221,22 +221,22 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     // z(omega * x): next natural index inside the coset
     const u32 i_next = gl::bitrev32((gl::bitrev32(i_br, log_n) + 1) & (u32)(n - 1), log_n);
     const size_t In = (I - i_br) + i_next;
-    const gl::e2 z_shift{gl::canon(stage2[In]), gl::canon(stage2[s2_stride + In])};
+    const gl::e2 z_shift{stage2[In], stage2[s2_stride + In]};
+    // The two product chains of a chunk run on WEAK residues (gl::mul_weak / add_weak: any u64 congruent to the value): raw
+    // words from memory in, nothing canonicalised until the lazy accumulators take lhs - rhs — a chain link is four weak
+    // products and two weak sums per F_p^2 factor instead of Karatsuba's three canonical products and five canonical sums.
     for (unsigned j = 0; j < n_chunks; j++) {
-        gl::e2 lhs = (j + 1 < n_chunks)
-                         ? gl::e2{gl::canon(stage2[((size_t)2 + 2 * j) * s2_stride + I]), gl::canon(stage2[((size_t)3 + 2 * j) * s2_stride + I])}
-                         : z_shift;
-        gl::e2 rhs = (j == 0) ? zv
-                              : gl::e2{gl::canon(stage2[((size_t)2 * j) * s2_stride + I]), gl::canon(stage2[((size_t)2 * j + 1) * s2_stride + I])};
+        gl::e2 lhs = (j + 1 < n_chunks) ? gl::e2{stage2[((size_t)2 + 2 * j) * s2_stride + I], stage2[((size_t)3 + 2 * j) * s2_stride + I]} : z_shift;
+        gl::e2 rhs = (j == 0) ? zv : gl::e2{stage2[((size_t)2 * j) * s2_stride + I], stage2[((size_t)2 * j + 1) * s2_stride + I]};
         for (unsigned c = j * chunk; c < (j + 1) * chunk && c < V; c++) {
-            const u64 wg = gl::add(gl::canon(vars[(size_t)c * var_stride + I]), ca.gamma.c0);   // w + gamma_0, shared by both factors
-            u64 sg = gl::canon(sigmas[(size_t)c * sig_stride + I]);
-            gl::e2 d{gl::add(gl::mul(sg, ca.beta.c0), wg), gl::add(gl::mul(sg, ca.beta.c1), ca.gamma.c1)};
-            lhs = gl::e2_mul(lhs, d);
-            gl::e2 nm{gl::add(gl::mul(x, kbeta[2 * c]), wg), gl::add(gl::mul(x, kbeta[2 * c + 1]), ca.gamma.c1)};
-            rhs = gl::e2_mul(rhs, nm);
+            const u64 wg = gl::add_weak(vars[(size_t)c * var_stride + I], ca.gamma.c0);   // w + gamma_0, shared by both factors
+            const u64 sg = sigmas[(size_t)c * sig_stride + I];
+            const gl::e2 d{gl::add_weak(gl::mul_weak(sg, ca.beta.c0), wg), gl::add_weak(gl::mul_weak(sg, ca.beta.c1), ca.gamma.c1)};
+            lhs = gl::e2_mul_weak(lhs, d);
+            const gl::e2 nm{gl::add_weak(gl::mul_weak(x, kbeta[2 * c]), wg), gl::add_weak(gl::mul_weak(x, kbeta[2 * c + 1]), ca.gamma.c1)};
+            rhs = gl::e2_mul_weak(rhs, nm);
         }
-        gl::e2 t = gl::e2_sub(lhs, rhs);
+        const gl::e2 t{gl::sub_weak(lhs.c0, rhs.c0), gl::sub_weak(lhs.c1, rhs.c1)};
         const u64 a0 = alphas[2 * j], a1 = alphas[2 * j + 1];
         s0.fma(t.c0, a0);
         s0.fma(t.c1, mul7q(a1));

@@ -62,14 +62,22 @@ copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
         for (int k = 0; k < RAT_PTS; k++) {
             const size_t r = base + (size_t)k * 256;
             if (r >= n) continue;
-            u64 w = gl::canon(vars[(size_t)i * var_stride + r]);
-            u64 kx = gl::mul(kr, x[k]);
-            gl::e2 a{gl::add(gl::add(gl::mul(kx, beta.c0), w), gamma.c0), gl::add(gl::mul(kx, beta.c1), gamma.c1)};
-            u64 s = gl::canon(sigmas[(size_t)i * sig_stride + r]);
-            gl::e2 b{gl::add(gl::add(gl::mul(s, beta.c0), w), gamma.c0), gl::add(gl::mul(s, beta.c1), gamma.c1)};
-            num[k] = gl::e2_mul(num[k], a);
-            den[k] = gl::e2_mul(den[k], b);
+            // weak residues throughout (any 64-bit representative; see gl::mul_weak): the running products are made canonical
+            // once, after the last column, instead of after every operation
+            const u64 w = vars[(size_t)i * var_stride + r];
+            const u64 wg = gl::add_weak(w, gamma.c0);
+            const u64 kx = gl::mul_weak(kr, x[k]);
+            const gl::e2 a{gl::add_weak(gl::mul_weak(kx, beta.c0), wg), gl::add_weak(gl::mul_weak(kx, beta.c1), gamma.c1)};
+            const u64 s = sigmas[(size_t)i * sig_stride + r];
+            const gl::e2 b{gl::add_weak(gl::mul_weak(s, beta.c0), wg), gl::add_weak(gl::mul_weak(s, beta.c1), gamma.c1)};
+            num[k] = gl::e2_mul_weak(num[k], a);
+            den[k] = gl::e2_mul_weak(den[k], b);
         }
+    }
+#pragma unroll
+    for (int k = 0; k < RAT_PTS; k++) {
+        num[k] = {gl::canon(num[k].c0), gl::canon(num[k].c1)};
+        den[k] = {gl::canon(den[k].c0), gl::canon(den[k].c1)};
     }
     // 1/den[k] for all k from one inversion: pre[k] = den[0..k-1], inv(all) walked back
     gl::e2 pre[RAT_PTS], run{1, 0};

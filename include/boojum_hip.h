@@ -124,7 +124,10 @@ enum { BJ_FIELD_ADD = 0, BJ_FIELD_SUB = 1, BJ_FIELD_MUL = 2, BJ_FIELD_MUL_LAZY =
        BJ_FIELD_EXT2_MUL = 6,
        BJ_FIELD_BUTTERFLY = 7, /* the radix-2 butterfly of serial_ct_ntt (src/fft/mod.rs:659-734) as the NTT kernels run it: d_a = [u | v]
                                 * (second half at +n), d_b = w;  out = [u + v*w | u - v*w]; n even */
-       BJ_FIELD_ADDSUB = 8     /* the same with twiddle 1: d_a = [u | v], d_b unused; out = [u + v | u - v] */ };
+       BJ_FIELD_ADDSUB = 8,    /* the same with twiddle 1: d_a = [u | v], d_b unused; out = [u + v | u - v] */
+       BJ_FIELD_ADD_LAZY = 9, BJ_FIELD_SUB_LAZY = 10, /* sum / difference of the RAW words as weak residues (what the quotient's product
+                                * chains run between their weak products), canonicalised only for the store */
+       BJ_FIELD_EXT2_MUL_LAZY = 11 /* the F_p^2 product on weak residues: raw words in (second halves at +n) */ };
 int bj_field_op_batch(bj_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
 
 /* Host-memory convenience for single-polynomial plumbing (what a Rust `impl PrimeFieldLikeVectorized` would call);

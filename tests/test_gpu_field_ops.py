@@ -126,3 +126,27 @@ def test_lazy_ntt_butterflies_match_python_integers():
         uu, vv, ww = np.full(2, u[i]), np.full(2, v[i]), np.full(2, w[i])
         g = ctx().field_op("butterfly", np.stack([uu, vv]), ww)
         assert int(g[0][0]) == (int(u[i]) + int(v[i]) * int(w[i])) % P and int(g[1][1]) == (int(u[i]) - int(v[i]) * int(w[i])) % P
+
+
+def test_weak_sum_difference_and_extension_product_on_extreme_words():
+    """gl::add_weak / sub_weak / e2_mul_weak (the links of the copy-permutation quotient's product chains) take ANY u64 and never
+    canonicalise in between: all pairs of the words around 0, 2^32, p and 2^64 — where the first and the second wrap of a sum or
+    a borrow of a difference happen — and random words, against Python integers."""
+    edge = [0, 1, 2, (1 << 32) - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, P - 2, P - 1, P, P + 1, (1 << 64) - (1 << 32) - 1,
+            (1 << 64) - (1 << 32), (1 << 64) - (1 << 32) + 2, (1 << 64) - 2, (1 << 64) - 1, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF00000000]
+    rng = np.random.default_rng(7)
+    a = np.array([x for x in edge for _ in edge] + [int(v) for v in rng.integers(0, 1 << 64, 4096, dtype=np.uint64)], dtype=np.uint64)
+    b = np.array([y for _ in edge for y in edge] + [int(v) for v in rng.integers(0, 1 << 64, 4096, dtype=np.uint64)], dtype=np.uint64)
+    for op, f in (("add_lazy", lambda x, y: (x + y) % P), ("sub_lazy", lambda x, y: (x - y) % P)):
+        got = ctx().field_op(op, a, b)
+        assert [int(v) for v in got] == [f(int(x), int(y)) for x, y in zip(a, b)], op
+    # F_p^2: (a0, a1) x (b0, b1), halves at +m; every combination of edge words in the four slots would be 19^4: sample them
+    m = 6000
+    pick = lambda: np.array([edge[int(i)] if k < 0.7 else int(r) for i, k, r in zip(rng.integers(0, len(edge), m), rng.random(m),
+                                                                                     rng.integers(0, 1 << 64, m, dtype=np.uint64))], dtype=np.uint64)
+    x = np.concatenate([pick(), pick()])
+    y = np.concatenate([pick(), pick()])
+    got = ctx().field_op("ext2_mul_lazy", x, y).reshape(2, m)
+    for i in range(m):
+        a0, a1, b0, b1 = int(x[i]), int(x[m + i]), int(y[i]), int(y[m + i])
+        assert (int(got[0, i]), int(got[1, i])) == ((a0 * b0 + 7 * a1 * b1) % P, (a0 * b1 + a1 * b0) % P), i
