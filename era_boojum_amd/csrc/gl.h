@@ -240,6 +240,15 @@ __host__ __device__ __forceinline__ u64 sub_weak(u64 a, u64 b) {
     const u64 r = pack(d0, d1);
     return b4 ? r - EPS : r;                                    // second borrow: the value was within 2^32 of 0 from below
 }
+// 7 * a on weak residues (the non-residue of F_p^2): the 67-bit product folded with 2^64 = EPS — three multiply-adds and a
+// carry fix instead of a full product
+__host__ __device__ __forceinline__ u64 mul7_weak(u64 a) {
+    const u64 lo = (u64)lo32(a) * 7u;
+    const u64 hi = (u64)hi32(a) * 7u + hi32(lo);       // 7 a = lo32(lo) + hi * 2^32,  hi < 7 * 2^32
+    const u64 t = (u64)hi32(hi) * EPS;                 // the bits above 2^64 (at most 6), times 2^64 mod p
+    const u64 s = pack(lo32(lo), lo32(hi)) + t;
+    return s < t ? s + EPS : s;                        // wrapped: s < 2^35 now, the second EPS cannot wrap
+}
 
 }  // namespace gl
 #include "gl_asm.inc"   // generated: butterfly2_weak_asm, addsub2_weak_asm (tools/gen_gl_asm.py)
@@ -333,11 +342,11 @@ __host__ __device__ __forceinline__ e2 e2_mul(e2 a, e2 b) {  // Karatsuba, field
     u64 seven_v1 = sub(mul_pow2(v1, 3), v1);
     return {add(v0, seven_v1), c1};
 }
-// the same product on weak residues, schoolbook: four weak products, two weak sums, 7 * a1 b1 as a fifth product — no
+// the same product on weak residues, schoolbook: four weak products, two weak sums, 7 * a1 b1 through mul7_weak — no
 // canonicalisation anywhere (Karatsuba's three products cost five canonical additions / subtractions on this VALU)
 __host__ __device__ __forceinline__ e2 e2_mul_weak(e2 a, e2 b) {
     const u64 v1 = mul_weak(a.c1, b.c1);
-    return {add_weak(mul_weak(a.c0, b.c0), mul_weak(v1, 7)), add_weak(mul_weak(a.c0, b.c1), mul_weak(a.c1, b.c0))};
+    return {add_weak(mul_weak(a.c0, b.c0), mul7_weak(v1)), add_weak(mul_weak(a.c0, b.c1), mul_weak(a.c1, b.c0))};
 }
 __host__ __device__ __forceinline__ e2 e2_sqr(e2 a) { return e2_mul(a, a); }
 __host__ __device__ __forceinline__ e2 e2_mul_base(e2 a, u64 s) { return {mul(a.c0, s), mul(a.c1, s)}; }

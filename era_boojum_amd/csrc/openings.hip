@@ -121,50 +121,75 @@ void launch_barycentric_weights(u64 *d_w0, u64 *d_w1, const u64 *d_tw_fwd, unsig
 // ---------------------------------------------------------------------------------------------------------
 // barycentric evaluation of a batch of base columns:  partial[col][block] = sum over the block's points of f * w
 // ---------------------------------------------------------------------------------------------------------
-static constexpr int BARY_PTS = 8;    // points per thread
+static constexpr int BARY_PTS = 32;   // points per lane: a workgroup covers 256 * BARY_PTS consecutive points
+static constexpr int BARY_STEP = 4;   // points in flight per column
 static constexpr int BARY_COLS = 8;   // columns sharing one read of the weights
 
+// A lane walks its BARY_PTS points four at a time and keeps one 160-bit accumulator pair per column for the whole walk: the
+// weights are read once per eight columns, and the cross-lane reduction — the larger half of this kernel when it ran after
+// every eight points of every column — happens once per workgroup, for all sixteen sums together, through a transposed LDS tree.
 __global__ void __launch_bounds__(256)
 barycentric_partial_kernel(const u64 *const *cols, unsigned n_cols, size_t n, const u64 *w0, const u64 *w1,
                            u64 *partials, unsigned n_blocks) {
-    __shared__ u64 red[2][256];
+    __shared__ u64 red[2 * BARY_COLS][256 + 1];
     const unsigned t = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * (256 * BARY_PTS) + t;
-    u64 a[BARY_PTS], b[BARY_PTS];
-#pragma unroll
-    for (int k = 0; k < BARY_PTS; k++) {
-        size_t i = base + (size_t)k * 256;
-        a[k] = i < n ? w0[i] : 0;
-        b[k] = i < n ? w1[i] : 0;
-    }
     const unsigned c0 = blockIdx.y * BARY_COLS;
-    for (unsigned c = c0; c < c0 + BARY_COLS && c < n_cols; c++) {
-        const u64 *f = cols[c];
-        Acc160 s0, s1;
-        s0.clear();
-        s1.clear();
+    const u64 *f[BARY_COLS];
 #pragma unroll
-        for (int k = 0; k < BARY_PTS; k++) {
-            size_t i = base + (size_t)k * 256;
-            u64 v = i < n ? f[i] : 0;
-            s0.fma(v, a[k]);
-            s1.fma(v, b[k]);
+    for (int c = 0; c < BARY_COLS; c++) f[c] = cols[c0 + c < n_cols ? c0 + c : c0];   // a short last group re-reads its first column; the surplus sums are dropped
+    Acc160 s0[BARY_COLS], s1[BARY_COLS];
+#pragma unroll
+    for (int c = 0; c < BARY_COLS; c++) {
+        s0[c].clear();
+        s1[c].clear();
+    }
+#pragma unroll 1
+    for (int k0 = 0; k0 < BARY_PTS; k0 += BARY_STEP) {
+        u64 a[BARY_STEP], b[BARY_STEP];
+#pragma unroll
+        for (int k = 0; k < BARY_STEP; k++) {   // past the end: a zero weight on a clamped (valid) index — no divergent loads
+            const size_t i = base + (size_t)(k0 + k) * 256;
+            const size_t ic = i < n ? i : n - 1;
+            const u64 wa = w0[ic], wb = w1[ic];
+            a[k] = i < n ? wa : 0;
+            b[k] = i < n ? wb : 0;
         }
-        red[0][t] = s0.reduce();
-        red[1][t] = s1.reduce();
-        __syncthreads();
-        for (unsigned stride = 128; stride > 0; stride >>= 1) {
-            if (t < stride) {
-                red[0][t] = gl::add(red[0][t], red[0][t + stride]);
-                red[1][t] = gl::add(red[1][t], red[1][t + stride]);
+#pragma unroll
+        for (int c = 0; c < BARY_COLS; c++) {
+            u64 v[BARY_STEP];
+#pragma unroll
+            for (int k = 0; k < BARY_STEP; k++) {
+                const size_t i = base + (size_t)(k0 + k) * 256;
+                v[k] = f[c][i < n ? i : n - 1];
             }
-            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BARY_STEP; k++) {
+                s0[c].fma(v[k], a[k]);
+                s1[c].fma(v[k], b[k]);
+            }
         }
-        if (t == 0) {
-            partials[((size_t)c * n_blocks + blockIdx.x) * 2 + 0] = red[0][0];
-            partials[((size_t)c * n_blocks + blockIdx.x) * 2 + 1] = red[1][0];
-        }
+    }
+#pragma unroll
+    for (int c = 0; c < BARY_COLS; c++) {
+        red[2 * c][t] = s0[c].reduce();
+        red[2 * c + 1][t] = s1[c].reduce();
+    }
+    __syncthreads();
+    {   // lane t: sum j = t & 15, the sixteen lanes' values of segment t >> 4; then sixteen lanes add the segments
+        const unsigned j = t & 15, seg = t >> 4;
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc = gl::add(acc, red[j][seg * 16 + k]);
         __syncthreads();
+        red[j][seg] = acc;
+        __syncthreads();
+        if (t < 2 * BARY_COLS && c0 + (t >> 1) < n_cols) {
+            u64 tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) tot = gl::add(tot, red[t][k]);
+            partials[((size_t)(c0 + (t >> 1)) * n_blocks + blockIdx.x) * 2 + (t & 1)] = tot;
+        }
     }
 }
 

@@ -38,8 +38,9 @@ void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_
 void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
                                unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
-                               const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, u64 *d_out0,
+                               const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, const u64 *d_inv_xm1, u64 *d_out0,
                                u64 *d_out1, hipStream_t s);
+void launch_inv_x_minus_one(const u64 *d_tw_fwd, size_t Q, size_t I0, u64 *d_out, hipStream_t s);
 void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, const u64 *d_idx, unsigned n_idx,
                         u64 *d_out, hipStream_t s);
 void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, const u64 *d_idx, unsigned n_idx,
@@ -89,6 +90,7 @@ struct bj_setup {
     u64 *d_lde = nullptr;          // [n_cols][cl][n]
     u64 *d_tree = nullptr;         // local subtree
     u64 *d_non_res = nullptr;
+    u64 *d_inv_xm1 = nullptr;      // 1 / (x - 1) on the points this GPU evaluates the quotient on (a property of the domain)
     std::vector<u64> cap;
 };
 
@@ -220,6 +222,7 @@ void bj_setup_destroy(bj_setup *s) {
     if (s->d_lde) (void)hipFree(s->d_lde);
     if (s->d_tree) (void)hipFree(s->d_tree);
     if (s->d_non_res) (void)hipFree(s->d_non_res);
+    if (s->d_inv_xm1) (void)hipFree(s->d_inv_xm1);
     for (auto &p : s->programs) p.release();
     for (auto &g : s->spec) g.program.release();
     delete s;
@@ -436,6 +439,16 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         if (!rc) rc = bj_lde_cosets_batch(ctx, s->d_mono, n, s->d_lde, s->log_n, s->n_cols, s->log_L, s->c0, s->cl);
         if (!rc) rc = bj_sync(ctx);
         if (rc) return bail(rc);
+    }
+    {   // the points the quotient is evaluated on here (prove_impl: Qe, I0) and 1 / (x - 1) on them, for the L_1 term
+        const size_t Qe = s->cl >= s->q ? n * s->q : (s->c0 < s->q ? s->Ls : 0);
+        if (Qe) {
+            if ((rc = bj::ensure_twiddles(ctx, s->log_n + s->log_L, false))) return bail(rc);
+            if (hipMalloc((void **)&s->d_inv_xm1, Qe * 8) != hipSuccess)
+                return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: device allocation failed"));
+            bj::launch_inv_x_minus_one(ctx->tw_fwd, Qe, (size_t)s->c0 * n, s->d_inv_xm1, ctx->stream);
+            if (hipGetLastError() != hipSuccess) return bail(bj::fail(ctx, BJ_ERR_HIP, "bj_setup_create: launch failed"));
+        }
     }
     if (hipMalloc((void **)&s->d_tree, bj_merkle_tree_digests(s->Nl, s->cap_l) * 32) != hipSuccess)
         return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: tree allocation failed"));
@@ -784,7 +797,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     }
     if (Qe)
         bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_L, ctx->tw_fwd,
-                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_spec_terms + n_gate_terms), a_l1 + 2, Qe, I0, t0, t1, st);
+                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_spec_terms + n_gate_terms), a_l1 + 2, Qe, I0, S->d_inv_xm1, t0, t1, st);
     BJ_CHECK_LAUNCH(ctx);
     u64 q_shift = gl::GEN;   // coset the gathered evaluations live on
     if (q_local) {

@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(256)
 quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas, size_t sig_stride, const u64 *stage2,
                           size_t s2_stride, const u64 *non_res, unsigned V, unsigned chunk, unsigned n_chunks,
                           unsigned log_n, const u64 *tw, CopyPermQArgs ca, const u64 *alphas /* [n_chunks][2] */,
-                          size_t Q, size_t I0 /* global index of local point 0 (multi-GPU coset shards) */, u64 *out0,
-                          u64 *out1) {
+                          size_t Q, size_t I0 /* global index of local point 0 (multi-GPU coset shards) */,
+                          const u64 *inv_xm1 /* 1 / (x_I - 1) per local point, or NULL: computed here */, u64 *out0, u64 *out1) {
     // k_c * beta for every column, once per workgroup (a lane would otherwise spend a product per column on k_c * x first)
     extern __shared__ u64 kbeta[];   // [V][2], sized by the launcher
     for (unsigned t = threadIdx.x; t < 2 * V; t += blockDim.x)
@@ -211,7 +211,7 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     s1.clear();
     const gl::e2 zv{gl::canon(stage2[I]), gl::canon(stage2[s2_stride + I])};
     {   // (z - 1) * (x^n - 1) / (x - 1) * alpha
-        u64 l1 = gl::mul(ca.xn_minus_one[coset], inv_chain3(gl::sub(x, 1)));
+        u64 l1 = gl::mul(ca.xn_minus_one[coset], inv_xm1 ? inv_xm1[I] : inv_chain3(gl::sub(x, 1)));
         gl::e2 t{gl::mul(gl::sub(zv.c0, 1), l1), gl::mul(zv.c1, l1)};
         s0.fma(t.c0, ca.alpha_l1.c0);
         s0.fma(t.c1, mul7q(ca.alpha_l1.c1));
@@ -250,7 +250,18 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     out1[I] = gl::mul(r1, vi);
 }
 
+// 1 / (x_I - 1) for the points I0 .. I0 + Q of the LDE domain: depends on the domain only, so a setup computes it once (the
+// fixed exponentiation is ~75 products per point, 3 % of quotient_copy_perm's arithmetic at 92 columns)
+__global__ void __launch_bounds__(256) inv_x_minus_one_kernel(const u64 *tw, size_t Q, size_t I0, u64 *out) {
+    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I < Q) out[I] = inv_chain3(gl::sub(lde_point(tw, I0 + I), 1));
+}
+
 // ----------------------------------------------------------------------------------------------- launchers
+void launch_inv_x_minus_one(const u64 *d_tw_fwd, size_t Q, size_t I0, u64 *d_out, hipStream_t s) {
+    if (Q) hipLaunchKernelGGL(inv_x_minus_one_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_tw_fwd, Q, I0, d_out);
+}
+
 void launch_quotient_gates(const u64 *d_vars, size_t var_stride, const u64 *d_consts, size_t const_stride,
                            const int *h_gates_flat /* 12 ints per gate */, unsigned n_gates, const u64 *d_alphas,
                            size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s) {
@@ -281,7 +292,7 @@ void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_
 void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
                                unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
-                               const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, u64 *d_out0,
+                               const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, const u64 *d_inv_xm1, u64 *d_out0,
                                u64 *d_out1, hipStream_t s) {
     const size_t n = (size_t)1 << log_n, Q = Q_local;
     const unsigned L = 1u << log_L;   // cosets of the whole LDE domain; a GPU may hold any contiguous range of them
@@ -305,7 +316,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
     const unsigned n_chunks = (V + chunk - 1) / chunk;
     hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 16, s, d_vars, var_stride,
                        d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
-                       d_alphas_cp, Q, I0, d_out0, d_out1);
+                       d_alphas_cp, Q, I0, d_inv_xm1, d_out0, d_out1);
 }
 
 // ----------------------------------------------------------------------------------------------- query gathers

@@ -106,13 +106,22 @@ def test_hip_proof_at_2p20_rows_equals_oracle_proof_under_both_bench_transcripts
 
 
 def _host_ram_gb():
+    """Memory this process may actually use: MemAvailable, capped by the container's cgroup limit where there is one."""
+    avail = 0.0
     try:
         for line in open("/proc/meminfo"):
             if line.startswith("MemAvailable:"):
-                return int(line.split()[1]) / 1e6
+                avail = int(line.split()[1]) / 1e6
     except OSError:
-        pass
-    return 0.0
+        return 0.0
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            text = open(path).read().strip()
+        except OSError:
+            continue
+        if text.isdigit():
+            avail = min(avail, int(text) / 1e9)
+    return avail
 
 
 def test_hip_proof_at_2p22_rows_equals_the_oracle():
