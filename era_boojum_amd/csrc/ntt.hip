@@ -392,28 +392,41 @@ __global__ void bitrev_scale_kernel(const u64 *in, u64 *out, unsigned log_n, siz
 // fixed mid the 32 x 32 elements {(h, l)} are read as 32 runs of 32 consecutive words (row r = rev(l), column c = rev(h))
 // and written as 32 runs of 32 consecutive words (row h, column l): both sides of the permutation are 256-byte runs, the
 // transposition happens in LDS (row stride 33: conflict-free).  The gather above reads one word per 128-byte line.
+// The factor scale * step^i of a coset transform splits along the same three index fields: scale * step^(h << (log_n - 5)) and
+// step^l come from the host (64 words of kernel arguments), step^(32 mid) is one exponentiation per workgroup — two products
+// per element where a per-element power cost ~45 (the quotient's 2 x 2^24 inverse transform: 695 -> ~90 us).
+struct BitrevPowers {
+    u64 hi[32];      // scale * step^(h << (log_n - 5))
+    u64 lo[32];      // step^l
+    u64 step32;      // step^32
+};
 __global__ void __launch_bounds__(256)
 bitrev_scale_tiled_kernel(const u64 *in, u64 *out, unsigned log_n, size_t in_col_stride, size_t out_col_stride, u64 scale,
-                          u64 step) {
+                          int stepped, BitrevPowers pw) {
     __shared__ u64 tile[32][33];
+    __shared__ u64 pw_mid;
     const unsigned mid_bits = log_n - 10;
     const u32 mid = blockIdx.x, rmid = gl::bitrev32(mid, mid_bits);
     const u64 *src = in + (size_t)blockIdx.y * in_col_stride;
     u64 *dst = out + (size_t)blockIdx.y * out_col_stride;
     const unsigned c = threadIdx.x & 31, r0 = threadIdx.x >> 5;       // 8 rows per sweep
+    if (stepped && threadIdx.x == 0) pw_mid = gl::pow(pw.step32, mid);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const unsigned r = r0 + 8 * k;
         tile[r][c] = src[((size_t)r << (log_n - 5)) | ((size_t)rmid << 5) | c];
     }
     __syncthreads();
+    const u64 col_factor = stepped ? gl::mul(pw.lo[c], pw_mid) : 1;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const unsigned h = r0 + 8 * k, l = c;
         const size_t i = ((size_t)h << (log_n - 5)) | ((size_t)mid << 5) | l;
         u64 v = gl::canon(tile[gl::bitrev32(l, 5)][gl::bitrev32(h, 5)]);
-        if (scale != 1) v = gl::mul(v, scale);
-        if (step != 1) v = gl::mul(v, gl::pow(step, i));
+        if (stepped)
+            v = gl::mul(v, gl::mul(pw.hi[h], col_factor));
+        else if (scale != 1)
+            v = gl::mul(v, scale);
         dst[i] = v;
     }
 }
@@ -421,10 +434,23 @@ void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s) {
     size_t n = (size_t)1 << log_n;
     unsigned tpb = 256;
-    if (log_n >= 10 && !getenv("BJ_BITREV_GATHER"))
+    if (log_n >= 10 && !getenv("BJ_BITREV_GATHER")) {
+        BitrevPowers pw{};
+        const int stepped = step != 1;
+        if (stepped) {
+            const u64 sh = gl::pow(step, (u64)1 << (log_n - 5));
+            u64 a = gl::canon(scale), b = 1;
+            for (int k = 0; k < 32; k++) {
+                pw.hi[k] = a;
+                pw.lo[k] = b;
+                a = gl::mul(a, sh);
+                b = gl::mul(b, step);
+            }
+            pw.step32 = b;
+        }
         hipLaunchKernelGGL(bitrev_scale_tiled_kernel, dim3(1u << (log_n - 10), n_cols), dim3(256), 0, s, d_in, d_out, log_n,
-                           in_col_stride, out_col_stride, scale, step);
-    else
+                           in_col_stride, out_col_stride, scale, stepped, pw);
+    } else
         hipLaunchKernelGGL(bitrev_scale_kernel, dim3((unsigned)((n + tpb - 1) / tpb), n_cols), dim3(tpb), 0, s, d_in,
                            d_out, log_n, in_col_stride, out_col_stride, scale, step);
 }
