@@ -66,6 +66,23 @@ def test_tree_matches_oracle(n_cols):
     d_c.free(); d_t.free()
 
 
+@pytest.mark.parametrize("n_cols,stride_pad", [(1, 0), (5, 3), (8, 0)])
+def test_narrow_tree_at_2p16_leaves_matches_oracle(n_cols, stride_pad):
+    """Trees over at most eight columns (one absorption per leaf: the quotient oracle's shape) at a size where every node
+    kernel variant is used, with a column stride larger than the leaf count."""
+    num_leaves, cap = 1 << 16, 16
+    rng = np.random.default_rng(900 + n_cols)
+    stride = num_leaves + stride_pad
+    buf = rand_gl(rng, (n_cols, stride), noncanonical=True)
+    cols = np.ascontiguousarray(buf[:, :num_leaves])
+    want = O.merkle_construct(cols, cap, threads=8)
+    d_c = DevBuf(buf)
+    d_t = DevBuf(nelems=want.size)
+    ctx().merkle_tree_build(d_c.ptr, stride, n_cols, num_leaves, cap, d_t.ptr)
+    assert np.array_equal(d_t.get(want.shape), want)
+    d_c.free(); d_t.free()
+
+
 @pytest.mark.parametrize("cap,num_leaves", [(1, 1), (1, 2), (4, 4), (32, 64)])
 def test_tree_edge_shapes(cap, num_leaves):
     rng = np.random.default_rng(99)
