@@ -39,3 +39,16 @@ def test_fused_gate_sweep_keeps_its_occupancy():
     m = re.search(r"Function Name: \S*gate_aot_fused_kernel\S*.*?\n.*?\n.*?VGPRs: (\d+)", r.stderr, re.S)
     assert m, "no resource report for the fused kernel"
     assert int(m.group(1)) <= 80, "gate_aot_fused_kernel uses %s VGPRs" % m.group(1)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_weak_residue_helpers_equal_128_bit_arithmetic_on_the_host(tmp_path):
+    """gl::add_weak / sub_weak / mul7_weak / e2_mul_weak / mul_pow2 and the canonical operators (csrc/gl.h) are __host__
+    __device__: their host halves are checked here on extreme and random words against unsigned __int128 arithmetic
+    (tools/gl_weak_host_check.cpp); the device halves, incl. the inline-assembly product, by tests/test_gpu_field_ops.py."""
+    exe = str(tmp_path / "gl_weak_host_check")
+    subprocess.check_call([HIPCC, "--cuda-host-only", "-x", "hip", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "era_boojum_amd", "csrc"),
+                           os.path.join(ROOT, "tools", "gl_weak_host_check.cpp"), "-o", exe], stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "weak helpers == 128-bit arithmetic" in out.stdout
