@@ -15,6 +15,8 @@
 #include "gl.h"
 #include "kernels.h"
 
+#include <cstdlib>
+
 using gl::u64;
 using gl::u32;
 
@@ -130,6 +132,120 @@ quotient_gates_kernel(const u64 *vars, size_t var_stride, const u64 *consts, siz
         }
         acc.c0 = gl::add(acc.c0, gl::mul(s0.reduce(), sel));
         acc.c1 = gl::add(acc.c1, gl::mul(s1.reduce(), sel));
+    }
+    out0[I] = acc.c0;
+    out1[I] = acc.c1;
+}
+
+// The same sum for the common gate set — at most one gate of each hand-written kind, repetitions 1 / 4 / 5 columns wide —
+// with every variable column read ONCE: the columns are taken in windows of 20 (= lcm(4, 5): five FMA repetitions, four
+// Reduction<4> repetitions, twenty constant allocations), held in registers, and every gate evaluates its repetitions of the
+// window from there.  quotient_gates_kernel above reads the sixty general-purpose columns of the SHA-256 circuit once per
+// gate (PMC: 2.05 x the algorithmic bytes); this one reads them once.
+constexpr int GW_WINDOW = 20;
+struct GateWindows {
+    int present[4];         // by kind (1, 2, 3)
+    int path_len[4], path[4][6];
+    int reps[4], const_stride[4], aoff[4];
+    int n_windows, n_vars;
+};
+__global__ void __launch_bounds__(256)
+quotient_gates_windowed_kernel(const u64 *vars, size_t var_stride, const u64 *consts, size_t const_stride, GateWindows gw,
+                               const u64 *alphas /* [n_terms][2] */, size_t Q, u64 *out0, u64 *out1) {
+    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= Q) return;
+    u64 sel[4] = {0, 0, 0, 0};
+    u64 pc[6];              // the selector path columns (shared by all gates), read once
+#pragma unroll
+    for (int b = 0; b < 6; b++) pc[b] = 0;
+    {
+        int max_path = 0;
+#pragma unroll
+        for (int k = 1; k <= 3; k++)
+            if (gw.present[k] && gw.path_len[k] > max_path) max_path = gw.path_len[k];
+#pragma unroll
+        for (int b = 0; b < 6; b++)
+            if (b < max_path) pc[b] = gl::canon(consts[(size_t)b * const_stride + I]);
+    }
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+        if (!gw.present[k]) continue;
+        u64 sv = 1;
+#pragma unroll
+        for (int b = 0; b < 6; b++)
+            if (b < gw.path_len[k]) sv = gl::mul(sv, gw.path[k][b] ? pc[b] : gl::sub(1, pc[b]));
+        sel[k] = sv;
+    }
+    u64 k2[2] = {0, 0}, k3[4] = {0, 0, 0, 0};
+    if (gw.present[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) k2[j] = gl::canon(consts[(size_t)(gw.path_len[2] + j) * const_stride + I]);
+    }
+    if (gw.present[3]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) k3[j] = gl::canon(consts[(size_t)(gw.path_len[3] + j) * const_stride + I]);
+    }
+    Acc160q s0[4], s1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        s0[k].clear();
+        s1[k].clear();
+    }
+#pragma unroll 1
+    for (int w = 0; w < gw.n_windows; w++) {
+        u64 v[GW_WINDOW];
+#pragma unroll
+        for (int c = 0; c < GW_WINDOW; c++) {
+            const int col = w * GW_WINDOW + c;
+            v[c] = gl::canon(vars[(size_t)(col < gw.n_vars ? col : 0) * var_stride + I]);   // past the last column: a valid address, never used
+        }
+        if (gw.present[1]) {    // ConstantsAllocator: a - c_r
+#pragma unroll
+            for (int i = 0; i < GW_WINDOW; i++) {
+                const int r = w * GW_WINDOW + i;
+                if (r < gw.reps[1]) {
+                    const u64 c = gl::canon(consts[(size_t)(gw.path_len[1] + r * gw.const_stride[1]) * const_stride + I]);
+                    const u64 term = gl::sub(v[i], c);
+                    s0[1].fma(term, alphas[2 * (gw.aoff[1] + r)]);
+                    s1[1].fma(term, alphas[2 * (gw.aoff[1] + r) + 1]);
+                }
+            }
+        }
+        if (gw.present[2]) {    // FMA: q*a*b + l*c - d
+#pragma unroll
+            for (int i = 0; i < GW_WINDOW / 4; i++) {
+                const int r = w * (GW_WINDOW / 4) + i;
+                if (r < gw.reps[2]) {
+                    const u64 term = gl::sub(gl::add(gl::mul(v[4 * i + 2], k2[1]), gl::mul(k2[0], gl::mul(v[4 * i], v[4 * i + 1]))), v[4 * i + 3]);
+                    s0[2].fma(term, alphas[2 * (gw.aoff[2] + r)]);
+                    s1[2].fma(term, alphas[2 * (gw.aoff[2] + r) + 1]);
+                }
+            }
+        }
+        if (gw.present[3]) {    // Reduction<4>: sum c_i v_i - r
+#pragma unroll
+            for (int i = 0; i < GW_WINDOW / 5; i++) {
+                const int r = w * (GW_WINDOW / 5) + i;
+                if (r < gw.reps[3]) {
+                    Acc160q t;
+                    t.clear();
+                    t.fma(v[5 * i], k3[0]);
+                    t.fma(v[5 * i + 1], k3[1]);
+                    t.fma(v[5 * i + 2], k3[2]);
+                    t.fma(v[5 * i + 3], k3[3]);
+                    const u64 term = gl::sub(t.reduce(), v[5 * i + 4]);
+                    s0[3].fma(term, alphas[2 * (gw.aoff[3] + r)]);
+                    s1[3].fma(term, alphas[2 * (gw.aoff[3] + r) + 1]);
+                }
+            }
+        }
+    }
+    gl::e2 acc{0, 0};
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+        if (!gw.present[k]) continue;
+        acc.c0 = gl::add(acc.c0, gl::mul(s0[k].reduce(), sel[k]));
+        acc.c1 = gl::add(acc.c1, gl::mul(s1[k].reduce(), sel[k]));
     }
     out0[I] = acc.c0;
     out1[I] = acc.c1;
@@ -270,6 +386,43 @@ void launch_quotient_gates(const u64 *d_vars, size_t var_stride, const u64 *d_co
     for (unsigned g = 0; g < n_gates && g < (unsigned)BJ_MAX_GATES; g++) {
         const int *f = h_gates_flat + 12 * g;
         gs.g[g] = GateDev{f[0], f[1], f[2], f[3], f[4], f[5], {f[6], f[7], f[8], f[9], f[10], f[11]}};
+    }
+    {   // the windowed kernel when the hand-written kinds appear at most once each with their principal widths
+        const char *env = getenv("BJ_GATES_WINDOWED");   // read per call: "0" selects the per-gate kernel (the tests run both)
+        const bool windowed_on = !(env && env[0] == '0');
+        GateWindows gw{};
+        const int width[4] = {0, 1, 4, 5};
+        bool ok = windowed_on && n_gates <= (unsigned)BJ_MAX_GATES;
+        int aoff = 0, span = 0, n_hand = 0;
+        for (unsigned g = 0; ok && g < n_gates; g++) {
+            const GateDev &G = gs.g[g];
+            if (G.num_terms == 0) continue;
+            if (G.kind >= 5) {   // evaluated by its own kernel: only the alpha powers are skipped (as in quotient_gates_kernel)
+                aoff += G.reps * G.num_terms;
+                continue;
+            }
+            if (G.kind < 1 || G.kind > 3 || gw.present[G.kind] || G.var_stride != width[G.kind] || G.num_terms != 1 || G.path_len > 6 ||
+                (G.kind != 1 && G.const_stride != 0)) {
+                ok = false;
+                break;
+            }
+            gw.present[G.kind] = 1;
+            gw.path_len[G.kind] = G.path_len;
+            for (int b = 0; b < 6; b++) gw.path[G.kind][b] = G.path[b];
+            gw.reps[G.kind] = G.reps;
+            gw.const_stride[G.kind] = G.const_stride;
+            gw.aoff[G.kind] = aoff;
+            aoff += G.reps;
+            if (G.reps * width[G.kind] > span) span = G.reps * width[G.kind];
+            n_hand++;
+        }
+        if (ok && n_hand > 0) {
+            gw.n_windows = (span + GW_WINDOW - 1) / GW_WINDOW;
+            gw.n_vars = span;
+            hipLaunchKernelGGL(quotient_gates_windowed_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_vars, var_stride,
+                               d_consts, const_stride, gw, d_alphas, Q, d_out0, d_out1);
+            return;
+        }
     }
     hipLaunchKernelGGL(quotient_gates_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, s, d_vars, var_stride,
                        d_consts, const_stride, gs, d_alphas, Q, d_out0, d_out1);

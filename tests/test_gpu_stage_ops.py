@@ -164,9 +164,19 @@ def test_quotient_term_kernels_one_by_one_and_together(log_n, kw):
     # makes on the top coefficient (prover.rs:1425-1438)
     mono = O.ifft_batch(np.stack([O.bitreverse(want[0]), O.bitreverse(want[1])]), 7, threads=2)
     assert mono[0][-1] == 0 and mono[1][-1] == 0
-    # gate terms alone (then the division by the vanishing polynomial through the third operator with zero challenges)
+    # gate terms alone (then the division by the vanishing polynomial through the third operator with zero challenges): once
+    # through the kernel that reads every variable column once for all gates (windows of 20 columns), once through the
+    # per-gate kernel that circuits with several gates of one kind fall back to
+    want_gates = _oracle_quotient(c, d, zero * nl + a_gates + zero * (1 + nch))
     gates(a_gates); copy_perm(zero * (1 + nch))
-    assert np.array_equal(out.get((2, Q)), _oracle_quotient(c, d, zero * nl + a_gates + zero * (1 + nch)))
+    assert np.array_equal(out.get((2, Q)), want_gates)
+    import os
+    os.environ["BJ_GATES_WINDOWED"] = "0"
+    try:
+        clear(); gates(a_gates); copy_perm(zero * (1 + nch))
+    finally:
+        del os.environ["BJ_GATES_WINDOWED"]
+    assert np.array_equal(out.get((2, Q)), want_gates)
     # lookup terms alone
     clear(); lookup(a_lookup); copy_perm(zero * (1 + nch))
     assert np.array_equal(out.get((2, Q)), _oracle_quotient(c, d, a_lookup + zero * (ng + 1 + nch)))
