@@ -63,4 +63,14 @@ void launch_fri_fold(const u64 *d_c0, const u64 *d_c1, size_t len, u64 *d_o0, u6
                      u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s);
 void launch_fri_fold_step(const u64 *d_c0, const u64 *d_c1, size_t len, unsigned k, u64 *d_o0, u64 *d_o1,
                           const u64 *d_roots, u64 coset_inv, u64 ch0, u64 ch1, hipStream_t s, size_t j0 = 0);
+// openings.hip: several DEEP opening sets in one launch (device-side argument pointers, canonical scalars)
+constexpr int DEEP_MAX_SETS = 3;
+struct DeepSetHostArgs {
+    const u64 *const *d_cols;
+    const u64 *d_coefs;     // [n_cols][2]
+    unsigned n_cols;
+    u64 c0, c1, at0, at1;
+};
+void launch_deep_accumulate_multi(const DeepSetHostArgs *sets, unsigned n_sets, size_t N, size_t I0, const u64 *d_tw_fwd,
+                                  u64 *d_dst0, u64 *d_dst1, int accumulate, hipStream_t s);
 }  // namespace bj

@@ -364,6 +364,104 @@ deep_accumulate_kernel(const u64 *const *cols, const u64 *coefs /*[n][2]*/, unsi
     }
 }
 
+// Several opening sets in one pass (the prover's z, z*omega and 0): dst (+)= sum_t (sum_k coef_tk f_tk - C_t) / (x - at_t).
+// One inversion serves DEEP_PTS * n_sets denominators instead of DEEP_PTS, and the destination is written once instead of
+// being re-read and re-written per set.  Phase 1 walks (set, point) forward building the prefix products of the norms,
+// phase 2 walks backward: it unwinds the inverses and computes each set's numerators only then, so that one set's
+// accumulators are live at a time.  Exact arithmetic: the same values as deep_accumulate_kernel applied set by set.
+struct DeepSetDev {
+    const u64 *const *cols;
+    const u64 *coefs;       // [n_cols][2]
+    unsigned n_cols;
+    u64 c0, c1, at0, at1;
+};
+struct DeepSetsDev {
+    DeepSetDev s[DEEP_MAX_SETS];
+    int n;
+};
+__global__ void __launch_bounds__(256)
+deep_accumulate_multi_kernel(DeepSetsDev S, size_t N, size_t I0, const u64 *tw, u64 *dst0, u64 *dst1, int accumulate) {
+    const size_t base = (size_t)blockIdx.x * (256 * DEEP_PTS) + threadIdx.x;
+    u64 x[DEEP_PTS];
+#pragma unroll
+    for (int k = 0; k < DEEP_PTS; k++) {
+        const size_t I = base + (size_t)k * 256;
+        const size_t Ic = I0 + (I < N ? I : 0);
+        u64 wi = tw[Ic >> 1];
+        if (Ic & 1) wi = gl::neg(wi);
+        x[k] = mul7(wi);
+    }
+    u64 norm[DEEP_MAX_SETS][DEEP_PTS], pref[DEEP_MAX_SETS][DEEP_PTS];
+    u64 run = 1;
+#pragma unroll
+    for (int t = 0; t < DEEP_MAX_SETS; t++) {
+        if (t >= S.n) break;
+        const u64 seven_d1sq = mul7(gl::sqr(S.s[t].at1));   // (-at1)^2 = at1^2
+#pragma unroll
+        for (int k = 0; k < DEEP_PTS; k++) {
+            const u64 d0 = gl::sub(x[k], S.s[t].at0);
+            norm[t][k] = gl::sub(gl::sqr(d0), seven_d1sq);
+            pref[t][k] = run;
+            run = gl::mul(run, norm[t][k]);
+        }
+    }
+    u64 inv_run = inv_chain(run);
+    gl::e2 acc[DEEP_PTS];
+#pragma unroll
+    for (int k = 0; k < DEEP_PTS; k++) {
+        const size_t I = base + (size_t)k * 256;
+        acc[k] = (accumulate && I < N) ? gl::e2{gl::canon(dst0[I]), gl::canon(dst1[I])} : gl::e2{0, 0};
+    }
+#pragma unroll
+    for (int t = DEEP_MAX_SETS - 1; t >= 0; t--) {
+        if (t >= S.n) continue;
+        Acc160 s0[DEEP_PTS], s1[DEEP_PTS];
+#pragma unroll
+        for (int k = 0; k < DEEP_PTS; k++) {
+            s0[k].clear();
+            s1[k].clear();
+        }
+        for (unsigned c = 0; c < S.s[t].n_cols; c++) {
+            const u64 *f = S.s[t].cols[c];
+            const u64 a = S.s[t].coefs[2 * c], b = S.s[t].coefs[2 * c + 1];
+#pragma unroll
+            for (int k = 0; k < DEEP_PTS; k++) {
+                const size_t I = base + (size_t)k * 256;
+                const u64 v = f[I < N ? I : 0];
+                s0[k].fma(v, a);
+                s1[k].fma(v, b);
+            }
+        }
+        const u64 d1 = gl::neg(S.s[t].at1);
+#pragma unroll
+        for (int k = DEEP_PTS - 1; k >= 0; k--) {
+            const u64 ni = gl::mul(inv_run, pref[t][k]);
+            inv_run = gl::mul(inv_run, norm[t][k]);
+            const u64 d0 = gl::sub(x[k], S.s[t].at0);
+            const gl::e2 den{gl::mul(d0, ni), gl::neg(gl::mul(d1, ni))};
+            const gl::e2 num{gl::sub(s0[k].reduce(), S.s[t].c0), gl::sub(s1[k].reduce(), S.s[t].c1)};
+            acc[k] = gl::e2_add(acc[k], gl::e2_mul(num, den));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DEEP_PTS; k++) {
+        const size_t I = base + (size_t)k * 256;
+        if (I < N) {
+            dst0[I] = acc[k].c0;
+            dst1[I] = acc[k].c1;
+        }
+    }
+}
+void launch_deep_accumulate_multi(const DeepSetHostArgs *sets, unsigned n_sets, size_t N, size_t I0, const u64 *d_tw_fwd,
+                                  u64 *d_dst0, u64 *d_dst1, int accumulate, hipStream_t s) {
+    DeepSetsDev S{};
+    S.n = (int)n_sets;
+    for (unsigned t = 0; t < n_sets && t < (unsigned)DEEP_MAX_SETS; t++)
+        S.s[t] = DeepSetDev{sets[t].d_cols, sets[t].d_coefs, sets[t].n_cols, sets[t].c0, sets[t].c1, sets[t].at0, sets[t].at1};
+    const unsigned blocks = (unsigned)((N + 256 * DEEP_PTS - 1) / (256 * DEEP_PTS));
+    hipLaunchKernelGGL(deep_accumulate_multi_kernel, dim3(blocks), dim3(256), 0, s, S, N, I0, d_tw_fwd, d_dst0, d_dst1, accumulate);
+}
+
 void launch_deep_accumulate(const u64 *const *d_col_ptrs, const u64 *d_coefs, unsigned n_cols, size_t N, size_t I0,
                             const u64 *d_tw_fwd, u64 c0, u64 c1, u64 at0, u64 at1, u64 *d_dst0, u64 *d_dst1,
                             int accumulate, hipStream_t s) {

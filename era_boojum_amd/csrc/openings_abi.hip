@@ -25,6 +25,13 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
                           const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
                           unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
                           int accumulate);
+struct DeepSetHost {   // one opening set, host side: sources (device pointers), values and challenges as F_p^2 pairs, the point
+    const uint64_t *const *src_c0, *const *src_c1;
+    size_t n_src;
+    const uint64_t *values, *challenges, *at2;
+};
+int deep_accumulate_multi(bj_ctx *ctx, const DeepSetHost *sets, unsigned n_sets, unsigned log_n, unsigned log_lde, size_t N_local,
+                          size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1, int accumulate);
 }
 namespace {
 // device-side argument block: [ptrs (n_cols)] [coefs (2*n_cols)] in one temporary allocation
@@ -164,6 +171,62 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
                                gl::canon(at2[0]), gl::canon(at2[1]), d_dst_c0, d_dst_c1, accumulate, ctx->stream);
     BJ_CHECK_LAUNCH(ctx);
     if (!args.from_arena) BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a hipMalloc'ed argument block is freed on return
+    return BJ_OK;
+}
+
+// up to DEEP_MAX_SETS opening sets at once (same argument meaning per set as deep_accumulate_range): one launch, one inversion
+// per lane for all of them, the destination written once
+int deep_accumulate_multi(bj_ctx *ctx, const DeepSetHost *sets, unsigned n_sets, unsigned log_n, unsigned log_lde, size_t N_local,
+                          size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1, int accumulate) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!sets || n_sets == 0 || n_sets > (unsigned)DEEP_MAX_SETS || !d_dst_c0 || !d_dst_c1)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "deep_accumulate_multi: bad arguments");
+    const unsigned log_full = log_n + log_lde;
+    if (log_full == 0 || log_full > 32) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "deep_accumulate_multi: bad domain");
+    if (int rc = bj::ensure_twiddles(ctx, log_full, false)) return rc;
+    std::vector<const u64 *> ptrs;
+    std::vector<u64> coefs;
+    DeepSetHostArgs a[DEEP_MAX_SETS];
+    size_t first_col[DEEP_MAX_SETS];
+    for (unsigned t = 0; t < n_sets; t++) {
+        const DeepSetHost &S = sets[t];
+        if (!S.src_c0 || !S.values || !S.challenges || !S.at2 || S.n_src == 0 || S.n_src > (1u << 20))
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "deep_accumulate_multi: bad set %u", t);
+        first_col[t] = ptrs.size();
+        gl::e2 C{0, 0};
+        for (size_t k = 0; k < S.n_src; k++) {
+            if (!S.src_c0[k]) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "deep_accumulate_multi: null source %zu of set %u", k, t);
+            const gl::e2 ch{gl::canon(S.challenges[2 * k]), gl::canon(S.challenges[2 * k + 1])};
+            const gl::e2 v{gl::canon(S.values[2 * k]), gl::canon(S.values[2 * k + 1])};
+            C = gl::e2_add(C, gl::e2_mul(ch, v));
+            ptrs.push_back(S.src_c0[k]);
+            coefs.push_back(ch.c0);
+            coefs.push_back(ch.c1);
+            if (S.src_c1 && S.src_c1[k]) {
+                ptrs.push_back(S.src_c1[k]);
+                coefs.push_back(gl::mul(gl::GEN, ch.c1));
+                coefs.push_back(ch.c0);
+            }
+        }
+        a[t].n_cols = (unsigned)(ptrs.size() - first_col[t]);
+        a[t].c0 = C.c0;
+        a[t].c1 = C.c1;
+        a[t].at0 = gl::canon(S.at2[0]);
+        a[t].at1 = gl::canon(S.at2[1]);
+    }
+    DevArgs args;
+    if (int rc = args.alloc(ctx, ptrs.size() * sizeof(u64 *) + coefs.size() * sizeof(u64))) return rc;
+    const u64 **d_ptrs = (const u64 **)args.d;
+    u64 *d_coefs = (u64 *)(d_ptrs + ptrs.size());
+    if (int rc = bj::h2d_async(ctx, (void *)d_ptrs, ptrs.data(), ptrs.size() * sizeof(u64 *))) return rc;
+    if (int rc = bj::h2d_async(ctx, d_coefs, coefs.data(), coefs.size() * sizeof(u64))) return rc;
+    for (unsigned t = 0; t < n_sets; t++) {
+        a[t].d_cols = d_ptrs + first_col[t];
+        a[t].d_coefs = d_coefs + 2 * first_col[t];
+    }
+    bj::launch_deep_accumulate_multi(a, n_sets, N_local, I0, ctx->tw_fwd, d_dst_c0, d_dst_c1, accumulate, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    if (!args.from_arena) BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return BJ_OK;
 }
 }  // namespace bj

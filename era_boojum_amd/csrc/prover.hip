@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 using gl::u64;
@@ -56,6 +57,13 @@ int deep_accumulate_range(bj_ctx *ctx, const uint64_t *const *h_src_c0, const ui
                           const uint64_t *h_values, const uint64_t *h_challenges, const uint64_t *at2, unsigned log_n,
                           unsigned log_lde, size_t N_local, size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1,
                           int accumulate);
+struct DeepSetHost {
+    const uint64_t *const *src_c0, *const *src_c1;
+    size_t n_src;
+    const uint64_t *values, *challenges, *at2;
+};
+int deep_accumulate_multi(bj_ctx *ctx, const DeepSetHost *sets, unsigned n_sets, unsigned log_n, unsigned log_lde, size_t N_local,
+                          size_t I0, uint64_t *d_dst_c0, uint64_t *d_dst_c1, int accumulate);
 }  // namespace bj
 
 struct bj_setup {
@@ -566,7 +574,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                     + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
                     + 4 * N + (N * sh.world) / 2                                                   // FRI layers + trees, DEEP argument blocks
                     + (sh.world > 1 ? 10 * n : 0)                                                  // sharded DEEP numerators: slices + gather staging
-                    + (hw ? 4 * N : 0);                                                            // host witness hashed in groups: the leaves' capacity words
+                    + (hw ? 4 * N : 0)                                                             // host witness hashed in groups: the leaves' capacity words
+                    + (size_t)2 * N * (1 + S->pub_cols.size());                                    // DEEP: one extended numerator per large opening set beyond the first
         if ((rc = bj::arena_reset(ctx, need))) return rc;
     }
     struct InProof {   // temporaries of the ABI calls below come out of the arena while this is alive
@@ -966,25 +975,53 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     // Every opening set goes the same way: the numerator sum_k ch_k f_k is a polynomial of degree < n, so it is combined on
     // the MONOMIAL forms (n coefficients per column instead of the fri_lde_factor * n values of the FRI domain), extended by
     // one two-column LDE and divided by (x - at) pointwise.  Exact arithmetic: the same values as combining on the LDE.
-    ArenaBuf num_mono, num_lde, num_slice;
+    ArenaBuf num_mono, num_slice;
     if ((rc = num_mono.alloc(ctx, 2 * n))) return rc;
     if (sh.world > 1 && (rc = num_slice.alloc(ctx, 2 * n / sh.world + 16))) return rc;
-    if ((rc = num_lde.alloc(ctx, 2 * N))) return rc;
-    auto deep_set = [&](const std::vector<Src> &ls, const std::vector<Src> &ms, const u64 *vals, const u64 *at, int accumulate) -> int {
+    // The sets are prepared one after the other (a large one leaves its extended numerator in a buffer of its own) and divided
+    // by their (x - at) TOGETHER, bj::DEEP_MAX_SETS per launch: one inversion per lane for all of them, the destination written once.
+    struct PendingDeep {
+        std::vector<const u64 *> p0, p1;
+        std::vector<u64> vals, ch;
+        u64 at[2];
+    };
+    std::deque<PendingDeep> pending;
+    bool deep_written = false;
+    auto flush_deep = [&]() -> int {
+        while (!pending.empty()) {
+            bj::DeepSetHost hs[3];
+            unsigned cnt = 0;
+            for (auto it = pending.begin(); it != pending.end() && cnt < 3; ++it, ++cnt)
+                hs[cnt] = bj::DeepSetHost{it->p0.data(), it->p1.data(), it->p0.size(), it->vals.data(), it->ch.data(), it->at};
+            int r = bj::deep_accumulate_multi(ctx, hs, cnt, log_n, S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p, deep.p + N,
+                                              deep_written ? 1 : 0);
+            if (r) return r;
+            deep_written = true;
+            for (unsigned k = 0; k < cnt; k++) pending.pop_front();
+        }
+        return BJ_OK;
+    };
+    auto deep_set = [&](const std::vector<Src> &ls, const std::vector<Src> &ms, const u64 *vals, const u64 *at) -> int {
         const u64 *ch = chs.data() + 2 * choff;
         std::vector<const u64 *> p0, p1;
         size_t n_base = 0;
         for (auto &m : ms) n_base += m.c1 ? 2 : 1;
         if (n_base < 16) {   // a handful of columns: streaming them over the FRI domain is cheaper than an extra LDE pass
+            PendingDeep pd;
             for (auto &l : ls) {
-                p0.push_back(l.c0);
-                p1.push_back(l.c1);
+                pd.p0.push_back(l.c0);
+                pd.p1.push_back(l.c1);
             }
-            int r = bj::deep_accumulate_range(ctx, p0.data(), p1.data(), ls.size(), vals, ch, at, log_n, S->log_fri, N,
-                                              sh.world > 1 ? I0 : 0, deep.p, deep.p + N, accumulate);
+            pd.vals.assign(vals, vals + 2 * ls.size());
+            pd.ch.assign(ch, ch + 2 * ls.size());
+            pd.at[0] = at[0];
+            pd.at[1] = at[1];
+            pending.push_back(std::move(pd));
             choff += ls.size();
-            return r;
+            return BJ_OK;
         }
+        ArenaBuf num_lde;   // this set's extended numerator: alive until the sets are flushed
+        if (int ra = num_lde.alloc(ctx, 2 * N)) return ra;
         for (auto &m : ms) {
             p0.push_back(m.c0);
             p1.push_back(m.c1);
@@ -1010,23 +1047,27 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         if (r) return r;
         gl::e2 C{0, 0};   // sum_k ch_k * v_k
         for (size_t k = 0; k < ms.size(); k++) C = gl::e2_add(C, gl::e2_mul(e2c(ch + 2 * k), e2c(vals + 2 * k)));
-        const u64 one_ch[2] = {1, 0}, cv[2] = {C.c0, C.c1};
-        const u64 *g0 = num_lde.p, *g1 = num_lde.p + N;
-        r = bj::deep_accumulate_range(ctx, &g0, &g1, 1, cv, one_ch, at, log_n, S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p,
-                                      deep.p + N, accumulate);
+        PendingDeep pd;   // one F_p^2 source (the extended numerator) with challenge 1 and "value" C
+        pd.p0.push_back(num_lde.p);
+        pd.p1.push_back(num_lde.p + N);
+        pd.vals = {C.c0, C.c1};
+        pd.ch = {1, 0};
+        pd.at[0] = at[0];
+        pd.at[1] = at[1];
+        pending.push_back(std::move(pd));
         choff += ms.size();
-        return r;
+        return BJ_OK;
     };
-    if ((rc = deep_set(srcs, msrcs, vz.data(), z, 0))) return rc;
+    if ((rc = deep_set(srcs, msrcs, vz.data(), z))) return rc;
     {
         std::vector<Src> mz{msrcs[VW + nC + V]};                      // z(x) at z*omega
-        if ((rc = deep_set(zsrc, mz, vzo.data(), zo, 1))) return rc;
+        if ((rc = deep_set(zsrc, mz, vzo.data(), zo))) return rc;
     }
     if (has_lookup) {
         std::vector<Src> ml;
         for (unsigned i = 0; i < S->lookup_reps + 1; i++) ml.push_back(msrcs[VW + nC + V + 1 + n_part + 1 + i]);
         u64 zero2[2] = {0, 0};
-        if ((rc = deep_set(lsrc, ml, v0.data(), zero2, 1))) return rc;
+        if ((rc = deep_set(lsrc, ml, v0.data(), zero2))) return rc;
     }
     for (auto &p : pubs) {
         std::vector<Src> ps, pl;
@@ -1038,8 +1079,9 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             pv.push_back(0);
         }
         u64 at2[2] = {p.at, 0};
-        if ((rc = deep_set(pl, ps, pv.data(), at2, 1))) return rc;
+        if ((rc = deep_set(pl, ps, pv.data(), at2))) return rc;
     }
+    if ((rc = flush_deep())) return rc;
     proof->stage_ms[4] = timer.lap();
 
     // ---------------- round 5b: FRI (prover.rs:2075-2105) ----------------
