@@ -111,6 +111,7 @@ void orc_quotient(const uint64_t *vars, size_t V, const uint64_t *consts, size_t
                   const uint64_t *alphas, size_t n_alphas, const uint64_t *beta2, const uint64_t *gamma2,
                   const uint64_t *lbeta2, const uint64_t *lgamma2, uint64_t *out_q, int threads, size_t coset_count) {
     size_t n = (size_t)1 << log_n, q = (size_t)1 << log_q;
+    (void)Kc;                                  /* number of constant columns: part of the call shape, the gates index into them */
     if (coset_count == 0) { coset_begin = 0; coset_count = q; }
     const size_t Q = coset_count * n;          /* stride of the arrays and number of points evaluated here */
     const orc_gate *gates = (const orc_gate *)gates_flat;
