@@ -69,3 +69,62 @@ def sharded_commit(backend, d_mono, log_n, n_cols, log_lde, cap_size, world, ran
     local_cap = backend.merkle_tree_cap(d_tree, local_leaves, frag)
     cap = all_gather_cap(local_cap, world, device)
     return d_lde, d_tree, local_leaves, cap
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Quotient evaluation sharded over ALL ranks ("costed, not built"): the model the device code will follow.
+#
+# T has degree < q*n.  Its evaluations on ONE coset s*H_n of the LDE domain (what a rank holding that coset can compute from
+# its own columns) determine R = T mod (x^n - a), a = s^n, by one size-n inverse transform with shift s: writing
+# T = sum_j x^(j n) T_j (T_j of degree < n), R = sum_j a^j T_j.  Any q residues with distinct a_i give T_0 .. T_{q-1} back
+# through the inverse of the Vandermonde matrix V[i][j] = a_i^j, coefficient by coefficient.  A rank holding m adjacent cosets
+# (m a power of two, the first of them at a multiple of m) holds one coset of H_{m n} and gets a residue modulo x^(m n) - a the
+# same way, so W ranks can split the q*n evaluation points evenly whenever W <= q * (cosets per rank).
+# ---------------------------------------------------------------------------------------------------------------------------
+P = (1 << 64) - (1 << 32) + 1
+
+
+def _omega(log_n):
+    w = 0x185629DCDA58878C
+    for _ in range(32 - log_n):
+        w = w * w % P
+    return w
+
+
+def _bitrev(x, bits):
+    return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
+
+
+def lde_coset_shift(log_n, log_lde, coset):
+    """x-shift of LDE coset `coset` (bit-reversed coset enumeration: 7 * w_{nL}^bitrev_L(coset), fft/mod.rs coset LDE)."""
+    return 7 * pow(_omega(log_n + log_lde), _bitrev(coset, log_lde), P) % P
+
+
+def residue_from_coset(evals_bitrev, shift, ifft_natural_to_natural, bitreverse):
+    """T mod (x^m - shift^m) from T's values on shift*H_m in bit-reversed order (m = len): the inverse transform with that shift."""
+    return ifft_natural_to_natural(bitreverse(evals_bitrev), shift)
+
+
+def combine_residues(residues, a_values):
+    """residues[i] = T mod (x^m - a_i) (arrays of m coefficients, python ints or u64) -> the q*m coefficients of T."""
+    q = len(residues)
+    m = len(residues[0])
+    # inverse of V[i][j] = a_i^j over F_p by Gauss-Jordan (q is 2, 4 or 8)
+    V = [[pow(a % P, j, P) for j in range(q)] for a in a_values]
+    A = [row[:] + [1 if i == k else 0 for k in range(q)] for i, row in enumerate(V)]
+    for c in range(q):
+        piv = next(r for r in range(c, q) if A[r][c])
+        A[c], A[piv] = A[piv], A[c]
+        inv = pow(A[c][c], P - 2, P)
+        A[c] = [v * inv % P for v in A[c]]
+        for r in range(q):
+            if r != c and A[r][c]:
+                f = A[r][c]
+                A[r] = [(v - f * w) % P for v, w in zip(A[r], A[c])]
+    Vinv = [row[q:] for row in A]
+    out = np.zeros(q * m, dtype=np.uint64)
+    res = [[int(v) % P for v in r] for r in residues]
+    for j in range(q):
+        for k in range(m):
+            out[j * m + k] = sum(Vinv[j][i] * res[i][k] for i in range(q)) % P
+    return out
