@@ -29,6 +29,13 @@ RC_INC = os.path.join(ROOT, "era_boojum_amd", "csrc", "poseidon_rc.inc")
 WAYS = int(os.environ.get("BJ_P2_WAYS", "3"))            # S-boxes interleaved in a full round (2, 3 or 4; v[24:71] holds four sets): 3 measured best by ~1 %
 assert WAYS in (2, 3, 4)
 COMBINE_INLINE = os.environ.get("BJ_P2_COMBINE", "") == "inline"
+# Experiments for the next round (default off: the committed stream and its profiles are those of the default build).
+#   BJ_P2_ZERO_HOIST=1: the zero high halves of the S-box addend pairs are written once per full round (3 moves instead of 12)
+#                       and once before the partial-round loop (v35 is not touched by the partial rounds' linear layer): -93 VALU;
+#   BJ_P2_LATE_CONST=1: the twelve constants of the first closing full round ride on the LAST partial round's linear layer
+#                       (two multiply-adds per word, as word 0's constant always does) instead of a weak addition each: -26 VALU.
+ZERO_HOIST = os.environ.get("BJ_P2_ZERO_HOIST", "") == "1"
+LATE_CONST = os.environ.get("BJ_P2_LATE_CONST", "") == "1"
 SH = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]           # internal matrix 1 + diag(2^SH)  (poseidon2/params.rs:38-39)
 P = (1 << 64) - (1 << 32) + 1
 
@@ -150,13 +157,14 @@ class Gen:
                        "v_subbrev_co_u32 v%d, vcc, 0, v%d, vcc" % (X + 1, X + 1), "s_branch %s" % back]
         return ch
 
-    def sbox(self, k, base, masks):
-        """x^7 on state word k in place; temporaries v[base : base+12), masks: three SGPR pair numbers."""
+    def sbox(self, k, base, masks, zero=True):
+        """x^7 on state word k in place; temporaries v[base : base+12), masks: three SGPR pair numbers.  zero=False: v[base+11]
+        already holds 0 (ZERO_HOIST)."""
         T, H, X1, X2, X3, Z = base, base + 2, base + 4, base + 6, base + 8, base + 10
         cm, c, bq = masks
         x = (S(k), S(k) + 1)
         x2, x3, x4 = (X1, X1 + 1), (X2, X2 + 1), (X3, X3 + 1)
-        ch = [Ins("v_mov_b32 v%d, 0" % (Z + 1))]
+        ch = [Ins("v_mov_b32 v%d, 0" % (Z + 1))] if zero else []
         ch += self.mulw(x, x, T, X1, H, Z, X1, cm, c, bq)          # x^2
         ch += self.mulw(x2, x, T, X2, H, Z, X2, cm, c, bq)         # x^3
         ch += self.mulw(x2, x2, T, X3, H, Z, X3, cm, c, bq)        # x^4
@@ -253,17 +261,20 @@ class Gen:
     def full_round(self):
         self.load_rc(16)                          # folded constants of the layer at the end of this round (arrive during the S-boxes)
         ways = WAYS                               # S-box chains issued round-robin: 12 temporaries and 3 mask pairs each
+        if ZERO_HOIST:                            # the linear layer before this round used these registers: zero them once per round
+            self.emit([Ins("v_mov_b32 v%d, 0" % (24 + 12 * i + 11)) for i in range(ways)])
         for k in range(0, 12, ways):
-            chains = [self.sbox(k + i, 24 + 12 * i, (S_MASK + 6 * i, S_MASK + 6 * i + 2, S_MASK + 6 * i + 4)) for i in range(ways)]
+            chains = [self.sbox(k + i, 24 + 12 * i, (S_MASK + 6 * i, S_MASK + 6 * i + 2, S_MASK + 6 * i + 4), zero=not ZERO_HOIST) for i in range(ways)]
             self.emit(interleave(chains))
         self.raw("s_waitcnt lgkmcnt(0)")
         self.ext_layer()
 
-    def partial_round(self):
-        """word 0 <- (word 0)^7, then state <- (1 + diag(2^SH)) * state, + the next round's constant on word 0."""
-        self.load_rc(1)
+    def partial_round(self, last=False):
+        """word 0 <- (word 0)^7, then state <- (1 + diag(2^SH)) * state, + the next round's constant on word 0 (last=True, LATE_CONST:
+        + the twelve constants of the full round that follows, one per word)."""
+        self.load_rc(12 if last else 1)
         SL, SH_ = 48, 50                          # sums of the low / high words
-        sb = self.sbox(0, 24, (S_MASK, S_MASK + 2, S_MASK + 4))
+        sb = self.sbox(0, 24, (S_MASK, S_MASK + 2, S_MASK + 4), zero=not ZERO_HOIST)
         sums = []
         for k in range(1, 12):
             sums.append(Ins("v_mad_u64_u32 %s, vcc, v%d, 1, %s" % (vp(SL), S(k), "0" if k == 1 else vp(SL))))
@@ -281,9 +292,9 @@ class Gen:
                 mult = str(1 << e) if (1 << e) <= 64 else "s%d" % SHIFT_REG[e]
                 ch = [Ins("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (vp(A), S(k), mult, vp(SL))),
                       Ins("v_mad_u64_u32 %s, vcc, v%d, %s, %s" % (vp(B), S(k) + 1, mult, vp(SH_)))]
-                if k == 0:                        # the next round's constant for word 0
-                    ch += [Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(A), S_RC, vp(A))),
-                           Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(B), S_RC + 1, vp(B)))]
+                if k == 0 or last:                # the next round's constant for word 0 (for every word in the last partial round)
+                    ch += [Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(A), S_RC + 2 * k, vp(A))),
+                           Ins("v_mad_u64_u32 %s, vcc, s%d, 1, %s" % (vp(B), S_RC + 2 * k + 1, vp(B)))]
                 ch += self.combine(A, B, S(k), k01, mask)
                 chains.append(ch)
             self.emit(interleave(chains))
@@ -324,14 +335,19 @@ class Gen:
         self.raw("s_cmp_lg_u32 s%d, 0" % S_PHASE)
         self.raw("s_cbranch_scc1 %s" % end)
         self.raw("s_mov_b32 s%d, 1" % S_PHASE)
-        self.raw("s_mov_b32 s%d, 22" % S_CNT)
+        self.raw("s_mov_b32 s%d, %d" % (S_CNT, 21 if LATE_CONST else 22))
+        if ZERO_HOIST:                            # v35 = 0 for every partial-round S-box (nothing in these rounds writes it)
+            self.raw("v_mov_b32 v35, 0")
         ploop = self.label("p")
         self.raw("%s:" % ploop)
         self.partial_round()
         self.raw("s_sub_u32 s%d, s%d, 1" % (S_CNT, S_CNT))
         self.raw("s_cmp_lg_u32 s%d, 0" % S_CNT)
         self.raw("s_cbranch_scc1 %s" % ploop)
-        self.add_constants_weak()
+        if LATE_CONST:
+            self.partial_round(last=True)
+        else:
+            self.add_constants_weak()
         self.raw("s_branch %s" % top)
         self.lines += self.stubs                  # rare paths of the products, out of line
         self.raw("%s:" % end)
@@ -385,10 +401,10 @@ def rc_table():
     R = lambda r: [x % P for x in rc[12 * r:12 * r + 12]]
     F = fold_ext_constants
     t = F(R(0)) + F(R(1)) + F(R(2)) + F(R(3)) + F([rc[12 * 4] % P] + [0] * 11)
-    t += [rc[12 * r] % P for r in range(5, 26)] + [0]
+    t += [rc[12 * r] % P for r in range(5, 26)] + ([] if LATE_CONST else [0])
     t += R(26)
     t += F(R(27)) + F(R(28)) + F(R(29)) + F([0] * 12)
-    assert len(t) == 16 * 5 + 22 + 12 + 16 * 4
+    assert len(t) == 16 * 5 + (21 if LATE_CONST else 22) + 12 + 16 * 4
     return t
 
 

@@ -2,13 +2,18 @@
 """A/B builds of the Poseidon2 instruction stream: the library relinked around poseidon2.hip compiled with another schedule
 (tools/gen_p2_asm.py under BJ_P2_WAYS / BJ_P2_COMBINE), into exp/libbj_p2_<name>.so; BOOJUM_HIP_LIB selects one at load.
     python tools/p2_variants.py build            # on the build host (hipcc cross-compiles)
-    python tools/p2_variants.py bench            # on the GPU: tree 2^23 x 93 with every variant, JSON lines"""
+    python tools/p2_variants.py bench            # on the GPU: tree 2^23 x 93 with every variant, JSON lines
+A list of variant names after the command restricts both to those."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 EXP = os.path.join(ROOT, "exp")
 VARIANTS = {"w2": {"BJ_P2_WAYS": "2"}, "w3": {"BJ_P2_WAYS": "3"}, "w4": {"BJ_P2_WAYS": "4"},
-            "w2_inline": {"BJ_P2_WAYS": "2", "BJ_P2_COMBINE": "inline"}, "w3_inline": {"BJ_P2_WAYS": "3", "BJ_P2_COMBINE": "inline"}}
+            "w2_inline": {"BJ_P2_WAYS": "2", "BJ_P2_COMBINE": "inline"}, "w3_inline": {"BJ_P2_WAYS": "3", "BJ_P2_COMBINE": "inline"},
+            "w3_hoist": {"BJ_P2_WAYS": "3", "BJ_P2_ZERO_HOIST": "1"},
+            "w3_hoist_lc": {"BJ_P2_WAYS": "3", "BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "1"}}
+if len(sys.argv) > 2:   # python tools/p2_variants.py build|bench name [name ...]
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[2:]}
 
 
 def build():
