@@ -124,6 +124,11 @@ class Emulator:
         self.vcc, self.scc = 0, 0
         for k, w in enumerate(state):
             self.v[2 * k], self.v[2 * k + 1] = w & M32, (w >> 32) & M32
+        self.execute(max_steps)
+        return [self.v[2 * k] | (self.v[2 * k + 1] << 32) for k in range(12)]
+
+    def execute(self, max_steps=200000):
+        """Runs the program on the current register contents (self.v, self.s, self.vcc, self.scc)."""
         self.counts = {"VALU": 0, "SALU": 0, "SMEM": 0, "branch": 0, "s_nop": 0, "other": 0, "stub_entries": 0}
         pc, steps = 0, 0
         while pc < len(self.prog):
@@ -181,6 +186,11 @@ class Emulator:
                 if a[0] == "vcc":
                     self.vcc = r
                 self.scc = 1 if r else 0
+            elif op == "s_or_b64":
+                self.counts["SALU"] += 1
+                r = self._r64(a[1]) | self._r64(a[2])
+                self._w64(a[0], r)
+                self.scc = 1 if r else 0
             elif op in ("s_cbranch_scc1", "s_branch"):
                 self.counts["branch"] += 1
                 if op == "s_branch" or self.scc:
@@ -205,7 +215,31 @@ class Emulator:
                 self.counts["other"] += 1
             else:
                 raise StreamError("instruction %r is not modelled" % op)
-        return [self.v[2 * k] | (self.v[2 * k + 1] << 32) for k in range(12)]
+
+
+def bind_sequence(lines, inputs32, outputs64, sgpr_pairs):
+    """An inline-asm sequence with %[name] operands (tools/gen_gl_asm.py) as a program over concrete registers: 32-bit inputs
+    get v0.., 64-bit outputs the even pairs above them, mask operands scalar pairs.  Returns (Emulator, name -> register)."""
+    regs, nv = {}, 0
+    for n in inputs32:
+        regs[n] = "v%d" % nv
+        nv += 1
+    nv += nv % 2
+    for n in outputs64:
+        regs[n] = "v[%d:%d]" % (nv, nv + 1)
+        nv += 2
+    for i, n in enumerate(sgpr_pairs):
+        regs[n] = "s[%d:%d]" % (2 * i, 2 * i + 1)
+    bound = []
+    for l in lines:
+        for n, r in regs.items():
+            l = l.replace("%%[%s]" % n, r)
+        if "%[" in l:
+            raise StreamError("unbound operand in %r" % l)
+        bound.append(l)
+    e = Emulator(bound, [])
+    e.v, e.s, e.vcc, e.scc = [0xDEADBEEF] * 256, [0xDEADBEEF] * 128, 0, 0
+    return e, regs
 
 
 def build(env=None):
