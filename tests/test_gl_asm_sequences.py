@@ -94,3 +94,26 @@ def test_two_add_sub_pairs_side_by_side():
             assert _get64(e, regs["sb"]) % P == (ub + vb) % P and _get64(e, regs["db"]) % P == (ub - vb) % P
     assert finished > 1000
     assert raised > 0                                           # words within 2^33 of 2^64 / of 0 wrap twice: the mask says so
+
+
+def test_the_inline_product_of_gl_h():
+    """gl::mul_weak (csrc/gl.h, hand-written inline assembly, the product every kernel but the generated streams uses): complete
+    by itself — the borrow-without-carry case is finished behind its wave-uniform branch — so the result must be congruent to
+    a * b for ANY operands, the rare-product fixture included."""
+    src = open(os.path.join(ROOT, "era_boojum_amd", "csrc", "gl.h")).read()
+    lines = EM.asm_lines_of(src, "__device__ __forceinline__ u64 mul_weak(u64 a, u64 b)")
+    assert len(lines) == 23 and lines[0].startswith("v_mad_u64_u32") and lines[-1].startswith("v_mad_u64_u32 %[out]")
+    e, regs = EM.bind_sequence(lines, ["a0", "a1", "b0", "b1"], ["out"], ["cm", "c"])
+    with open(os.path.join(ROOT, "tests", "golden", "gl_mul_rare.json")) as f:
+        rare = [(v["a"], v["b"]) for v in json.load(f)["vectors"]]
+    w = _words()
+    pairs = [(a, b) for a in w for b in w[::2]] + rare + [(b, a) for a, b in rare]
+    slow = 0
+    for a, b in pairs:
+        for n, val in (("a", a), ("b", b)):
+            lo, hi = regs[n + "0"], regs[n + "1"]
+            e.v[int(lo[1:])], e.v[int(hi[1:])] = val & 0xFFFFFFFF, val >> 32
+        e.execute()
+        slow += e.counts["VALU"] > 15                           # the three extra instructions of the rare path
+        assert _get64(e, regs["out"]) % P == a * b % P, (a, b)
+    assert slow >= 6                                            # the class-1 vectors, both operand orders

@@ -191,6 +191,10 @@ class Emulator:
                 r = self._r64(a[1]) | self._r64(a[2])
                 self._w64(a[0], r)
                 self.scc = 1 if r else 0
+            elif op == "s_cbranch_vccz":
+                self.counts["branch"] += 1
+                if self.vcc == 0:
+                    pc = self.labels[a[0]]
             elif op in ("s_cbranch_scc1", "s_branch"):
                 self.counts["branch"] += 1
                 if op == "s_branch" or self.scc:
@@ -215,6 +219,26 @@ class Emulator:
                 self.counts["other"] += 1
             else:
                 raise StreamError("instruction %r is not modelled" % op)
+
+
+def asm_lines_of(source_text, function_name):
+    """The instruction lines of the first asm(...) statement inside `function_name` in a C++ source: the string literals of the
+    template joined, split at the "\n\t" separators."""
+    i = source_text.index(function_name)
+    j = source_text.index("asm(", i)
+    lines, pos = [], j
+    while True:
+        q0 = source_text.index('"', pos)
+        if source_text[pos:q0].strip(" \n\tasm(") .startswith(":"):
+            break
+        q1 = source_text.index('"', q0 + 1)
+        lines.append(source_text[q0 + 1:q1])
+        pos = q1 + 1
+        rest = source_text[pos:].lstrip()
+        if rest.startswith(":"):
+            break
+    text = "".join(lines).replace("\\t", "")
+    return [l.strip() for l in text.split("\\n") if l.strip()]
 
 
 def bind_sequence(lines, inputs32, outputs64, sgpr_pairs):
