@@ -117,3 +117,21 @@ def test_the_inline_product_of_gl_h():
         slow += e.counts["VALU"] > 15                           # the three extra instructions of the rare path
         assert _get64(e, regs["out"]) % P == a * b % P, (a, b)
     assert slow >= 6                                            # the class-1 vectors, both operand orders
+
+
+def test_no_scheduled_sequence_reads_a_mask_too_early():
+    """tools/hazard_lint.py: two wait states between a VALU write of a scalar pair / vcc and a VALU read of it, in the Poseidon2
+    stream under every generator option, the butterfly sequences and gl::mul_weak; and the check does flag a sequence that has
+    lost one of its s_nop."""
+    import hazard_lint as HL
+    seqs = HL.all_sequences()
+    assert len(seqs) >= 9
+    for name, (lines, scal) in seqs.items():
+        assert HL.lint(lines, scal) == [], name
+    lines, scal = seqs["gl::mul_weak"]
+    broken = [l for l in lines if l != "s_nop 0"]
+    assert len(broken) == len(lines) - 1
+    assert HL.lint(broken, scal)
+    lines, scal = seqs["poseidon2 default"]
+    i = next(k for k, l in enumerate(lines) if l.startswith("s_nop"))
+    assert HL.lint(lines[:i] + lines[i + 1:], scal)
