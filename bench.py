@@ -45,6 +45,31 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, through torch.distributed.run
+    (the command the driver uses for N > 1) on a free local port, and hand its exit code back.  Fewer than N visible devices is
+    an error — never a silent single-GPU run — unless BJ_BENCH_BACKEND=gloo asks for the functional mode in which ranks share
+    GPUs."""
+    import socket
+    import subprocess
+    if os.environ.get("BJ_BENCH_BACKEND", "nccl") != "gloo":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n_ranks:
+            print("bench.py --gpus %d: only %d GPU(s) visible; refusing to run on fewer devices than asked "
+                  "(BJ_BENCH_BACKEND=gloo runs the ranks on shared GPUs as a functional check)" % (n_ranks, have), file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +91,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ and ("TORCHELASTIC_RUN_ID" in os.environ or int(os.environ["WORLD_SIZE"]) > 1)
+    if args.gpus > 1 and not launched:
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -76,7 +106,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -220,7 +250,7 @@ def main():
         "metric": "prover_constraints_per_sec",
         "value": round(value, 1),
         "unit": "rows/s",
-        "n_gpus": world,
+        "n_gpus": dist.get_world_size() if dist is not None else 1,      # what the process group reports, not what was asked
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -255,7 +285,7 @@ def main():
         cm = torch.tensor([comm_ms_acc / args.steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         cmax = cm.clone()
         dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
-        out["comm"] = {"calls_per_proof": int(comm_calls), "mb_received_per_rank_per_proof": round(comm_mb, 2),
+        out["comm"] = {"world": int(comm.world), "calls_per_proof": int(comm_calls), "mb_received_per_rank_per_proof": round(comm_mb, 2),
                         "ms_in_collectives_rank0": round(float(cm[0]), 3), "ms_in_collectives_max_rank": round(float(cmax[0]), 3),
                         "note": "time between the start and the end of each all-gather on the proof's stream (transfer + waiting for "
                                 "the slowest peer), summed over a proof; replicated main-domain work is ~21 ms per rank (DESIGN.md §6)",

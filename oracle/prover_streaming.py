@@ -33,9 +33,16 @@ def _coset_caps(mono, n, log_L, fri_lde, cap_size, threads, cosets=None):
 
 
 def commitments_and_openings(circuit, setup_cap, fri_lde_factor=8, cap_size=16, threads=1, transcript_kind=1,
-                             check_setup_cosets=(0,)):
+                             check_setup_cosets=(0,), cap_cosets=None, claimed_caps=None):
     """Returns the dict of proof fields listed above plus "setup_cap_fragments" {coset: cap nodes} for `check_setup_cosets`
-    (the transcript absorbs the caller's `setup_cap`; hashing all of the setup oracle again is the caller's choice)."""
+    (the transcript absorbs the caller's `setup_cap`; hashing all of the setup oracle again is the caller's choice).
+
+    `cap_cosets` (with `claimed_caps` = {"witness_oracle_cap" | "stage_2_oracle_cap" | "quotient_oracle_cap": nodes} from the
+    proof under check): hash only those cosets of the witness and second-stage oracles — at 2^23 rows a coset of the witness
+    oracle is 10^8 permutations — and let the transcript absorb the CLAIMED caps of those two oracles; the recomputed subtree roots come back in
+    out["cap_fragments"][name][coset] for the caller to compare with the claimed nodes.  Every challenge then is the one the
+    proof under check used, and every value at z / z*omega / 0 is still recomputed from the witness alone.  The quotient
+    oracle (one permutation per leaf) is always hashed in full."""
     c = circuit
     n, log_n, V, q = c.n, c.log_n, c.num_vars, c.quotient_degree
     assert all(g.kind < 5 for g in c.gates) and not getattr(c, "specialized_gates", None) and not getattr(c, "num_witness_cols", 0)
@@ -49,9 +56,12 @@ def commitments_and_openings(circuit, setup_cap, fri_lde_factor=8, cap_size=16, 
     t.absorb_cap(np.asarray(setup_cap, dtype=np.uint64))                  # prover.rs:211
     pub_vals = [v for (_, _, v) in c.public_inputs]
     t.absorb(pub_vals)
-    out = {"public_inputs": pub_vals}
+    out = {"public_inputs": pub_vals, "cap_fragments": {}}
 
-    def full_cap(mono, log_lde_used):
+    def full_cap(mono, log_lde_used, name=None):
+        if cap_cosets is not None and name is not None:
+            out["cap_fragments"][name] = _coset_caps(mono, n, log_lde_used, fri_lde_factor, cap_size, threads, cap_cosets)
+            return np.asarray(claimed_caps[name], dtype=np.uint64).reshape(cap_size, 4)
         frag = _coset_caps(mono, n, log_lde_used, fri_lde_factor, cap_size, threads)
         return np.concatenate([frag[k] for k in range(fri_lde_factor)])
 
@@ -61,7 +71,7 @@ def commitments_and_openings(circuit, setup_cap, fri_lde_factor=8, cap_size=16, 
     out["setup_cap_fragments"] = _coset_caps(setup_mono, n, log_L, fri_lde_factor, cap_size, threads, check_setup_cosets)
     # round 1: witness oracle, leaf = variables || multiplicities  (prover.rs:270-353)
     wit_mono = O.ifft_batch(np.concatenate([c.variables] + ([c.multiplicities] if has_lookup else []), axis=0), 1, threads)
-    wit_cap = full_cap(wit_mono, log_L)
+    wit_cap = full_cap(wit_mono, log_L, "witness_oracle_cap")
     t.absorb_cap(wit_cap)
     # round 2: copy permutation + lookup polynomials on the main domain  (prover.rs:360-554)
     beta, gamma = t.challenge_ext(), t.challenge_ext()
@@ -76,7 +86,7 @@ def commitments_and_openings(circuit, setup_cap, fri_lde_factor=8, cap_size=16, 
         stage2 += [A_nat[i][k] for i in range(c.lookup_reps) for k in range(2)] + [B_nat[0], B_nat[1]]
     s2_mono = O.ifft_batch(np.stack(stage2), 1, threads)
     del stage2, z_nat, partials_nat
-    s2_cap = full_cap(s2_mono, log_L)
+    s2_cap = full_cap(s2_mono, log_L, "stage_2_oracle_cap")
     t.absorb_cap(s2_cap)
     # round 3: the quotient on the first q cosets, one coset at a time  (prover.rs:560-1495)
     alpha = t.challenge_ext()

@@ -229,19 +229,35 @@ def test_prover_checks_public_values_against_the_witness():
     gsetup.close()
 
 
-@pytest.mark.timeout(300)
-def test_proof_at_2p23_rows_is_accepted_by_the_verifier_restatement():
-    """BASELINE config 5's size (2^23 rows, LDE 8 => 2^26-point oracles): the verifier restatement accepts the proof, public
-    inputs included (their DEEP opening sets run over all 2^26 points; one of those launches lost a loop's exit test to an
-    undeclared SCC write until round 2, tests/test_gpu_openings.py)."""
+@pytest.mark.timeout(900)
+def test_proof_at_2p23_rows_equals_the_streaming_oracle():
+    """BASELINE config 5's size (2^23 rows, LDE 8 => 2^26-point oracles), prover.rs:153-168.  The coset-streaming restatement
+    (oracle/prover_streaming.py) recomputes from the witness alone: the cap nodes of cosets {0, 5} of the witness and
+    second-stage oracles (a coset of the witness oracle is 10^8 permutations on the host: all eight would not fit the suite),
+    the WHOLE quotient cap, and all 241 values at z, z*omega and 0 under the challenges of the HIP proof's transcript; all of
+    them must equal the HIP proof's.  The verifier restatement then accepts the rest (DEEP, FRI, queries; public inputs
+    included — their DEEP opening sets run over all 2^26 points; one of those launches lost a loop's exit test to an undeclared
+    SCC write until round 2, tests/test_gpu_openings.py)."""
+    from oracle import prover_streaming as PS
     c = S.sha_shaped_circuit(23, seed=42, table_bits=4)
     setup = E.ProverSetup(ctx(), c, 8, 16, 100)
     d_vars, d_mult = ctx().upload(c.variables), ctx().upload(c.multiplicities)
     buf, stage_ms = setup.prove_dev(d_vars, d_mult)
     assert sum(v for k, v in stage_ms.items() if k != "witness_tree_leaf_kernel") < 5000.0      # ms; the regression took 500 s
-    pg = proof_format.parse(buf, security_level=100)
-    assert OV.verify(OV.VerificationKey(c, setup.cap(), 8, 16), pg, verbose=True)
+    cap = setup.cap()
     setup.close()
     ctx().free(d_vars)
     ctx().free(d_mult)
     ctx().release_workspace()      # ~150 GB of arena: give it back before the multi-process tests share this GPU
+    pg = proof_format.parse(buf, security_level=100)
+    assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg, verbose=True)
+    claimed = {k: pg[k] for k in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap")}
+    po = PS.commitments_and_openings(c, cap, 8, 16, threads=64, transcript_kind=1, check_setup_cosets=(5,), cap_cosets=(0, 5),
+                                     claimed_caps=claimed)
+    for k in ("public_inputs", "quotient_oracle_cap", "values_at_z", "values_at_z_omega", "values_at_0"):
+        assert pg[k] == po[k], k
+    for name in ("witness_oracle_cap", "stage_2_oracle_cap"):
+        for cs, frag in po["cap_fragments"][name].items():
+            assert np.array_equal(frag, np.asarray(pg[name], dtype=np.uint64)[2 * cs:2 * cs + 2]), (name, cs)
+    for cs, frag in po["setup_cap_fragments"].items():
+        assert np.array_equal(frag, cap[2 * cs:2 * cs + 2]), "setup cap nodes of coset %d" % cs

@@ -53,13 +53,15 @@ def test_hip_proof_of_the_8_kib_bench_circuit_verifies(transcript):
     gsetup.close()
 
 
-@pytest.mark.parametrize("transcript,kind", [("poseidon2", 1), ("poseidon", 2)])
+@pytest.mark.parametrize("transcript,kind", [("poseidon2", 1), ("poseidon", 2), ("blake2s", 3)])
 def test_hip_proof_of_the_8_kib_bench_circuit_equals_oracle_proof(transcript, kind):
-    """BASELINE config 1's circuit (8 KiB, 2^16 rows, LDE 8, cap 16, security 100) under both transcripts the bench offers:
-    every cap, opening, FRI layer and query of the HIP proof equals the oracle prover's (not only "verifier accepts")."""
+    """BASELINE config 1's circuit (8 KiB, 2^16 rows, LDE 8, cap 16, security 100) under both transcripts the bench offers
+    and under cfg1's exact pairing — Blake2s tree hasher + Blake2s transcript, `run_sha256_prover_non_recursive`
+    (sha256/mod.rs:265-270): every cap, opening, FRI layer and query of the HIP proof equals the oracle prover's (not only
+    "verifier accepts")."""
     c = S.sha256_circuit(S.bench_message(8 << 10))
     assert c.log_n == 16
-    osetup = OP.Setup(c, 8, 16, threads=32)
+    osetup = OP.Setup(c, 8, 16, threads=32, hasher=2 if kind == 3 else 1)
     po = OP.prove(c, osetup, 8, 16, security_level=100, threads=32, transcript_kind=kind)
     gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript=transcript)
     assert np.array_equal(gsetup.cap(), osetup.cap)

@@ -126,3 +126,36 @@ def test_in_library_rccl_transport_world_1():
     comm.close()
     for d in (d_s, d_r, d_r2):
         d.free()
+
+
+def test_plain_bench_command_with_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2 …` with NO launcher around it (the shape of the driver's N = 1 command) starts two ranks by
+    itself: the JSON line reports the world size of the process group, the sharded proof went through collectives and rank 0's
+    verifier restatement accepted it.  gloo backend: the two ranks share this box's one GPU (functional check)."""
+    import json
+    env = dict(os.environ, BJ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--log-n", "16", "--steps", "2",
+           "--warmup", "1", "--no-ntt", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["comm"]["world"] == 2 and out["comm"]["calls_per_proof"] > 0 and out["comm"]["mb_received_per_rank_per_proof"] > 0
+    assert "accepts" in out["config"]["verified"]
+
+
+def test_plain_bench_command_refuses_more_gpus_than_visible():
+    """Without the functional gloo mode, asking for more devices than the box has is an error — never a silent single-GPU run
+    that prints n_gpus 1."""
+    import torch
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "BJ_BENCH_BACKEND"):
+        env.pop(k, None)
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(want), "--log-n", "14",
+                        "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())

@@ -91,3 +91,25 @@ def test_coset_streaming_restatement_equals_the_full_prover(small_case):
         for cs, frag in got["setup_cap_fragments"].items():
             assert np.array_equal(frag, setup.cap[2 * cs:2 * cs + 2])
     assert got["challenges"]["z"] != aux["z"]      # the other transcript draws other challenges: the comparison above is not vacuous
+
+
+def test_coset_streaming_restatement_with_claimed_caps(small_case):
+    """The cfg5 mode (2^23 rows): only cosets {0, 5} of the witness and second-stage oracles are hashed, the transcript absorbs
+    the caps of the proof under check, the recomputed subtree roots are returned for comparison and every opening is still
+    recomputed.  A proof with one wrong cap node is told apart: its fragment differs, and so does everything drawn after it."""
+    from oracle import prover_streaming as PS
+    c, setup, proof, aux, vk = small_case
+    claimed = {k: proof[k] for k in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap")}
+    got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, cap_cosets=(0, 5), claimed_caps=claimed)
+    for k in ("quotient_oracle_cap", "values_at_z", "values_at_z_omega", "values_at_0"):
+        assert got[k] == proof[k], k
+    for name in ("witness_oracle_cap", "stage_2_oracle_cap"):
+        assert sorted(got["cap_fragments"][name]) == [0, 5]
+        for cs, frag in got["cap_fragments"][name].items():
+            assert np.array_equal(frag, np.asarray(proof[name], dtype=np.uint64)[2 * cs:2 * cs + 2]), (name, cs)
+    bad = dict(claimed)
+    bad["witness_oracle_cap"] = [list(x) for x in claimed["witness_oracle_cap"]]
+    bad["witness_oracle_cap"][10][1] ^= 1
+    got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, cap_cosets=(5,), claimed_caps=bad)
+    assert not np.array_equal(got["cap_fragments"]["witness_oracle_cap"][5], np.asarray(bad["witness_oracle_cap"], dtype=np.uint64)[10:12])
+    assert got["values_at_z"] != proof["values_at_z"]
