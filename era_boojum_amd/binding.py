@@ -11,6 +11,7 @@ u64p = C.POINTER(C.c_uint64)
 # every symbol include/boojum_hip.h declares (checked by tests/test_abi_symbols.py against the header text)
 _SIGNATURES = {
     "bj_abi_version": (C.c_int, []),
+    "bj_env_reload": (None, []),
     "bj_device_count": (C.c_int, []),
     "bj_status_string": (C.c_char_p, [C.c_int]),
     "bj_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),

@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -123,6 +125,44 @@ u64 *arena_alloc(bj_ctx *ctx, size_t elems) {
     return ctx->arena + start;
 }
 
+
+namespace {
+EnvConfig g_env;
+std::once_flag g_env_once;
+void load_env() {
+    EnvConfig e;
+    auto set = [](const char *name) { return getenv(name) != nullptr; };
+    auto str = [](const char *name) { const char *v = getenv(name); return std::string(v ? v : ""); };
+    e.ntt_first_narrow = set("BJ_NTT_FIRST_NARROW");
+    e.ntt_generic = str("BJ_NTT_GENERIC").rfind("1", 0) == 0;
+    e.ntt_generic_remainder = set("BJ_NTT_GENERIC_REMAINDER");
+    e.bitrev_gather = set("BJ_BITREV_GATHER");
+    if (set("BJ_NTT_FRONT")) e.ntt_front = atoi(getenv("BJ_NTT_FRONT"));
+    e.ntt_first4_v = str("BJ_NTT_FIRST4_V").rfind("1", 0) == 0 ? 1 : 2;
+    e.ntt_inv_fused = str("BJ_NTT_INV_FUSED").rfind("0", 0) != 0;
+    e.gate_no_aot = set("BJ_GATE_NO_AOT");
+    e.gate_no_fuse = set("BJ_GATE_NO_FUSE");
+    e.gate_no_jit = set("BJ_GATE_NO_JIT");
+    e.gates_windowed = str("BJ_GATES_WINDOWED").rfind("0", 0) != 0;
+    e.prove_no_absorb = set("BJ_PROVE_NO_ABSORB");
+    if (set("BJ_PROVE_H2D_GROUP")) {
+        const unsigned v = (unsigned)strtoul(getenv("BJ_PROVE_H2D_GROUP"), nullptr, 10);
+        e.prove_h2d_group = v ? v : 8u;
+    }
+    if (set("BJ_NODES_LANEPAR_MAX")) e.nodes_lanepar_max = (size_t)strtoull(getenv("BJ_NODES_LANEPAR_MAX"), nullptr, 10);
+    e.jit_cache_dir = str("BJ_GATE_JIT_CACHE");
+    e.rccl_lib = str("BJ_RCCL_LIB");
+    g_env = e;
+}
+}  // namespace
+const EnvConfig &env() {
+    std::call_once(g_env_once, load_env);
+    return g_env;
+}
+void env_reload() {
+    (void)env();
+    load_env();
+}
 }  // namespace bj
 
 using bj::bind;
@@ -154,9 +194,12 @@ const char *bj_status_string(int status) {
     }
 }
 
+void bj_env_reload(void) { bj::env_reload(); }
+
 int bj_ctx_create(int device, bj_ctx **out) {
     if (!out) return BJ_ERR_INVALID_ARG;
     *out = nullptr;
+    (void)bj::env();      // the one place the environment is read
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BJ_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return BJ_ERR_INVALID_ARG;

@@ -30,7 +30,8 @@ Api &api() {
     static Api a;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *env = getenv("BJ_RCCL_LIB");
+        const std::string rccl_lib = bj::env().rccl_lib;
+        const char *env = rccl_lib.empty() ? nullptr : rccl_lib.c_str();
         const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char *nm : names) {
             if (!nm || !*nm) continue;

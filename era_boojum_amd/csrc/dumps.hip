@@ -93,11 +93,15 @@ bool read_tree(Reader &r, std::vector<unsigned char> &prefix, TreeWalk *w, int d
     if (tag == 0) return true;
     if (tag == 1) {
         const uint64_t idx = r.u64v();
-        r.u64v();   // num_constants
+        const uint64_t num_constants = r.u64v();
         const uint64_t degree = r.u64v();
         r.u8v();    // needs_selector
         const unsigned char is_lookup = r.u8v();
         if (!r.ok) return (w->err = "truncated GateDescription"), false;
+        // untrusted sizes: a gate of degree 2^16 or with 2^16 constants does not exist (the quotient degree derived from them
+        // below is at most 16 here); without the bound a crafted degree wrapped the sum / never ended the doubling loop
+        if (degree > (1u << 16) || num_constants > (1u << 16))
+            return (w->err = "GateDescription with a degree or constant count above 2^16"), false;
         if (is_lookup) return (w->err = "a lookup placed through the selector tree (general-purpose-column lookups) is not supported"), false;
         if (idx >= w->path.size() || w->seen[idx]) return (w->err = "selector tree names a gate index the circuit does not have (or twice)"), false;
         w->seen[idx] = 1;
@@ -191,11 +195,23 @@ static bool parse_setup_dump(const void *setup_base, size_t setup_base_len, size
     return true;
 }
 
+// quotient degree from the selector tree: the power of two covering max (depth + degree) - 1 (setup.rs:560-600).  64-bit with a
+// cap: `max_degree` comes from the dump (read_tree bounds every term, this loop must end whatever it is handed)
+static bool quotient_degree_from_tree(uint64_t max_degree, unsigned *q_out) {
+    uint64_t q = 1;
+    while (q + 1 < max_degree && q <= 64) q *= 2;
+    if (q > 64) return false;
+    *q_out = (unsigned)q;
+    return true;
+}
+
 extern "C" int bj_setup_dump_info(const void *setup_base, size_t setup_base_len, uint64_t *info8) {
     if (!setup_base || !info8) return BJ_ERR_INVALID_ARG;
     ParsedSetup P;
     std::string err;
     if (!parse_setup_dump(setup_base, setup_base_len, 4096, &P, &err)) return BJ_ERR_INVALID_ARG;
+    unsigned q = 0;      // the derived quotient degree must exist: the same host-side steps bj_setup_create_from_dump runs
+    if (!quotient_degree_from_tree(P.walk.max_degree, &q)) return BJ_ERR_INVALID_ARG;
     size_t gates = 0, longest = 0;
     for (size_t g = 0; g < P.walk.seen.size(); g++)
         if (P.walk.seen[g]) {
@@ -246,9 +262,9 @@ int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void
     }
     c.gates = gates.data();
     if (c.quotient_degree == 0) {   // quotient degree: the power of two covering max (depth + degree) - 1 (setup.rs:560-600)
-        unsigned q = 1;
-        while (q + 1 < walk.max_degree) q *= 2;
-        c.quotient_degree = q;
+        if (!quotient_degree_from_tree(walk.max_degree, &c.quotient_degree))
+            return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "SetupBaseStorage dump: selector depth + gate degree %llu asks for a quotient "
+                                                     "degree above 64", (unsigned long long)walk.max_degree);
     }
     std::vector<u64> nr;
     if (!c.non_residues) {

@@ -176,7 +176,7 @@ static ProgArgs make_prog_args(const DevProgram &P, const u64 *d_vars, size_t va
 void launch_gate_programs(const GateLaunch *gates, unsigned n, const u64 *d_vars, size_t var_stride, const u64 *d_consts,
                           size_t const_stride, size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s, const u64 *d_wits) {
     if (!Q || !n) return;
-    static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr, no_fuse = getenv("BJ_GATE_NO_FUSE") != nullptr;
+    const bool no_aot = bj::env().gate_no_aot, no_fuse = bj::env().gate_no_fuse;
     std::vector<unsigned> fused;
     if (!no_aot && !no_fuse)
         for (unsigned i = 0; i < n; i++) {
@@ -214,7 +214,7 @@ void launch_gate_program(const DevProgram &P, const u64 *d_vars, size_t var_stri
                                       rep_const_stride, d_alphas, Q, d_out0, d_out1, d_terms, d_wits, rep_wit_stride);
     if (!Q) return;
     const dim3 grid((unsigned)((Q + 255) / 256)), block(256);
-    static const bool no_aot = getenv("BJ_GATE_NO_AOT") != nullptr;
+    const bool no_aot = bj::env().gate_no_aot;
     if (!no_aot && launch_gate_aot(P.fp[0], P.fp[1], a, grid.x, s)) return;   // a build-time generated straight-line kernel
     // the reference's own capture of the Poseidon2 flattened gate: the hand-written evaluator (quotient mode, one repetition)
     if (!no_aot && d_alphas && !d_terms && reps == 1 && gate_is_poseidon2_flattened(P.fp[0], P.fp[1])) {

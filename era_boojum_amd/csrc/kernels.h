@@ -4,9 +4,30 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string>
 
 namespace bj {
 typedef uint64_t u64;
+
+// The environment switches of DESIGN.md §3 (A/B plans and test hooks; none changes a result), read ONCE — by the first
+// bj_ctx_create of the process, under std::call_once — and never again on a proof path: no getenv races with a host thread's
+// setenv, no per-proof lookups, and every context of a process (one per GPU, each on its own host thread) sees the same plan.
+// bj_env_reload() re-reads them for tests that exercise both sides of a switch in one process (not thread-safe by contract).
+struct EnvConfig {
+    bool ntt_first_narrow = false, ntt_generic = false, ntt_generic_remainder = false, bitrev_gather = false;
+    int ntt_front = 4;                  // BJ_NTT_FRONT: 0 remainder passes only, 5 first5 wherever it applies, default 4
+    int ntt_first4_v = 2;               // BJ_NTT_FIRST4_V: indices per lane of the four-round front pass
+    bool ntt_inv_fused = true;          // BJ_NTT_INV_FUSED=0: inverse transforms end in the separate bit-reversal sweep
+    bool gate_no_aot = false, gate_no_fuse = false, gate_no_jit = false;
+    bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
+    bool prove_no_absorb = false;
+    unsigned prove_h2d_group = 8;
+    size_t nodes_lanepar_max = 16384;
+    std::string jit_cache_dir, rccl_lib;
+};
+const EnvConfig &env();
+void env_reload();
+
 
 // ntt.hip
 void launch_twiddles(u64 *d_out, unsigned log_n, bool inverse, hipStream_t s);

@@ -221,7 +221,7 @@ static void launch_first_rounds(const u64 *src, u64 *d_out, const u64 *d_tw, con
     const size_t quarter = ((size_t)1 << log_n) >> R;
     // two indices per lane need 16-byte aligned columns and an even slice
     const bool wide = quarter % 512 == 0 && src_col_stride % 2 == 0 && src_coset_stride % 2 == 0 && out_col_stride % 2 == 0 &&
-                      ((uintptr_t)src % 16) == 0 && ((uintptr_t)d_out % 16) == 0 && !getenv("BJ_NTT_FIRST_NARROW");
+                      ((uintptr_t)src % 16) == 0 && ((uintptr_t)d_out % 16) == 0 && !bj::env().ntt_first_narrow;
     dim3 grid((unsigned)((quarter / (wide ? 2 : 1) + 255) / 256), n_cols, 1);
     if (wide) {
         if (R == 1)
@@ -254,14 +254,7 @@ static void launch_generic_pass(const u64 *src, u64 *d_out, const u64 *d_tw, con
     hipLaunchKernelGGL(ntt_pass_generic_kernel, dim3(tiles, n_cols, n_cosets), dim3(tpb), lds, s, a);
 }
 
-static bool force_generic() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("BJ_NTT_GENERIC");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
-}
+static bool force_generic() { return bj::env().ntt_generic; }
 
 // Pass plan.  log_n < 12 (or BJ_NTT_GENERIC=1): generic LDS passes.  Otherwise the last 12 rounds run in
 // ntt_local12, the rounds in front of it in radix-16 strided passes of 8 or 4 rounds, and a remainder of 1..3
@@ -306,10 +299,7 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
     // 14 + 4k and 15 + 4k rounds: the coset-expanding front pass is bound by its traffic whatever it computes, so it takes four
     // or five rounds (ntt_first4 / ntt_first5) and the local pass runs ten or nine instead of twelve — the same number of passes,
     // butterflies moved into idle VALU slots.  13 + 4k rounds keep the remainder pass of one round.
-    static const int front_policy = [] {
-        const char *e = getenv("BJ_NTT_FRONT");      // 0: remainder passes only (the round-1 plan); 5: first5 wherever it applies; default: measured best
-        return e ? atoi(e) : 4;
-    }();
+    const int front_policy = bj::env().ntt_front;   // 0: remainder passes only (the round-1 plan); 5: first5 wherever it applies; default: measured best
     const bool aligned16 = ((uintptr_t)d_in % 16) == 0 && ((uintptr_t)d_out % 16) == 0 && in_col_stride % 2 == 0 &&
                            out_col_stride % 2 == 0;
     unsigned F = 0, Lr = 12;
@@ -347,7 +337,7 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
     }
     if (front % 4) {
         unsigned R = front % 4;
-        static const bool old_remainder = getenv("BJ_NTT_GENERIC_REMAINDER") != nullptr;
+        const bool old_remainder = bj::env().ntt_generic_remainder;
         if (!old_remainder && n_cosets <= 64)
             launch_first_rounds(src, d_out, d_tw, d_round_scale, log_n, R, n_cols, n_cosets, src_col_stride,
                                 src_coset_stride, out_col_stride, s);
@@ -434,7 +424,7 @@ void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s) {
     size_t n = (size_t)1 << log_n;
     unsigned tpb = 256;
-    if (log_n >= 10 && !getenv("BJ_BITREV_GATHER")) {
+    if (log_n >= 10 && !bj::env().bitrev_gather) {
         BitrevPowers pw{};
         const int stepped = step != 1;
         if (stepped) {

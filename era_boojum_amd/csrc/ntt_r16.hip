@@ -453,10 +453,7 @@ void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
     R16Args a{in, out, tw, round_scale, log_n, 0, n_cols, 1, in_col_stride, in_coset_stride, out_col_stride};
     const size_t sl = ((size_t)1 << log_n) >> 4;
     // two adjacent indices per lane (16-byte accesses, 206 VGPRs: 2 waves per SIMD) or one (8-byte accesses, 4 waves)
-    static const int v = [] {
-        const char *e = getenv("BJ_NTT_FIRST4_V");
-        return e && e[0] == '1' ? 1 : 2;
-    }();
+    const int v = bj::env().ntt_first4_v;
     dim3 grid((unsigned)((sl / v + 255) / 256), n_cols, 1);
     if (v == 2) {
         if (round_scale)

@@ -462,11 +462,7 @@ __global__ void poseidon2_permute_states_kernel(u64 *states, size_t n_states) {
 }
 
 static size_t nodes_lanepar_max() {   // layers up to this many parents use the lane-parallel kernel (BJ_NODES_LANEPAR_MAX=0: never)
-    static const size_t v = [] {
-        const char *e = getenv("BJ_NODES_LANEPAR_MAX");
-        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)16384;
-    }();
-    return v;
+    return bj::env().nodes_lanepar_max;
 }
 void launch_poseidon2_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
                              size_t num_leaves, u64 *d_digests, hipStream_t s) {

@@ -648,7 +648,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         // kernel — runs under the transfer of the later groups instead of after the last one has landed.
         unsigned G = hw->group;
         if ((nW + G - 1) / G > 64) G = (nW + 63) / 64;
-        const bool absorb = ctx->hasher == BJ_HASHER_POSEIDON2 && getenv("BJ_PROVE_NO_ABSORB") == nullptr;
+        const bool absorb = ctx->hasher == BJ_HASHER_POSEIDON2 && !bj::env().prove_no_absorb;
         if (absorb) G = (G + 7) / 8 * 8;
         const unsigned n_groups = (nW + G - 1) / G;
         ArenaBuf capacity;
@@ -989,9 +989,9 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     bool deep_written = false;
     auto flush_deep = [&]() -> int {
         while (!pending.empty()) {
-            bj::DeepSetHost hs[3];
+            bj::DeepSetHost hs[bj::DEEP_MAX_SETS];
             unsigned cnt = 0;
-            for (auto it = pending.begin(); it != pending.end() && cnt < 3; ++it, ++cnt)
+            for (auto it = pending.begin(); it != pending.end() && cnt < (unsigned)bj::DEEP_MAX_SETS; ++it, ++cnt)
                 hs[cnt] = bj::DeepSetHost{it->p0.data(), it->p1.data(), it->p0.size(), it->vals.data(), it->ch.data(), it->at};
             int r = bj::deep_accumulate_multi(ctx, hs, cnt, log_n, S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p, deep.p + N,
                                               deep_written ? 1 : 0);
@@ -1286,11 +1286,7 @@ int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const 
         BJ_HIP(ctx, hipMalloc((void **)&ctx->wit_stage, need * 8));
         ctx->wit_stage_elems = need;
     }
-    static const unsigned group = [] {
-        const char *e = getenv("BJ_PROVE_H2D_GROUP");
-        const unsigned v = e ? (unsigned)strtoul(e, nullptr, 10) : 8u;
-        return v ? v : 8u;
-    }();
+    const unsigned group = bj::env().prove_h2d_group;
     const HostWitness hw{h_variables, h_multiplicities, group};
     // the copies are queued inside the proof (after the workspace is reserved); a previous proof on this context has drained
     return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + (size_t)(S->V + S->Wc) * n, h_public_values, out, &hw);

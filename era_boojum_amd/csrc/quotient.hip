@@ -388,8 +388,7 @@ void launch_quotient_gates(const u64 *d_vars, size_t var_stride, const u64 *d_co
         gs.g[g] = GateDev{f[0], f[1], f[2], f[3], f[4], f[5], {f[6], f[7], f[8], f[9], f[10], f[11]}};
     }
     {   // the windowed kernel when the hand-written kinds appear at most once each with their principal widths
-        const char *env = getenv("BJ_GATES_WINDOWED");   // read per call: "0" selects the per-gate kernel (the tests run both)
-        const bool windowed_on = !(env && env[0] == '0');
+        const bool windowed_on = bj::env().gates_windowed;   // BJ_GATES_WINDOWED=0 selects the per-gate kernel (the tests run both)
         GateWindows gw{};
         const int width[4] = {0, 1, 4, 5};
         bool ok = windowed_on && n_gates <= (unsigned)BJ_MAX_GATES;

@@ -48,6 +48,10 @@ int bj_abi_version(void);
 int bj_device_count(void);
 const char *bj_status_string(int status);
 
+/* The optional BJ_* environment switches (A/B pass plans, test hooks; none changes a result — DESIGN.md §3) are read once, by
+ * the first bj_ctx_create of the process; nothing on a proof path calls getenv.  bj_env_reload() reads them again (tests that
+ * exercise both sides of a switch in one process); it must not run concurrently with any other call into the library. */
+void bj_env_reload(void);
 int bj_ctx_create(int device, bj_ctx **out);
 void bj_ctx_destroy(bj_ctx *ctx);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) for all subsequent work; NULL = the default stream. */

@@ -163,3 +163,22 @@ def test_run_time_compiled_kernels_are_cached_on_disk(tmp_path):
     assert "1 gate kernels compiled" in outs[0][1] and "0 loaded" in outs[0][1]
     assert "0 gate kernels compiled" in outs[1][1] and "1 loaded" in outs[1][1]
     assert np.array_equal(outs[0][0], outs[1][0])
+    # a cache file that does not belong to THIS build is refused and recompiled, never loaded: (a) truncated,
+    # (b) a foreign / pre-header file of the right name, (c) one byte of the code object flipped, (d) header with another build key
+    path = [os.path.join(str(tmp_path), f) for f in os.listdir(str(tmp_path)) if f.endswith(".hsaco")][0]
+    good = open(path, "rb").read()
+    assert good[:8] == b"BJJITv2\0" and int.from_bytes(good[16:24], "little") == len(good) - 32
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0x40
+    wrong_key = bytearray(good)
+    wrong_key[8] ^= 1
+    for k, bad in enumerate((good[:len(good) // 2], good[32:], bytes(flipped), bytes(wrong_key))):
+        open(path, "wb").write(bad)
+        out = os.path.join(str(tmp_path), "terms_bad%d.npy" % k)
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, BJ_GATE_JIT_CACHE=str(tmp_path)), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        status = [l for l in r.stdout.splitlines() if l.startswith("STATUS")][0]
+        assert "1 gate kernels compiled" in status and "0 loaded" in status and "1 cache files refused" in status, (k, status)
+        assert np.array_equal(np.load(out), outs[0][0])
+        assert open(path, "rb").read() == good          # and the file was rewritten with a valid one

@@ -171,11 +171,13 @@ def test_quotient_term_kernels_one_by_one_and_together(log_n, kw):
     gates(a_gates); copy_perm(zero * (1 + nch))
     assert np.array_equal(out.get((2, Q)), want_gates)
     import os
-    os.environ["BJ_GATES_WINDOWED"] = "0"
+    os.environ["BJ_GATES_WINDOWED"] = "0"          # the switches are read once per process: bj_env_reload re-reads them
     try:
+        E.load_library().bj_env_reload()
         clear(); gates(a_gates); copy_perm(zero * (1 + nch))
     finally:
         del os.environ["BJ_GATES_WINDOWED"]
+        E.load_library().bj_env_reload()
     assert np.array_equal(out.get((2, Q)), want_gates)
     # lookup terms alone
     clear(); lookup(a_lookup); copy_perm(zero * (1 + nch))

@@ -115,3 +115,31 @@ def test_the_librarys_reader_agrees_and_survives_mangled_dumps():
         assert rc in (0, -1)
         refused += rc != 0
     assert refused > 1000
+
+
+def test_hostile_gate_degrees_are_refused_not_looped_on():
+    """GateDescription.degree / num_constants were read unchecked; a degree above 2^31 + 1 sent the doubling
+    loop that derives the quotient degree to 0 for ever, and depth + degree could wrap.  Every such dump is refused at once by
+    the host part bj_setup_create_from_dump shares with bj_setup_dump_info."""
+    import ctypes as C
+    import struct
+    import time
+    import era_boojum_amd as E
+    from era_boojum_amd import memcopy_format as M, synthetic as S
+    lib = E.load_library()
+    c = S.sha_shaped_circuit(6, seed=3, table_bits=1)
+    dump = M.write_setup_base(c)
+    info = (C.c_uint64 * 8)()
+    g = c.gates[1]
+    leaf = struct.pack("<IQQQ", 1, 1, g.num_constants, g.degree)
+    at = dump.rindex(leaf)
+    t0 = time.perf_counter()
+    for degree in ((1 << 31) + 5, (1 << 32) + 3, (1 << 63) + 1, (1 << 64) - 1, (1 << 64) - 2, 1 << 16 | 1, 200):
+        bad = dump[:at] + struct.pack("<IQQQ", 1, 1, g.num_constants, degree) + dump[at + len(leaf):]
+        assert lib.bj_setup_dump_info(bad, len(bad), info) == -1, degree
+    for numc in ((1 << 64) - 1, (1 << 16) + 1):
+        bad = dump[:at] + struct.pack("<IQQQ", 1, 1, numc, g.degree) + dump[at + len(leaf):]
+        assert lib.bj_setup_dump_info(bad, len(bad), info) == -1, numc
+    ok = dump[:at] + struct.pack("<IQQQ", 1, 1, g.num_constants, 30) + dump[at + len(leaf):]      # a legal one: quotient degree 32
+    assert lib.bj_setup_dump_info(ok, len(ok), info) == 0
+    assert time.perf_counter() - t0 < 5.0

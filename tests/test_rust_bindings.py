@@ -43,3 +43,17 @@ def test_prove_hip_source_is_complete():
     # the deserialiser reads the header fields the serialiser writes (csrc/prover.hip) in the same order as proof_format.py
     from era_boojum_amd import proof_format
     assert "0x424A_5046" in src and proof_format.MAGIC == 0x424A5046
+
+
+def test_array_parameters_decay_to_pointers_and_array_fields_stay_arrays():
+    """C adjusts a parameter `uint64_t fp[2]` to `uint64_t *fp`: the binding must pass one address, not 16 bytes by value
+    (ADVICE round 3); a struct field `unsigned char path[8]` stays an inline array."""
+    g = _gen()
+    assert g.parse_param("uint64_t fp[2]", {}, set(), decay=True) == ("fp", "*mut u64")
+    assert g.parse_param("const uint64_t roots[4]", {}, set(), decay=True) == ("roots", "*const u64")
+    assert g.parse_param("uint32_t v[]", {}, set(), decay=True) == ("v", "*mut u32")
+    assert g.parse_param("unsigned char path[8]", {}, set()) == ("path", "[u8; 8]")
+    funcs = {name: ps for name, _, ps in g.parse_header()["funcs"]}
+    assert dict(funcs["bj_gate_program_canonical_info"])["fp"] == "*mut u64"
+    for name, ps in funcs.items():
+        assert not any(t.startswith("[") for _, t in ps), name        # no by-value array in any extern "C" signature

@@ -73,13 +73,19 @@ def split_params(s):
     return out
 
 
-def parse_param(p, enums, structs):
-    """'const uint64_t *d_in' -> (name, rust type); function pointers handled by the caller."""
-    m = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)(\[(\d+)\])?$", p.strip())
-    ctype, name, _, arr = m.groups()
-    rt = rust_type(ctype, enums, structs)
-    if arr:
-        rt = "[%s; %s]" % (rt, arr)
+def parse_param(p, enums, structs, decay=False):
+    """'const uint64_t *d_in' -> (name, rust type); function pointers handled by the caller.  `decay`: the declaration is a
+    FUNCTION PARAMETER, where C adjusts an array type `T name[N]` to the pointer `T *name` (C11 6.7.6.3p7) — a by-value
+    `[T; N]` on the Rust side would push N elements where the callee expects one address; struct fields keep their arrays."""
+    m = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)(\[(\d*)\])?$", p.strip())
+    ctype, name, brackets, arr = m.groups()
+    if brackets and decay:
+        rt = rust_type(ctype.rstrip() + " *", enums, structs)
+    else:
+        rt = rust_type(ctype, enums, structs)
+        if brackets:
+            assert arr, "an array field needs its extent: %r" % p
+            rt = "[%s; %s]" % (rt, arr)
     if name in ("type", "in", "ref", "fn", "match", "mod", "box", "loop", "move", "use"):
         name += "_"
     return name, rt
@@ -88,7 +94,7 @@ def parse_param(p, enums, structs):
 def parse_fn_pointer(decl, enums, structs):
     m = re.match(r"^(.*?)\(\s*\*\s*([A-Za-z_][A-Za-z0-9_]*)\s*\)\s*\((.*)\)$", decl.strip(), flags=re.S)
     ret, name, params = m.groups()
-    ps = [parse_param(p, enums, structs) for p in split_params(params)]
+    ps = [parse_param(p, enums, structs, decay=True) for p in split_params(params)]
     r = rust_type(ret, enums, structs)
     sig = "unsafe extern \"C\" fn(%s)%s" % (", ".join("%s: %s" % p for p in ps), "" if r == "c_void" else " -> " + r)
     return name, "Option<%s>" % sig
@@ -144,7 +150,7 @@ def parse_header(path=HEADER):
         ret, name, params = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
         if ret.startswith("typedef"):
             continue
-        ps = [] if params in ("void", "") else [parse_param(p, enums, struct_names) for p in split_params(params)]
+        ps = [] if params in ("void", "") else [parse_param(p, enums, struct_names, decay=True) for p in split_params(params)]
         funcs.append((name, rust_type(ret, enums, struct_names), ps))
     return dict(defines=defines, enums=enums, enum_consts=enum_consts, opaque=opaque, structs=structs, funcs=funcs)
 
