@@ -27,8 +27,10 @@ Extra objects on the JSON line:
                 timed proofs.  It is integer-VALU-bound by construction (~472 field multiplications per 64 absorbed bytes).
   ntt           BASELINE configs[1] ("cfg2"): 2^20 x 256-column forward NTT, algorithmic 16 B/element vs the HBM peak.
   stages_ms     per-round wall time, named after the reference's log lines.
+  kernels       gate evaluation, copy-permutation quotient, barycentric evaluation, DEEP and the first FRI fold: first launch of
+                each inside every timed proof (HIP events on the launch stream), algorithmic bytes by SURVEY §8d vs the HBM peak.
   cpu_baseline  the C/Python oracle prover (restated reference CPU algorithm) on this box's host cores, on a smaller
-                instance of the same circuit (bounded to ~10-30 s), in rows/s; `micro` times the oracle's C primitives on all
+                instance of the same circuit (2^20 rows = BASELINE cfg3's size, ~40 s; 2^18 as `micro.proof_2p18`), in rows/s; `micro` times the oracle's C primitives on all
                 cores at the bench's own sizes (NTT 2^20 x 256, Poseidon2 tree 2^23 x 93: benches/benchmarks.rs:479-520, 73-79);
                 `cores` = threads started, `cgroup_quota_cores` / `busy_cores_measured` = what the container actually gave them.
 """
@@ -86,7 +88,8 @@ def main():
     ap.add_argument("--fri-lde", type=int, default=8)
     ap.add_argument("--cap", type=int, default=16)
     ap.add_argument("--security", type=int, default=100)
-    ap.add_argument("--cpu-log-n", type=int, default=18)
+    ap.add_argument("--cpu-log-n", type=int, default=20)
+    ap.add_argument("--cpu-micro-log-n", type=int, default=18, help="second, smaller oracle proof reported under cpu_baseline.micro")
     ap.add_argument("--no-host-witness", action="store_true", help="skip the bj_prove (host witness, PCIe inclusive) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
@@ -207,13 +210,16 @@ def main():
     barrier()
     comm0 = (comm.calls, comm.bytes) if sharded else (0, 0)
     t0 = time.perf_counter()
-    leaf_ms, stage_acc, proof_buf, comm_ms_acc = [], {}, None, 0.0
+    leaf_ms, stage_acc, proof_buf, comm_ms_acc, kern_acc = [], {}, None, 0.0, {}
     for _ in range(args.steps):
         proof_buf, stages = step()
         if os.environ.get('BJ_BENCH_DEBUG'):
             print({k: round(v, 1) for k, v in stages.items()}, file=sys.stderr)
         leaf_ms.append(stages.pop("witness_tree_leaf_kernel"))
         comm_ms_acc += setup.last_comm["ms_in_collectives"]
+        for kname, (kms, kbytes) in setup.last_kernels.items():
+            acc = kern_acc.setdefault(kname, [0.0, kbytes])
+            acc[0] += kms
         for k, v in stages.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
@@ -281,6 +287,16 @@ def main():
                      "note": "integer-VALU-bound: ~472 Goldilocks multiplications per 64 absorbed bytes (DESIGN.md §4)"},
         "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},
     }
+    # the other kernels north_star names, each against the HBM roofline: first launch of each inside every timed proof, HIP
+    # events on the launch stream (bj_proof_kernel_stats), algorithmic bytes by SURVEY §8d; the VALU-bound ones say so
+    KNOTE = {"quotient_gates": "bj::quotient_gates_windowed_kernel: 8 (gp columns + constants) qn + 16 qn",
+             "quotient_copy_perm": "bj::quotient_copy_perm_kernel: 8 (2V + z + partial products + 1/(x-1)) qn + 32 qn",
+             "barycentric_eval": "bj::barycentric_partial_kernel + final: 8 n per base column + 16 n weights (the set at z)",
+             "deep_accumulate_multi": "bj::deep_accumulate_multi_kernel: 8 (#base columns) Ln + 16 Ln",
+             "fri_fold_first": "bj::fri_fold_fused_kernel<k> of the first FRI oracle: 16 m (1 + 2^-k)"}
+    out["kernels"] = {k: {"ms": round(v[0] / args.steps, 4), "algorithmic_bytes": v[1], "achieved": round(v[1] / (v[0] / args.steps) / 1e6, 1),
+                          "unit": "GB/s", "frac": round(v[1] / (v[0] / args.steps) / 1e6 / HBM_PEAK_GBPS, 4), "what": KNOTE.get(k, k)}
+                      for k, v in kern_acc.items() if v[0] > 0}
     if sharded:      # what a scaling record needs to explain itself: per proof on rank 0, and the slowest rank's time in collectives
         cm = torch.tensor([comm_ms_acc / args.steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         cmax = cm.clone()
@@ -388,24 +404,35 @@ def main():
                     break
         except OSError:
             pass
-        if args.circuit == "sha256" and args.cpu_log_n >= 14:
-            csmall = SHA.sha256_circuit(SHA.bench_message(SHA.message_len_for_log_n(args.cpu_log_n), seed=42))
-        else:
-            csmall = S.sha_shaped_circuit(args.cpu_log_n, seed=42, table_bits=4 if args.cpu_log_n >= 14 else 2)
-        osetup = OP.Setup(csmall, args.fri_lde, args.cap, threads=threads)
         quota = None                                  # cgroup CPU quota of this container, in cores (None = unlimited / unknown)
         try:
             q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
             quota = None if q == "max" else round(float(q) / float(per), 2)
         except (OSError, ValueError):
             pass
-        cpu0 = sum(os.times()[:2])
-        c0 = time.perf_counter()
-        OP.prove(csmall, osetup, args.fri_lde, args.cap, security_level=args.security, threads=threads,
-                 transcript_kind=setup.transcript_kind if setup.transcript_kind in (1, 2) else 1)
-        t_cpu = time.perf_counter() - c0
-        busy_cores = (sum(os.times()[:2]) - cpu0) / t_cpu        # CPU seconds per wall second: the cores the proof actually kept busy
-        del osetup, csmall
+
+        def oracle_proof(lg):
+            """One proof of the same circuit at 2^lg rows by the oracle prover: (seconds, busy cores)."""
+            if args.circuit == "sha256" and lg >= 14:
+                csmall = SHA.sha256_circuit(SHA.bench_message(SHA.message_len_for_log_n(lg), seed=42))
+            else:
+                csmall = S.sha_shaped_circuit(lg, seed=42, table_bits=4 if lg >= 14 else 2)
+            osetup = OP.Setup(csmall, args.fri_lde, args.cap, threads=threads)
+            cpu0 = sum(os.times()[:2])
+            c0 = time.perf_counter()
+            OP.prove(csmall, osetup, args.fri_lde, args.cap, security_level=args.security, threads=threads,
+                     transcript_kind=setup.transcript_kind if setup.transcript_kind in (1, 2) else 1)
+            t = time.perf_counter() - c0
+            return t, (sum(os.times()[:2]) - cpu0) / t        # CPU seconds per wall second: the cores the proof actually kept busy
+
+        # the bounded sample: 2^20 rows (BASELINE cfg3's size, a quarter of the bench's; the oracle proves it in ~40 s on 16 cores)
+        # unless the calibration says this host would need minutes, then the 2^18 one alone
+        est_main = 40.0 * (3.0e6 / max(perm_rate, 1.0)) * (2.0 ** (args.cpu_log_n - 20))
+        main_log = args.cpu_log_n if est_main < 150.0 else min(args.cpu_log_n, args.cpu_micro_log_n)
+        t_cpu, busy_cores = oracle_proof(main_log)
+        small = None
+        if args.cpu_micro_log_n < main_log:
+            small = (args.cpu_micro_log_n,) + oracle_proof(args.cpu_micro_log_n)
         # the oracle's C primitives at the bench's own sizes, all host cores (benches/benchmarks.rs:479-520 and :73-79)
         a = rng.integers(0, E.P, size=(256, 1 << 20), dtype=np.uint64)
         c0 = time.perf_counter()
@@ -421,11 +448,14 @@ def main():
         t_tree = time.perf_counter() - c0
         perms = (1 << tl_log) * 12 + (1 << tl_log) - args.cap
         del cols
-        out["cpu_baseline"] = {"value": round((1 << args.cpu_log_n) / t_cpu, 1), "unit": "rows/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": round((1 << main_log) / t_cpu, 1), "unit": "rows/s", "cores": threads, "kind": "port",
                                "cpu_model": cpu_model, "affinity_cpus": affinity, "cgroup_quota_cores": quota, "busy_cores_measured": round(busy_cores, 1),
                                "sample": "one proof of the same circuit at 2^%d rows by the oracle prover (C bulk ops + python "
-                                         "orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (args.cpu_log_n, t_cpu),
-                               "micro": {"ntt_2p20_x256": {"ms": round(t_ntt * 1e3, 1), "GBps": round(16.0 * 256 * (1 << 20) / t_ntt / 1e9, 2),
+                                         "orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (main_log, t_cpu),
+                               "micro": {**({"proof_2p%d" % small[0]: {"s": round(small[1], 2), "rows_per_s": round((1 << small[0]) / small[1], 1),
+                                                                       "busy_cores_measured": round(small[2], 1),
+                                                                       "what": "the same oracle proof at the size earlier rounds reported"}} if small else {}),
+                                         "ntt_2p20_x256": {"ms": round(t_ntt * 1e3, 1), "GBps": round(16.0 * 256 * (1 << 20) / t_ntt / 1e9, 2),
                                                            "what": "oracle fft_natural_to_bitreversed, coset 7, one column per thread"},
                                          "poseidon2_tree_2p%d_x93" % tl_log: {"ms": round(t_tree * 1e3, 1), "Mperm_per_s": round(perms / t_tree / 1e6, 2),
                                                                              "what": "oracle MerkleTreeWithCap::construct, leaves then node layers"}}}

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "bj_prove_from_dumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "bj_proof_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_proof_kernel_stats": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_proof_comm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
     "bj_transcript_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -761,6 +762,11 @@ class ProverSetup:
         cms, calls, recv = C.c_float(), C.c_size_t(), C.c_size_t()
         self._lib.bj_proof_comm_stats(h, C.byref(cms), C.byref(calls), C.byref(recv))
         self.last_comm = {"ms_in_collectives": float(cms.value), "calls": int(calls.value), "bytes_received": int(recv.value)}
+        self.last_kernels = {}        # name -> (ms, algorithmic bytes) of the first launch of each probed kernel in this proof
+        name, kms, kb, k = C.c_char_p(), C.c_float(), C.c_double(), 0
+        while self._lib.bj_proof_kernel_stats(h, k, C.byref(name), C.byref(kms), C.byref(kb)) == 0:
+            self.last_kernels[name.value.decode()] = (float(kms.value), float(kb.value))
+            k += 1
         self._lib.bj_proof_destroy(h)
         stages = dict(zip(STAGE_NAMES, [float(x) for x in ms][:7]))
         stages["witness_tree_leaf_kernel"] = float(ms[7])

@@ -126,6 +126,22 @@ u64 *arena_alloc(bj_ctx *ctx, size_t elems) {
 }
 
 
+int probe_begin(bj_ctx *ctx, const char *name, double algorithmic_bytes) {
+    if (!ctx->in_proof || ctx->probe_n >= BJ_MAX_KERNEL_PROBES) return -1;
+    for (unsigned i = 0; i < ctx->probe_n; i++)
+        if (!strcmp(ctx->probes[i].name, name)) return -1;
+    auto &p = ctx->probes[ctx->probe_n];
+    if (!p.ev[0] && hipEventCreate(&p.ev[0]) != hipSuccess) return -1;
+    if (!p.ev[1] && hipEventCreate(&p.ev[1]) != hipSuccess) return -1;
+    p.name = name;
+    p.bytes = algorithmic_bytes;
+    if (hipEventRecord(p.ev[0], ctx->stream) != hipSuccess) return -1;
+    return (int)ctx->probe_n++;
+}
+void probe_end(bj_ctx *ctx, int idx) {
+    if (idx >= 0) (void)hipEventRecord(ctx->probes[idx].ev[1], ctx->stream);
+}
+
 namespace {
 EnvConfig g_env;
 std::once_flag g_env_once;
@@ -231,6 +247,9 @@ void bj_ctx_destroy(bj_ctx *ctx) {
             if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->copy_ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &p : ctx->probes)
+        for (hipEvent_t e : p.ev)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <string>
 
+#define BJ_MAX_KERNEL_PROBES 12
+
 struct bj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -43,9 +45,21 @@ struct bj_ctx {
     unsigned comm_n = 0;          // pairs recorded by the proof in flight
     size_t comm_bytes = 0;        // bytes received by this rank in them
     float comm_host_ms = 0;       // synchronous host-callback transport: wall time inside the callbacks
+    // per-kernel probes of the proof in flight (bj_proof_kernel_stats): an event pair on the launch stream around the first
+    // launch of each named kernel, with the algorithmic bytes of that launch — no synchronisation added
+    struct KernelProbe {
+        const char *name = nullptr;
+        double bytes = 0;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    } probes[BJ_MAX_KERNEL_PROBES];
+    unsigned probe_n = 0;
 };
 
 namespace bj {
+// first launch of `name` inside a proof: records the opening event and returns the probe's index (-1: not in a proof, name
+// already probed in this proof, or table full — the caller just launches); probe_end records the closing event
+int probe_begin(bj_ctx *ctx, const char *name, double algorithmic_bytes);
+void probe_end(bj_ctx *ctx, int idx);
 int fail(bj_ctx *ctx, int code, const char *fmt, ...);
 int bind(bj_ctx *ctx);
 // host block -> device, ordered on ctx->stream like a kernel launch; returns without waiting (h_src may be reused at once)

@@ -173,14 +173,18 @@ int bj::fri_prove_sharded(bj_ctx *ctx, const bj::Shard &sh, const u64 *d_c0, con
         const size_t out_len = cur_len >> k, loc_out = loc_len >> k;
         u64 *nxt = alloc(2 * out_len);
         if (!nxt) return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
+        // FRI fold by 2^k over m F_p^2 inputs, SURVEY §8d: 16 m + 16 m / 2^k
+        const int pf = bj::probe_begin(ctx, "fri_fold_first", 16.0 * (double)loc_len * (1.0 + 1.0 / (double)(1u << k)));
         if (parts == 1) {
             bj::launch_fri_fold_step(cur0, cur1, cur_len, k, nxt, nxt + out_len, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
                                      ctx->stream);
+            bj::probe_end(ctx, pf);
         } else {
             u64 *part = alloc(2 * loc_out);   // [2][loc_out] of this rank, gathered into nxt = [2][out_len]
             if (!part) return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_fri_prove: layer allocation failed"));
             bj::launch_fri_fold_step(cur0, cur1, loc_len, k, part, part + loc_out, ctx->tw_inv, kappa, oo.ch0, oo.ch1,
                                      ctx->stream, (size_t)sh.rank * loc_out);
+            bj::probe_end(ctx, pf);
             rc = bj::all_gather_columns(ctx, sh, part, nxt, 2, loc_out);
             if (rc) return bail(rc);
         }

@@ -82,7 +82,10 @@ int bj_barycentric_eval_batch(bj_ctx *ctx, const uint64_t *const *h_col_ptrs, un
     u64 *d_partials = (u64 *)(d_ptrs + n_cols);
     u64 *d_out = d_partials + (size_t)n_cols * nb * 2;
     if (int rc = bj::h2d_async(ctx, (void *)d_ptrs, h_col_ptrs, n_cols * sizeof(u64 *))) return rc;
+    // barycentric, SURVEY §8d: 8 n per base column + 16 n of weights (cached across the columns of a workgroup)
+    const int pb = bj::probe_begin(ctx, "barycentric_eval", 8.0 * (double)n * n_cols + 16.0 * (double)n);
     bj::launch_barycentric_eval(d_ptrs, n_cols, n, d_w0, d_w1, d_partials, d_out, ctx->stream);
+    bj::probe_end(ctx, pb);
     BJ_CHECK_LAUNCH(ctx);
     return bj_memcpy_d2h(ctx, h_out, d_out, (size_t)n_cols * 2 * sizeof(u64));
 }

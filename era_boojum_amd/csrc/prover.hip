@@ -108,6 +108,12 @@ struct bj_proof {
     float comm_ms = 0;             // sharded proofs: time between the start and the end of every collective on this rank, summed
     unsigned comm_calls = 0;
     size_t comm_bytes = 0;         // bytes received from the other ranks
+    struct KernelStat {            // bj_proof_kernel_stats: first launch of each probed kernel
+        const char *name;
+        float ms;
+        double bytes;
+    } kernel_stats[BJ_MAX_KERNEL_PROBES] = {};
+    unsigned n_kernel_stats = 0;
 };
 
 namespace {
@@ -497,6 +503,13 @@ int bj_proof_comm_stats(const bj_proof *p, float *ms_in_collectives, size_t *cal
     if (bytes_received) *bytes_received = p->comm_bytes;
     return BJ_OK;
 }
+int bj_proof_kernel_stats(const bj_proof *p, unsigned index, const char **name, float *ms, double *algorithmic_bytes) {
+    if (!p || index >= p->n_kernel_stats) return BJ_ERR_INVALID_ARG;
+    if (name) *name = p->kernel_stats[index].name;
+    if (ms) *ms = p->kernel_stats[index].ms;
+    if (algorithmic_bytes) *algorithmic_bytes = p->kernel_stats[index].bytes;
+    return BJ_OK;
+}
 int bj_proof_stage_ms(const bj_proof *p, float *out8) {
     if (!p || !out8) return BJ_ERR_INVALID_ARG;
     std::memcpy(out8, p->stage_ms, sizeof(p->stage_ms));
@@ -585,6 +598,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             c->comm_n = 0;
             c->comm_bytes = 0;
             c->comm_host_ms = 0;
+            c->probe_n = 0;
         }
         ~InProof() { c->in_proof = false; }
     } in_proof(ctx);
@@ -762,7 +776,10 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
               *a_l1 = a_gates + 2 * n_gate_terms;
     const u64 *d_sig_lde = S->d_lde, *d_con_lde = S->d_lde + (size_t)V * Ln, *d_tab_lde = S->d_lde + (size_t)(V + nC) * Ln;
     if (Qe) {
+        // gate evaluation, SURVEY §8d: 8 (V + consts) qn + 16 qn — V = the general-purpose columns the gates read
+        const int pg = bj::probe_begin(ctx, "quotient_gates", 8.0 * (S->num_gp_vars + nC) * (double)Qe + 16.0 * (double)Qe);
         bj::launch_quotient_gates(wit_lde.p, Ln, d_con_lde, Ln, S->gates_flat.data(), S->n_gates, a_gates, Qe, t0, t1, st);
+        bj::probe_end(ctx, pg);
         unsigned aoff = 0;   // op-list gates (seam S3) add their contribution on top, with their own slice of alpha powers
         std::vector<bj::GateLaunch> prog_gates;
         for (unsigned g = 0; g < S->n_gates; g++) {
@@ -804,9 +821,13 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                                    Ln, wit_lde.p + (size_t)VW * Ln, dA, dB, Ln, S->lookup_reps, S->lookup_w, lbeta, lgamma,
                                    a_lookup, Qe, t0, t1, st);
     }
-    if (Qe)
+    if (Qe) {
+        // variables + sigmas + z and the partial products + 1/(x - 1), accumulators read and written
+        const int pc = bj::probe_begin(ctx, "quotient_copy_perm", 8.0 * (2.0 * V + 2 + 2 * n_part + 1) * (double)Qe + 32.0 * (double)Qe);
         bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_L, ctx->tw_fwd,
                                       beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_spec_terms + n_gate_terms), a_l1 + 2, Qe, I0, S->d_inv_xm1, t0, t1, st);
+        bj::probe_end(ctx, pc);
+    }
     BJ_CHECK_LAUNCH(ctx);
     u64 q_shift = gl::GEN;   // coset the gathered evaluations live on
     if (q_local) {
@@ -993,8 +1014,13 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             unsigned cnt = 0;
             for (auto it = pending.begin(); it != pending.end() && cnt < (unsigned)bj::DEEP_MAX_SETS; ++it, ++cnt)
                 hs[cnt] = bj::DeepSetHost{it->p0.data(), it->p1.data(), it->p0.size(), it->vals.data(), it->ch.data(), it->at};
+            double deep_cols = 0;      // DEEP, SURVEY §8d: 8 (#base columns) Ln + 16 Ln (the destination pair)
+            for (unsigned k = 0; k < cnt; k++)
+                for (size_t j = 0; j < hs[k].n_src; j++) deep_cols += hs[k].src_c1 && hs[k].src_c1[j] ? 2 : 1;
+            const int pd = bj::probe_begin(ctx, "deep_accumulate_multi", 8.0 * deep_cols * (double)N + (deep_written ? 32.0 : 16.0) * (double)N);
             int r = bj::deep_accumulate_multi(ctx, hs, cnt, log_n, S->log_fri, N, sh.world > 1 ? I0 : 0, deep.p, deep.p + N,
                                               deep_written ? 1 : 0);
+            bj::probe_end(ctx, pd);
             if (r) return r;
             deep_written = true;
             for (unsigned k = 0; k < cnt; k++) pending.pop_front();
@@ -1263,6 +1289,11 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         proof->comm_ms = ms;
         proof->comm_calls = n_stream + (ctx->comm_n >> 16);
         proof->comm_bytes = ctx->comm_bytes;
+        for (unsigned i = 0; i < ctx->probe_n; i++) {
+            float e = 0;
+            if (hipEventElapsedTime(&e, ctx->probes[i].ev[0], ctx->probes[i].ev[1]) != hipSuccess) continue;
+            proof->kernel_stats[proof->n_kernel_stats++] = {ctx->probes[i].name, e, ctx->probes[i].bytes};
+        }
     }
     guard.ok = true;
     *out = proof;

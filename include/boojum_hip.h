@@ -530,6 +530,13 @@ int bj_proof_serialize(const bj_proof *p, uint64_t *out);
  * [2] quotient work and LDE + tree, [3] openings at z, [4] batched FRI opening computation (DEEP), [5] FRI, [6] queries;
  * [7] = duration of the witness-tree Poseidon2 leaf kernel alone, measured with HIP events on the launch stream */
 int bj_proof_stage_ms(const bj_proof *p, float *out8);
+/* Per-kernel measurements of the proof (measurement only; SURVEY §8d "each evidenced by ... HBM GB/s against the roofline"): the
+ * FIRST launch inside this proof of each probed kernel — "quotient_gates" (prover.rs:1031-1080), "quotient_copy_perm"
+ * (copy_permutation.rs:1000-1249), "barycentric_eval" (utils.rs:907-1242; the set at z), "deep_accumulate_multi"
+ * (prover.rs:2523-2706), "fri_fold_first" (fri/mod.rs:362-678) — bracketed by HIP events on the launch stream: its duration in
+ * ms and the algorithmic bytes of that launch by SURVEY §8d's per-unit figures.  index = 0, 1, ... until BJ_ERR_INVALID_ARG;
+ * *name points to a string with static storage.  Any out pointer may be NULL. */
+int bj_proof_kernel_stats(const bj_proof *p, unsigned index, const char **name, float *ms, double *algorithmic_bytes);
 /* Sharded proofs: how long this rank spent inside collectives (sum over the all-gathers of the time between their start and
  * their end on the proof's stream: transfer + waiting for the slowest peer), how many there were and how many bytes arrived
  * from the other ranks.  Zeroes for a single-GPU proof.  Any out pointer may be NULL. */

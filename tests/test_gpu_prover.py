@@ -261,3 +261,42 @@ def test_proof_at_2p23_rows_equals_the_streaming_oracle():
             assert np.array_equal(frag, np.asarray(pg[name], dtype=np.uint64)[2 * cs:2 * cs + 2]), (name, cs)
     for cs, frag in po["setup_cap_fragments"].items():
         assert np.array_equal(frag, cap[2 * cs:2 * cs + 2]), "setup cap nodes of coset %d" % cs
+
+
+def test_two_contexts_on_two_host_threads_prove_concurrently():
+    """The shape a Rust host with 8 GPUs uses: one bj_ctx per host thread, all inside ONE process (here both on this box's one
+    device, each context on its own HIP stream).  Each thread proves its own circuit eight times while the other one is
+    proving: every proof is the bytes the same setup gave when it ran alone — no cross-talk through the twiddle caches, the
+    arenas, the staging rings, the gate-kernel caches or the environment switches (read once per process, kernels.h)."""
+    import threading
+    import torch
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs = [E.Context(0, stream=s.cuda_stream) for s in streams]
+    circuits = [S.sha_shaped_circuit(12, seed=101, table_bits=2), S.sha_shaped_circuit(13, seed=102, table_bits=2)]
+    setups = [E.ProverSetup(ctxs[i], circuits[i], 8, 16, 40) for i in range(2)]
+    alone = [setups[i].prove()[0].copy() for i in range(2)]
+    for i in range(2):
+        assert OV.verify(OV.VerificationKey(circuits[i], setups[i].cap(), 8, 16), proof_format.parse(alone[i], security_level=40))
+    errors, barrier = [], threading.Barrier(2)
+
+    def work(i):
+        try:
+            barrier.wait()
+            for k in range(8):
+                buf, _ = setups[i].prove()
+                if not np.array_equal(buf, alone[i]):
+                    errors.append("thread %d, proof %d differs from the proof made alone" % (i, k))
+        except Exception as e:          # noqa: BLE001 - reported by the main thread
+            errors.append("thread %d: %r" % (i, e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for s in setups:
+        s.close()
+    for c in ctxs:
+        c.release_workspace()
+        c.close()

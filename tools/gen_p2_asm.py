@@ -29,13 +29,13 @@ RC_INC = os.path.join(ROOT, "era_boojum_amd", "csrc", "poseidon_rc.inc")
 WAYS = int(os.environ.get("BJ_P2_WAYS", "3"))            # S-boxes interleaved in a full round (2, 3 or 4; v[24:71] holds four sets): 3 measured best by ~1 %
 assert WAYS in (2, 3, 4)
 COMBINE_INLINE = os.environ.get("BJ_P2_COMBINE", "") == "inline"
-# Experiments for the next round (default off: the committed stream and its profiles are those of the default build).
+# On since round 4 (validated on the GPU in round 3; "=0" rebuilds the round-3 stream for A/B):
 #   BJ_P2_ZERO_HOIST=1: the zero high halves of the S-box addend pairs are written once per full round (3 moves instead of 12)
 #                       and once before the partial-round loop (v35 is not touched by the partial rounds' linear layer): -93 VALU;
 #   BJ_P2_LATE_CONST=1: the twelve constants of the first closing full round ride on the LAST partial round's linear layer
 #                       (two multiply-adds per word, as word 0's constant always does) instead of a weak addition each: -26 VALU.
-ZERO_HOIST = os.environ.get("BJ_P2_ZERO_HOIST", "") == "1"
-LATE_CONST = os.environ.get("BJ_P2_LATE_CONST", "") == "1"
+ZERO_HOIST = os.environ.get("BJ_P2_ZERO_HOIST", "1") == "1"
+LATE_CONST = os.environ.get("BJ_P2_LATE_CONST", "1") == "1"
 SH = [4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12]           # internal matrix 1 + diag(2^SH)  (poseidon2/params.rs:38-39)
 P = (1 << 64) - (1 << 32) + 1
 

@@ -15,7 +15,7 @@ OUT = os.path.join(ROOT, "rust", "boojum_hip_sys.rs")
 
 SCALARS = {
     "int": "c_int", "unsigned": "c_uint", "unsigned int": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32",
-    "float": "f32", "unsigned char": "u8", "char": "c_char", "void": "c_void",
+    "float": "f32", "double": "f64", "unsigned char": "u8", "char": "c_char", "void": "c_void",
 }
 
 

@@ -87,8 +87,8 @@ def all_sequences():
     import p2_emulate as EM
     out = {}
     for name, env in (("poseidon2 default", None), ("poseidon2 ways2", {"BJ_P2_WAYS": "2"}), ("poseidon2 ways4", {"BJ_P2_WAYS": "4"}),
-                      ("poseidon2 combine_inline", {"BJ_P2_COMBINE": "inline"}), ("poseidon2 zero_hoist", {"BJ_P2_ZERO_HOIST": "1"}),
-                      ("poseidon2 zero_hoist+late_const", {"BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "1"})):
+                      ("poseidon2 combine_inline", {"BJ_P2_COMBINE": "inline"}), ("poseidon2 zero_hoist only", {"BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "0"}),
+                      ("poseidon2 round-3 stream", {"BJ_P2_ZERO_HOIST": "0", "BJ_P2_LATE_CONST": "0"})):
         e = EM.build(env)
         lines = []
         labels = {v: k for k, v in e.labels.items()}

@@ -291,7 +291,7 @@ def build(env=None):
 
 if __name__ == "__main__":
     import json
-    for name, env in (("default", None), ("hoist", {"BJ_P2_ZERO_HOIST": "1"}), ("hoist+late_const", {"BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "1"})):
+    for name, env in (("default", None), ("hoist only", {"BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "0"}), ("round-3 stream", {"BJ_P2_ZERO_HOIST": "0", "BJ_P2_LATE_CONST": "0"})):
         e = build(env)
         e.run([(0x0123456789ABCDEF * (k + 1)) & M64 for k in range(12)])
         print(name, json.dumps(e.counts))

@@ -8,9 +8,9 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 EXP = os.path.join(ROOT, "exp")
-VARIANTS = {"w2": {"BJ_P2_WAYS": "2"}, "w3": {"BJ_P2_WAYS": "3"}, "w4": {"BJ_P2_WAYS": "4"},
+VARIANTS = {"w2": {"BJ_P2_WAYS": "2"}, "w3": {"BJ_P2_WAYS": "3"}, "r3": {"BJ_P2_WAYS": "3", "BJ_P2_ZERO_HOIST": "0", "BJ_P2_LATE_CONST": "0"}, "w4": {"BJ_P2_WAYS": "4"},
             "w2_inline": {"BJ_P2_WAYS": "2", "BJ_P2_COMBINE": "inline"}, "w3_inline": {"BJ_P2_WAYS": "3", "BJ_P2_COMBINE": "inline"},
-            "w3_hoist": {"BJ_P2_WAYS": "3", "BJ_P2_ZERO_HOIST": "1"},
+            "w3_hoist": {"BJ_P2_WAYS": "3", "BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "0"},
             "w3_hoist_lc": {"BJ_P2_WAYS": "3", "BJ_P2_ZERO_HOIST": "1", "BJ_P2_LATE_CONST": "1"}}
 if len(sys.argv) > 2:   # python tools/p2_variants.py build|bench name [name ...]
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[2:]}
