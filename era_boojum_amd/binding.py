@@ -61,6 +61,7 @@ _SIGNATURES = {
     "bj_quotient_copy_perm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "bj_combine_residues": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p]),
     "bj_rccl_available": (C.c_int, []),
     "bj_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "bj_comm_rccl_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
@@ -308,6 +309,11 @@ class Context:
         self._check(self._lib.bj_quotient_copy_perm(self._h, d_vars, var_stride, d_sigmas, sig_stride, d_stage2, s2_stride,
                                                     _np_ptr(nr), num_vars, chunk, log_n, log_lde, _np_ptr(self._e2(beta)),
                                                     _np_ptr(self._e2(gamma)), _np_ptr(al), num_points, first_point, d_out0, d_out1))
+
+    def combine_residues(self, d_residues, world, residue_len, num_cols, moduli, d_out):
+        """bj_combine_residues: [world][num_cols][E] residues T mod (x^E - a_i) -> [num_cols][world * E] coefficients of T."""
+        a = np.ascontiguousarray(np.array([int(v) for v in moduli], dtype=np.uint64))
+        self._check(self._lib.bj_combine_residues(self._h, d_residues, world, residue_len, num_cols, _np_ptr(a), d_out))
 
     FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "mul_lazy": 3, "square": 4, "inverse": 5, "ext2_mul": 6, "butterfly": 7, "addsub": 8,
                  "add_lazy": 9, "sub_lazy": 10, "ext2_mul_lazy": 11}

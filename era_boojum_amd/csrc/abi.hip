@@ -160,6 +160,7 @@ void load_env() {
     e.gate_no_fuse = set("BJ_GATE_NO_FUSE");
     e.gate_no_jit = set("BJ_GATE_NO_JIT");
     e.gates_windowed = str("BJ_GATES_WINDOWED").rfind("0", 0) != 0;
+    e.copy_perm_generic = set("BJ_COPY_PERM_GENERIC");
     e.prove_no_absorb = set("BJ_PROVE_NO_ABSORB");
     if (set("BJ_PROVE_H2D_GROUP")) {
         const unsigned v = (unsigned)strtoul(getenv("BJ_PROVE_H2D_GROUP"), nullptr, 10);

@@ -20,6 +20,7 @@ struct EnvConfig {
     bool ntt_inv_fused = true;          // BJ_NTT_INV_FUSED=0: inverse transforms end in the separate bit-reversal sweep
     bool gate_no_aot = false, gate_no_fuse = false, gate_no_jit = false;
     bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
+    bool copy_perm_generic = false;     // BJ_COPY_PERM_GENERIC: the one-column-at-a-time copy-permutation quotient kernel for every chunk width
     bool prove_no_absorb = false;
     unsigned prove_h2d_group = 8;
     size_t nodes_lanepar_max = 16384;

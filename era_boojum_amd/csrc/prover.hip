@@ -42,6 +42,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
                                const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, const u64 *d_inv_xm1, u64 *d_out0,
                                u64 *d_out1, hipStream_t s);
 void launch_inv_x_minus_one(const u64 *d_tw_fwd, size_t Q, size_t I0, u64 *d_out, hipStream_t s);
+bool launch_combine_residues(const u64 *d_residues, unsigned W, size_t E, unsigned n_cols, const u64 *h_a, u64 *d_out, hipStream_t s);
 void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, const u64 *d_idx, unsigned n_idx,
                         u64 *d_out, hipStream_t s);
 void launch_merkle_paths(const u64 *d_tree, size_t num_leaves, unsigned depth, const u64 *d_idx, unsigned n_idx,
@@ -286,8 +287,8 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     if (n_chunks < 2) return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: a single copy-permutation chunk is not supported");
     if (comm && comm->world > 1) {
         const unsigned W = comm->world;
-        if (!bj::is_pow2(W) || comm->rank >= W || (!comm->all_gather && !comm->all_gather_stream))
-            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must be a power of two, rank < world, callback set");
+        if (!bj::is_pow2(W) || W > 8 || comm->rank >= W || (!comm->all_gather && !comm->all_gather_stream))
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must be a power of two <= 8, rank < world, callback set");
         if (cfg->fri_lde_factor % W || cfg->cap_size % W || c->quotient_degree > cfg->fri_lde_factor)
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must divide fri_lde_factor and cap_size, and "
                                                      "quotient_degree must not exceed fri_lde_factor");
@@ -296,6 +297,8 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: cosets per rank must divide the quotient degree");
         if ((((size_t)1 << c->log_n) * cl) < cfg->cap_size / W)
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: shard smaller than its cap fragment");
+        if ((((size_t)c->quotient_degree << c->log_n) / W) < 2)   // every rank evaluates q n / W points of the quotient
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: fewer than two quotient points per rank");
     }
     bj_setup *s = new bj_setup();
     s->device = ctx->device;
@@ -455,7 +458,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         if (rc) return bail(rc);
     }
     {   // the points the quotient is evaluated on here (prove_impl: Qe, I0) and 1 / (x - 1) on them, for the L_1 term
-        const size_t Qe = s->cl >= s->q ? n * s->q : (s->c0 < s->q ? s->Ls : 0);
+        const size_t Qe = (n * s->q) / s->sh.world;
         if (Qe) {
             if ((rc = bj::ensure_twiddles(ctx, s->log_n + s->log_L, false))) return bail(rc);
             if (hipMalloc((void **)&s->d_inv_xm1, Qe * 8) != hipSuccess)
@@ -555,11 +558,11 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     // N / Ln: leaves / column stride HELD BY THIS GPU (the whole domain on one GPU); Q: points of the quotient domain
     const size_t n = (size_t)1 << log_n, N = S->Nl, Q = n * q, Ln = S->Ls, I0 = (size_t)S->c0 * n;
     const size_t capl = S->cap_l;
-    // quotient evaluation: a rank holding >= q cosets evaluates on its own first q cosets (they form the coset
-    // 7*w^bitrev(c0) of the size-qn subgroup, same monomials); otherwise the ranks holding cosets < q each evaluate
-    // theirs and the pieces are all-gathered
-    const bool q_local = S->cl >= q;
-    const size_t Qe = q_local ? Q : (S->c0 < q ? Ln : 0);   // points this rank evaluates
+    // quotient evaluation: the q n points are split evenly, rank r evaluates on the first Qe = q n / W points of ITS OWN range of
+    // the LDE (they form the coset x_{I0} * H_Qe in bit-reversed order, whether Qe is several cosets of H_n, one, or a fraction
+    // of one), inverse-transforms them to T mod (x^Qe - x_{I0}^Qe), and the residues are all-gathered and combined (below)
+    const bool q_local = sh.world == 1;
+    const size_t Qe = Q / sh.world;   // points this rank evaluates
     const unsigned VW = V + S->Wc;                         // variables, then the non-copiable witness columns (prover.rs:317-343)
     const unsigned nW = VW + (has_lookup ? 1 : 0);
     const unsigned n_chunks = (V + q - 1) / q, n_part = n_chunks - 1;
@@ -770,8 +773,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     ArenaBuf Tl;   // this rank's evaluations [2][Qe] (T itself when nothing has to be gathered)
     if (q_local)
         Tl.p = T.p;
-    else if ((rc = Tl.alloc(ctx, 2 * Ln))) return rc;
-    u64 *t0 = Tl.p, *t1 = Tl.p + (q_local ? Q : Ln);
+    else if ((rc = Tl.alloc(ctx, 2 * Qe))) return rc;
+    u64 *t0 = Tl.p, *t1 = Tl.p + Qe;
     const u64 *a_lookup = d_alphas.p, *a_spec = d_alphas.p + 2 * n_lookup_terms, *a_gates = a_spec + 2 * n_spec_terms,
               *a_l1 = a_gates + 2 * n_gate_terms;
     const u64 *d_sig_lde = S->d_lde, *d_con_lde = S->d_lde + (size_t)V * Ln, *d_tab_lde = S->d_lde + (size_t)(V + nC) * Ln;
@@ -829,22 +832,32 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         bj::probe_end(ctx, pc);
     }
     BJ_CHECK_LAUNCH(ctx);
-    u64 q_shift = gl::GEN;   // coset the gathered evaluations live on
-    if (q_local) {
-        q_shift = gl::mul(gl::GEN, gl::pow(gl::omega(log_n + S->log_L), gl::bitrev32(S->c0, S->log_L)));
-    } else {
-        // ranks [0, q/cl) hold cosets [0, q); everybody receives everything and keeps those pieces
-        ArenaBuf all;
-        if ((rc = all.alloc(ctx, (size_t)2 * Ln * sh.world))) return rc;
-        if ((rc = bj::all_gather(ctx, sh, Tl.p, all.p, 2 * Ln))) return rc;
-        for (unsigned r = 0; r < q / S->cl; r++)
-            BJ_HIP(ctx, hipMemcpy2DAsync(T.p + (size_t)r * Ln, Q * 8, all.p + (size_t)r * 2 * Ln, Ln * 8, Ln * 8, 2,
-                                         hipMemcpyDeviceToDevice, st));
-    }
-    // flatten (= bit-reversal of the size-qn array), iNTT on coset g, chunk, LDE to fri_lde_factor (prover.rs:1386-1482)
+    // flatten (= bit-reversal of the evaluations), iNTT on their coset (prover.rs:1386-1422)
     const unsigned log_Q = log_n + S->log_q;
-    rc = bj_bitreverse_batch(ctx, T.p, T.p, log_Q, 2, Q);
-    if (!rc) rc = bj_intt_batch(ctx, T.p, T.p, log_Q, 2, Q, q_shift);
+    if (q_local) {
+        rc = bj_bitreverse_batch(ctx, T.p, T.p, log_Q, 2, Q);
+        if (!rc) rc = bj_intt_batch(ctx, T.p, T.p, log_Q, 2, Q, gl::GEN);
+    } else {
+        // Sharded: the first Qe points of this rank are s * H_Qe with s = x_{I0} = 7 * w_{Ln}^{bitrev(c0)}: the inverse transform
+        // with that shift gives R = T mod (x^Qe - a), a = s^Qe.  With T = sum_j x^(j Qe) T_j, R_i = sum_j a_i^j T_j: W residues
+        // (all-gathered: 2 Qe words from every rank, 2 q n in total) determine T by a W x W Vandermonde solve per coefficient
+        // (combine_residues_kernel) — no rank evaluates a point twice and the size-q n inverse transform is not replicated.
+        const unsigned log_E = bj::log2_exact(Qe);
+        auto rank_shift = [&](unsigned r) {
+            return gl::mul(gl::GEN, gl::pow(gl::omega(log_n + S->log_L), gl::bitrev32(r * S->cl, S->log_L)));
+        };
+        rc = bj_bitreverse_batch(ctx, Tl.p, Tl.p, log_E, 2, Qe);
+        if (!rc) rc = bj_intt_batch(ctx, Tl.p, Tl.p, log_E, 2, Qe, rank_shift(sh.rank));
+        if (rc) return rc;
+        ArenaBuf all;
+        if ((rc = all.alloc(ctx, (size_t)2 * Q))) return rc;
+        if ((rc = bj::all_gather(ctx, sh, Tl.p, all.p, 2 * Qe))) return rc;
+        u64 a[8];
+        for (unsigned r = 0; r < sh.world; r++) a[r] = gl::pow(rank_shift(r), Qe);
+        if (!bj::launch_combine_residues(all.p, sh.world, Qe, 2, a, T.p, st))
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "sharded quotient: the residues' moduli are not distinct");
+        BJ_CHECK_LAUNCH(ctx);
+    }
     u64 top[2] = {1, 1};
     if (!rc) rc = bj_memcpy_d2h(ctx, &top[0], T.p + Q - 1, 8);
     if (!rc) rc = bj_memcpy_d2h(ctx, &top[1], T.p + 2 * Q - 1, 8);

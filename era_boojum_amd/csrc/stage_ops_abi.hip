@@ -21,6 +21,7 @@ void launch_quotient_lookup(const u64 *d_lvars, size_t var_stride, const u64 *d_
                             size_t tab_stride, const u64 *d_mult, const u64 *d_A, const u64 *d_B, size_t s2_stride,
                             unsigned reps, unsigned w, const u64 *lbeta, const u64 *lgamma, const u64 *d_alphas,
                             size_t Q, u64 *d_out0, u64 *d_out1, hipStream_t s);
+bool launch_combine_residues(const u64 *d_residues, unsigned W, size_t E, unsigned n_cols, const u64 *h_a, u64 *d_out, hipStream_t s);
 void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
                                unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
@@ -180,6 +181,18 @@ int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride
     bj::launch_quotient_copy_perm(d_vars, var_stride, d_sigmas, sig_stride, d_stage2, stage2_stride, (const u64 *)nr.p, num_vars,
                                   chunk, log_n, log_lde, ctx->tw_fwd, h_beta, h_gamma, h_alphas, (const u64 *)al.p, num_points,
                                   first_point, nullptr, d_out0, d_out1, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+int bj_combine_residues(bj_ctx *ctx, const uint64_t *d_residues, unsigned world, size_t residue_len, unsigned num_cols,
+                        const uint64_t *h_moduli, uint64_t *d_out) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!d_residues || !h_moduli || !d_out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_combine_residues: null pointer");
+    if (world == 0 || world > 8 || residue_len == 0 || num_cols == 0 || num_cols > 65535)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_combine_residues: 1..8 residues of at least one coefficient, at most 65535 columns");
+    if (!bj::launch_combine_residues(d_residues, world, residue_len, num_cols, h_moduli, d_out, ctx->stream))
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_combine_residues: the moduli x^E - a_i are not pairwise distinct");
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

@@ -400,6 +400,14 @@ int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride
                           const uint64_t *d_stage2, size_t stage2_stride, const uint64_t *h_non_residues, unsigned num_vars,
                           unsigned chunk, unsigned log_n, unsigned log_lde, const uint64_t *h_beta, const uint64_t *h_gamma,
                           const uint64_t *h_alphas, size_t num_points, size_t first_point, uint64_t *d_out0, uint64_t *d_out1);
+/* Sharded quotient (the reference's single-host flow is prover.rs:1386-1482: evaluations on q cosets, one size-q n
+ * inverse transform): every rank evaluates the terms on q n / world points of its OWN cosets — first_point .. first_point +
+ * num_points of the three calls above may be a fraction of a coset — and inverse-transforms them (bj_intt_batch with the
+ * coset shift x_{first_point}) to R_i = T mod (x^E - a_i), E = residue_len, a_i = x_{first_point}^E.  This call solves the
+ * world x world Vandermonde system coefficient by coefficient: d_residues = [world][num_cols][E] (the all-gathered blocks),
+ * h_moduli[i] = a_i (pairwise distinct), d_out = [num_cols][world * E] = the monomial coefficients of T (canonical). */
+int bj_combine_residues(bj_ctx *ctx, const uint64_t *d_residues, unsigned world, size_t residue_len, unsigned num_cols,
+                        const uint64_t *h_moduli, uint64_t *d_out);
 
 typedef struct bj_circuit {
     unsigned log_n;              /* trace length 2^log_n */

@@ -7,6 +7,7 @@ prover.rs:1031-1227, utils.rs:770-817) in oracle/prover_ops.c — so that a regr
 import numpy as np
 import pytest
 
+import era_boojum_amd as E
 import oracle as O
 from era_boojum_amd import synthetic as S
 from gpu_util import DevBuf, ctx, rand_gl
@@ -205,3 +206,33 @@ def test_stage_operators_report_bad_arguments():
     with pytest.raises(E.BoojumHipError):
         ctx().quotient_copy_perm(d.ptr, 8, d.ptr, 8, d.ptr, 8, [1], 1, 4, 3, 7, BETA, GAMMA, [(1, 0)] * 2, 8, 0, d.ptr, d.ptr)   # LDE 128
     d.free()
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 9), (4, 9), (8, 9), (8, 5), (1, 6)])
+def test_residue_combination_of_the_sharded_quotient(world, log_n):
+    """bj_combine_residues against the definition: T (two columns, degree < q n) is reduced modulo x^E - a_i by hand (R_i[k] =
+    sum_j a_i^j T[j E + k]) for the moduli the sharded prover uses — a_i = x_{I0_i}^E, I0_i = the first LDE point of rank i, E =
+    q n / W points per rank — and the device's Vandermonde solve must give T back.  Equal moduli are refused."""
+    from tests import sharding_model as M
+    q, log_lde = 4, 3
+    n, P = 1 << log_n, E.P
+    Elen = q * n // world
+    rng = np.random.default_rng(world * 100 + log_n)
+    T = rng.integers(0, P, size=(2, q * n), dtype=np.uint64)
+    a = [pow(M.lde_coset_shift(log_n, log_lde, r * ((1 << log_lde) // world)), Elen, P) for r in range(world)]
+    res = np.zeros((world, 2, Elen), dtype=np.uint64)
+    for i in range(world):
+        for col in range(2):
+            acc = np.zeros(Elen, dtype=object)
+            ap = 1
+            for j in range(world):
+                acc = (acc + ap * T[col, j * Elen:(j + 1) * Elen].astype(object)) % P
+                ap = ap * a[i] % P
+            res[i, col] = acc.astype(np.uint64)
+    d_res, d_out = DevBuf(res), DevBuf(nelems=2 * q * n)
+    ctx().combine_residues(d_res.ptr, world, Elen, 2, a, d_out.ptr)
+    assert np.array_equal(d_out.get((2, q * n)), T)
+    if world > 1:
+        with pytest.raises(E.BoojumHipError, match="pairwise distinct"):
+            ctx().combine_residues(d_res.ptr, world, Elen, 2, [a[0]] * world, d_out.ptr)
+    d_res.free(); d_out.free()

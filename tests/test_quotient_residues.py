@@ -75,3 +75,25 @@ def test_two_cosets_per_rank_recover_the_quotient():
         a.append(pow(s, 2 * n, P))
     got = M.combine_residues(res, a)
     assert np.array_equal(got, T)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_even_split_over_all_ranks_recovers_the_quotient(world):
+    """What the sharded prover does since round 4 (csrc/prover.hip, bj_combine_residues): EVERY rank evaluates the first
+    E = q n / W points of its own coset range — two cosets (W = 2), one (W = 4) or the first HALF of one (W = 8: the points of
+    the coset shift * H_{n/2}, the even powers in the bit-reversed enumeration) — and the W residues modulo x^E - shift^E give T."""
+    log_n, log_lde, q = 5, 3, 4
+    n, L = 1 << log_n, 1 << log_lde
+    rng = np.random.default_rng(70 + world)
+    T = rng.integers(0, P, size=q * n, dtype=np.uint64)
+    ev = _evaluate_on_lde(T, log_n, log_lde).reshape(-1)          # flat LDE: index coset * n + i
+    E, per_rank = q * n // world, L * n // world
+    res, a = [], []
+    for r in range(world):
+        first_coset = r * (L // world)
+        s = M.lde_coset_shift(log_n, log_lde, first_coset)
+        pts = ev[r * per_rank:r * per_rank + E]
+        res.append(M.residue_from_coset(pts, s, O.ifft_natural_to_natural, O.bitreverse))
+        a.append(pow(s, E, P))
+    assert len(set(a)) == world
+    assert np.array_equal(M.combine_residues(res, a), T)
