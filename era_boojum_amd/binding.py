@@ -714,7 +714,7 @@ class ProverSetup:
         spec = (_GateDesc * max(1, len(spec_list)))()
         for i, g in enumerate(spec_list):                # gates over specialized columns: op lists, no selector
             spec[i].kind, spec[i].path_len = 5, 0
-            spec[i].num_repetitions, spec[i].var_stride, spec[i].const_stride, spec[i].num_terms = g.reps, g.var_stride, 0, g.num_terms
+            spec[i].num_repetitions, spec[i].var_stride, spec[i].const_stride, spec[i].num_terms = g.reps, g.var_stride, g.const_stride, g.num_terms
             spec[i].program = C.cast(C.pointer(g.program.struct), C.c_void_p)
         nr = np.array(c.non_residues, dtype=np.uint64)
         cols = (C.c_uint * max(1, len(c.public_inputs)))(*[p[0] for p in c.public_inputs])

@@ -155,12 +155,12 @@ void load_env() {
     e.bitrev_gather = set("BJ_BITREV_GATHER");
     if (set("BJ_NTT_FRONT")) e.ntt_front = atoi(getenv("BJ_NTT_FRONT"));
     e.ntt_first4_v = str("BJ_NTT_FIRST4_V").rfind("1", 0) == 0 ? 1 : 2;
+    if (set("BJ_NTT_FIRST4_MODE")) e.ntt_first4_mode = atoi(getenv("BJ_NTT_FIRST4_MODE"));
     e.ntt_inv_fused = str("BJ_NTT_INV_FUSED").rfind("0", 0) != 0;
     e.gate_no_aot = set("BJ_GATE_NO_AOT");
     e.gate_no_fuse = set("BJ_GATE_NO_FUSE");
     e.gate_no_jit = set("BJ_GATE_NO_JIT");
     e.gates_windowed = str("BJ_GATES_WINDOWED").rfind("0", 0) != 0;
-    e.copy_perm_generic = set("BJ_COPY_PERM_GENERIC");
     e.prove_no_absorb = set("BJ_PROVE_NO_ABSORB");
     if (set("BJ_PROVE_H2D_GROUP")) {
         const unsigned v = (unsigned)strtoul(getenv("BJ_PROVE_H2D_GROUP"), nullptr, 10);

@@ -267,8 +267,14 @@ __global__ void __launch_bounds__(256) ntt_strided4_kernel(R16Args a) {
 // these rounds are uniform per coset and live in LDS.  No tile and no barrier in the data path.  The pass is bound by its
 // 8 * (1 + cosets) * n bytes per column, so its butterflies ride on VALU slots that would idle anyway: the local pass behind
 // it then runs 10 rounds instead of 12 (ntt_local12_kernel<., 10>).
-template <bool SCALED, int V>
-__global__ void __launch_bounds__(256) ntt_first4_kernel(R16Args a, unsigned n_cosets) {
+// HOIST = true keeps the 16 (x V) input words of a lane in registers across the coset loop (206 VGPRs with V = 2: two waves per
+// SIMD, whose butterflies and stores then run one after the other: the pass took the SUM of its VALU time and its HBM time).
+// HOIST = false asks for them again for every coset through an opaque pointer — the seven repeats hit the L2 (a workgroup's
+// inputs are 64 KB) — so the register file holds one working set and four waves share a SIMD: stores of one wave drain under
+// the butterflies of the others.
+template <bool SCALED, int V, int WAVES /* 0: HOIST; else reload with this many waves per SIMD asked of the register allocator */>
+__global__ void __launch_bounds__(256, WAVES ? WAVES : 1) ntt_first4_kernel(R16Args a, unsigned n_cosets) {
+    constexpr bool HOIST = WAVES == 0;
     __shared__ u64 tws[64 * 16];                          // [coset][15 (+1 pad)]
     const size_t n = (size_t)1 << a.log_n, sl = n >> 4;
     for (u32 t = threadIdx.x; t < n_cosets * 15; t += blockDim.x) {
@@ -293,20 +299,23 @@ __global__ void __launch_bounds__(256) ntt_first4_kernel(R16Args a, unsigned n_c
             lo = p[0];
         }
     };
-    u64 in0[16], in1[V == 2 ? 16 : 1];
-    if (a.in_coset_stride == 0) {
+    const bool shared_input = a.in_coset_stride == 0;
+    u64 in0[HOIST ? 16 : 1], in1[HOIST && V == 2 ? 16 : 1];
+    if (HOIST && shared_input) {
 #pragma unroll
         for (int m = 0; m < 16; m++) load(src + (size_t)m * sl, in0[m], in1[V == 2 ? m : 0]);
     }
     for (unsigned c = 0; c < n_cosets; c++) {
         u64 x0[16], x1[V == 2 ? 16 : 1];
+        const u64 *cs = src + (size_t)c * a.in_coset_stride;
+        if (!HOIST) asm volatile("" : "+v"(cs));          // a fresh pointer per coset: the loads below stay inside the loop
 #pragma unroll
         for (int m = 0; m < 16; m++) {
-            if (a.in_coset_stride == 0) {
+            if (HOIST && shared_input) {
                 x0[m] = in0[m];
                 if (V == 2) x1[m] = in1[m];
             } else {
-                load(src + (size_t)c * a.in_coset_stride + (size_t)m * sl, x0[m], x1[V == 2 ? m : 0]);
+                load(cs + (size_t)m * sl, x0[m], x1[V == 2 ? m : 0]);
             }
         }
         const u64 *tw = tws + c * 16;
@@ -454,16 +463,20 @@ void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
     const size_t sl = ((size_t)1 << log_n) >> 4;
     // two adjacent indices per lane (16-byte accesses, 206 VGPRs: 2 waves per SIMD) or one (8-byte accesses, 4 waves)
     const int v = bj::env().ntt_first4_v;
+    const int mode = bj::env().ntt_first4_mode;      // 0: inputs hoisted (round 3), 3 / 4: reloaded per coset, waves per SIMD
     dim3 grid((unsigned)((sl / v + 255) / 256), n_cols, 1);
+#define BJ_FIRST4(SC, VV, WV) hipLaunchKernelGGL((ntt_first4_kernel<SC, VV, WV>), grid, dim3(256), 0, s, a, n_cosets)
     if (v == 2) {
-        if (round_scale)
-            hipLaunchKernelGGL((ntt_first4_kernel<true, 2>), grid, dim3(256), 0, s, a, n_cosets);
-        else
-            hipLaunchKernelGGL((ntt_first4_kernel<false, 2>), grid, dim3(256), 0, s, a, n_cosets);
+        if (round_scale) {
+            if (mode == 0) BJ_FIRST4(true, 2, 0); else if (mode == 3) BJ_FIRST4(true, 2, 3); else BJ_FIRST4(true, 2, 4);
+        } else {
+            if (mode == 0) BJ_FIRST4(false, 2, 0); else if (mode == 3) BJ_FIRST4(false, 2, 3); else BJ_FIRST4(false, 2, 4);
+        }
     } else if (round_scale)
-        hipLaunchKernelGGL((ntt_first4_kernel<true, 1>), grid, dim3(256), 0, s, a, n_cosets);
+        BJ_FIRST4(true, 1, 0);
     else
-        hipLaunchKernelGGL((ntt_first4_kernel<false, 1>), grid, dim3(256), 0, s, a, n_cosets);
+        BJ_FIRST4(false, 1, 0);
+#undef BJ_FIRST4
 }
 
 void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,

@@ -79,6 +79,7 @@ struct bj_setup {
     struct SpecGate {                        // a gate over specialized columns: op list, no selector, own columns
         bj::DevProgram program;
         unsigned reps = 0, width = 0, terms = 0, first_col = 0;
+        unsigned first_const = 0, const_width = 0;   // its constant columns: reps * const_width of them from first_const on
     };
     std::vector<SpecGate> spec;
     unsigned n_spec_terms = 0;
@@ -379,27 +380,38 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         for (unsigned b = 0; b < G.path_len; b++) f[6 + b] = G.path[b] ? 1 : 0;
         s->gates_flat.insert(s->gates_flat.end(), f, f + 12);
     }
-    {   // gates over specialized columns
+    {   // gates over specialized columns (evaluator_data.rs:124-240, prover.rs:635-800): their variable columns follow the lookup ones
+        // in declaration order; their constant columns follow the general-purpose gates' ones and the table-id column (which is the
+        // first "special purpose" constant: setup.rs:963-1010), num_repetitions * const_stride columns each — every repetition its
+        // own principal_width.num_constants columns (share_constants = false, per_repetition_offset.constants_offset = that width)
         unsigned col = c->num_gp_vars + c->lookup_width * c->lookup_reps;
+        unsigned spec_consts = 0;
+        for (unsigned g = 0; c->specialized_gates && g < c->num_specialized_gates; g++)
+            spec_consts += c->specialized_gates[g].num_repetitions * c->specialized_gates[g].const_stride;
+        if (spec_consts > c->num_constant_cols || (c->lookup_reps && c->table_id_col + 1 + spec_consts != c->num_constant_cols)) {
+            bj_setup_destroy(s);
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: %u constant columns declared; the specialized gates' %u must be the "
+                            "last ones, right behind the table-id column", c->num_constant_cols, spec_consts);
+        }
+        unsigned ccol = c->num_constant_cols - spec_consts;
         s->spec.resize(c->num_specialized_gates);
         for (unsigned g = 0; g < c->num_specialized_gates; g++) {
             const bj_gate_desc &G = c->specialized_gates[g];
             bool ok = c->specialized_gates && G.kind == BJ_GATE_PROGRAM && G.program && G.path_len == 0 && G.num_repetitions &&
                       G.var_stride && G.program->num_writes == G.num_terms;
+            unsigned ve = 0, ce = 0, we = 0;
             if (ok) {
-                unsigned ve = 0, ce = 0, we = 0;
                 bj::gate_program_extent(G.program, &ve, &ce, &we);
-                ok = ve <= G.var_stride && ce == 0 && we == 0;   // a repetition reads its own var_stride columns, no constants, no witness
-            }
-            for (uint32_t i = 0; ok && i < G.program->num_relations; i++) {
-                const bj_gate_relation &R = G.program->relations[i];
-                const bool binary = R.op == BJ_OP_ADD || R.op == BJ_OP_SUB || R.op == BJ_OP_MUL;
-                if (R.a.kind == BJ_IDX_CONSTANT_POLY || (binary && R.b.kind == BJ_IDX_CONSTANT_POLY)) ok = false;
+                // a repetition reads its own var_stride variable columns and its own const_stride constant columns, no witness column.
+                // Constants SHARED by the repetitions (share_constants = true with constants) are refused: the reference itself hands
+                // such an evaluator an empty constant range (per_repetition_offset.constants_offset = 0, prover.rs:748-772)
+                ok = ve <= G.var_stride && we == 0 && ce <= G.const_stride;
             }
             if (!ok) {
                 bj_setup_destroy(s);
-                return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: specialized gate %u must be an op list without a "
-                                "selector path that reads no constant column", g);
+                return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: specialized gate %u must be an op list without a selector path "
+                                "whose repetitions each read their own var_stride variable and const_stride constant columns "
+                                "(share_constants = false) and no witness column", g);
             }
             bj_setup::SpecGate &sg = s->spec[g];
             if (int prc = sg.program.upload(ctx, G.program)) {
@@ -407,7 +419,9 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
                 return prc;
             }
             sg.reps = G.num_repetitions; sg.width = G.var_stride; sg.terms = G.num_terms; sg.first_col = col;
+            sg.first_const = ccol; sg.const_width = G.const_stride;
             col += sg.reps * sg.width;
+            ccol += sg.reps * sg.const_width;
             s->n_spec_terms += sg.reps * sg.terms;
         }
         if (col != c->num_vars) {
@@ -813,8 +827,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         unsigned soff = 0;   // gates over specialized columns: every row, no selector
         const unsigned char no_path[8] = {0};
         for (const auto &sg : S->spec) {
-            bj::launch_gate_program(sg.program, wit_lde.p + (size_t)sg.first_col * Ln, Ln, d_con_lde, Ln, 0, no_path, sg.reps,
-                                    sg.width, 0, a_spec + 2 * (size_t)soff, Qe, t0, t1, nullptr, st);
+            bj::launch_gate_program(sg.program, wit_lde.p + (size_t)sg.first_col * Ln, Ln, d_con_lde + (size_t)sg.first_const * Ln, Ln, 0,
+                                    no_path, sg.reps, sg.width, sg.const_width, a_spec + 2 * (size_t)soff, Qe, t0, t1, nullptr, st);
             soff += sg.reps * sg.terms;
         }
     }

@@ -367,97 +367,6 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     out1[I] = gl::mul(r1, vi);
 }
 
-// The same terms for chunks of a COMPILE-TIME width (the quotient degree: 4 for every circuit of the bench's class).  The generic
-// kernel above walks its columns one at a time and waits for the two words of a column right after asking for them: 92 exposed
-// HBM round trips per lane, 2.7 TB/s — neither issue- nor bandwidth-bound (PMC, round 3).  Here a lane asks for ALL the words of
-// chunk j + 1 (its CHUNK variable and CHUNK sigma words and its partial product) before it multiplies chunk j out, so the memory
-// system always has a chunk per wave in flight; rhs_j is the partial product already loaded as lhs_{j-1} (two loads per chunk
-// fewer).  Same arithmetic, same accumulation order: identical results.
-template <unsigned CHUNK>
-__global__ void __launch_bounds__(256)
-quotient_copy_perm_chunked_kernel(const u64 *__restrict__ vars, size_t var_stride, const u64 *__restrict__ sigmas, size_t sig_stride,
-                                  const u64 *__restrict__ stage2, size_t s2_stride, const u64 *__restrict__ non_res, unsigned V,
-                                  unsigned n_chunks, unsigned log_n, const u64 *__restrict__ tw, CopyPermQArgs ca,
-                                  const u64 *__restrict__ alphas, size_t Q, size_t I0, const u64 *__restrict__ inv_xm1, u64 *out0,
-                                  u64 *out1) {
-    extern __shared__ u64 kbeta[];   // [V][2]: k_c * beta
-    for (unsigned t = threadIdx.x; t < 2 * V; t += blockDim.x)
-        kbeta[t] = gl::mul(non_res[t >> 1], (t & 1) ? ca.beta.c1 : ca.beta.c0);
-    __syncthreads();
-    const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (I >= Q) return;
-    const size_t n = (size_t)1 << log_n;
-    const unsigned coset = (unsigned)((I0 + I) >> log_n);
-    const u32 i_br = (u32)(I & (n - 1));
-    const u64 x = lde_point(tw, I0 + I);
-    // z(omega * x): next natural index inside the coset
-    const u32 i_next = gl::bitrev32((gl::bitrev32(i_br, log_n) + 1) & (u32)(n - 1), log_n);
-    const size_t In = (I - i_br) + i_next;
-    const gl::e2 z_shift{stage2[In], stage2[s2_stride + In]};
-    const gl::e2 zv_raw{stage2[I], stage2[s2_stride + I]};
-    const u64 ix = inv_xm1 ? inv_xm1[I] : 0;
-    const u64 acc0 = out0[I], acc1 = out1[I];
-    // chunk j: CHUNK (variable, sigma) pairs + the partial product that opens its left-hand chain
-    u64 w_cur[CHUNK], s_cur[CHUNK], w_nxt[CHUNK], s_nxt[CHUNK];
-    gl::e2 l_cur, l_nxt;
-    auto load_chunk = [&](unsigned j, u64 (&w)[CHUNK], u64 (&sg)[CHUNK], gl::e2 &l) {
-#pragma unroll
-        for (unsigned k = 0; k < CHUNK; k++) {
-            const unsigned c = j * CHUNK + k;      // < V: the launcher takes this kernel only when CHUNK divides V
-            w[k] = vars[(size_t)c * var_stride + I];
-            sg[k] = sigmas[(size_t)c * sig_stride + I];
-        }
-        if (j + 1 < n_chunks) l = gl::e2{stage2[((size_t)2 + 2 * j) * s2_stride + I], stage2[((size_t)3 + 2 * j) * s2_stride + I]};
-        else l = z_shift;
-    };
-    load_chunk(0, w_cur, s_cur, l_cur);
-    Acc160q s0, s1;
-    s0.clear();
-    s1.clear();
-    const gl::e2 zv{gl::canon(zv_raw.c0), gl::canon(zv_raw.c1)};
-    {   // (z - 1) * (x^n - 1) / (x - 1) * alpha
-        u64 l1 = gl::mul(ca.xn_minus_one[coset], inv_xm1 ? ix : inv_chain3(gl::sub(x, 1)));
-        gl::e2 t{gl::mul(gl::sub(zv.c0, 1), l1), gl::mul(zv.c1, l1)};
-        s0.fma(t.c0, ca.alpha_l1.c0);
-        s0.fma(t.c1, mul7q(ca.alpha_l1.c1));
-        s1.fma(t.c0, ca.alpha_l1.c1);
-        s1.fma(t.c1, ca.alpha_l1.c0);
-    }
-    gl::e2 rhs = zv;
-    for (unsigned j = 0; j < n_chunks; j++) {
-        if (j + 1 < n_chunks) load_chunk(j + 1, w_nxt, s_nxt, l_nxt);
-        gl::e2 lhs = l_cur;
-#pragma unroll
-        for (unsigned k = 0; k < CHUNK; k++) {
-            const unsigned c = j * CHUNK + k;
-            const u64 wg = gl::add_weak(w_cur[k], ca.gamma.c0);   // w + gamma_0, shared by both factors
-            const u64 sg = s_cur[k];
-            const gl::e2 d{gl::add_weak(gl::mul_weak(sg, ca.beta.c0), wg), gl::add_weak(gl::mul_weak(sg, ca.beta.c1), ca.gamma.c1)};
-            lhs = gl::e2_mul_weak(lhs, d);
-            const gl::e2 nm{gl::add_weak(gl::mul_weak(x, kbeta[2 * c]), wg), gl::add_weak(gl::mul_weak(x, kbeta[2 * c + 1]), ca.gamma.c1)};
-            rhs = gl::e2_mul_weak(rhs, nm);
-        }
-        const gl::e2 t{gl::sub_weak(lhs.c0, rhs.c0), gl::sub_weak(lhs.c1, rhs.c1)};
-        const u64 a0 = alphas[2 * j], a1 = alphas[2 * j + 1];
-        s0.fma(t.c0, a0);
-        s0.fma(t.c1, mul7q(a1));
-        s1.fma(t.c0, a1);
-        s1.fma(t.c1, a0);
-        rhs = l_cur;           // partial product j: the right-hand chain of chunk j + 1 starts from it
-        l_cur = l_nxt;
-#pragma unroll
-        for (unsigned k = 0; k < CHUNK; k++) {
-            w_cur[k] = w_nxt[k];
-            s_cur[k] = s_nxt[k];
-        }
-    }
-    u64 r0 = gl::add(gl::canon(acc0), s0.reduce());
-    u64 r1 = gl::add(gl::canon(acc1), s1.reduce());
-    const u64 vi = ca.vanishing_inv[coset];
-    out0[I] = gl::mul(r0, vi);
-    out1[I] = gl::mul(r1, vi);
-}
-
 // 1 / (x_I - 1) for the points I0 .. I0 + Q of the LDE domain: depends on the domain only, so a setup computes it once (the
 // fixed exponentiation is ~75 products per point, 3 % of quotient_copy_perm's arithmetic at 92 columns)
 __global__ void __launch_bounds__(256) inv_x_minus_one_kernel(const u64 *tw, size_t Q, size_t I0, u64 *out) {
@@ -614,12 +523,6 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
         }
     }
     const unsigned n_chunks = (V + chunk - 1) / chunk;
-    if (chunk == 4 && V % 4 == 0 && !bj::env().copy_perm_generic) {   // the bench's class: loads of the next chunk in flight under the products of this one
-        hipLaunchKernelGGL(quotient_copy_perm_chunked_kernel<4>, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 16, s, d_vars,
-                           var_stride, d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, n_chunks, log_n, d_tw_fwd, ca, d_alphas_cp, Q,
-                           I0, d_inv_xm1, d_out0, d_out1);
-        return;
-    }
     hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 16, s, d_vars, var_stride,
                        d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
                        d_alphas_cp, Q, I0, d_inv_xm1, d_out0, d_out1);

@@ -271,11 +271,14 @@ class Circuit:
 
 def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
                        lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False, boolean_columns=0, gates=None,
-                       max_allowed_constraint_degree=4, num_witness_cols=0):
+                       max_allowed_constraint_degree=4, num_witness_cols=0, specialized_constant_columns=0):
     """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
     (ConstantsAllocator, FMA, Reduction); the rest are Nop rows.  boolean_columns > 0 adds a BooleanConstraintGate placed
     over that many specialized columns (GatePlacementStrategy::UseSpecializedColumns, boolean_allocator.rs): every row of
-    those columns holds a bit, some of them linked to a copy of themselves in another boolean column."""
+    those columns holds a bit, some of them linked to a copy of themselves in another boolean column.
+    specialized_constant_columns > 0 adds, after it, a ConstantsAllocatorGate over that many specialized columns with
+    share_constants = false: every repetition has its own variable column and its own CONSTANT column (the last constant
+    columns, behind the table-id one: evaluator_data.rs:196-238, prover.rs:748-772), cell = constant on every row."""
     n = 1 << log_n
     rng = np.random.default_rng(seed)
     rand_f = lambda shape: rng.integers(0, P, size=shape, dtype=np.uint64)
@@ -289,8 +292,8 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     while q < max_deg - 1:
         q *= 2
     table_id_col = consts_for_gates
-    Kc = consts_for_gates + 1
-    V = num_gp_vars + lookup_width * lookup_reps + boolean_columns
+    Kc = consts_for_gates + 1 + specialized_constant_columns
+    V = num_gp_vars + lookup_width * lookup_reps + boolean_columns + specialized_constant_columns
     variables = np.zeros((V, n), dtype=np.uint64)
     witness = rand_f((num_witness_cols, n)) if num_witness_cols else None   # unconstrained cells hold anything: they are committed and opened all the same
     constants = np.zeros((Kc, n), dtype=np.uint64)
@@ -495,9 +498,21 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         if boolean_columns >= 2:                       # column 1 repeats column 0 on the first half: copy constraints
             bits[1, : n // 2] = bits[0, : n // 2]
             swaps.append((first, first + 1, slice(0, n // 2)))
-        variables[first:] = bits
+        variables[first:first + boolean_columns] = bits
         specialized.append(GateDesc(GATE_PROGRAM, "BooleanConstraintGate", 2, 0, 1, boolean_columns, 1, 0, 1, False,
                                     program=boolean_program()))
+    if specialized_constant_columns:
+        from .gate_program import constants_allocator_program
+        R = specialized_constant_columns
+        vals = rand_f((R, n))
+        vals[0, : n // 4] = 5                          # some rows share a value: a copy cycle between two of these cells
+        if R >= 2:
+            vals[1, : n // 4] = 5
+            swaps.append((V - R, V - R + 1, slice(0, n // 4)))
+        variables[V - R:] = vals
+        constants[Kc - R:] = vals
+        specialized.append(GateDesc(GATE_PROGRAM, "ConstantsAllocatorGate", 1, 1, 1, R, 1, 1, 1, False,
+                                    program=constants_allocator_program()))
     # --- sigma = id o link,  id(c, r) = k_c * omega^r; linked cells (the FMA chains) exchange identities
     ks = non_residues(V, n)
     om = F.powers(F.omega(log_n), n)
@@ -558,11 +573,14 @@ def check_satisfied(c: Circuit):
                     assert not t.any(), "%s unsatisfied" % g.name
     assert sum(m.sum() for m in sel_rows.values()) == n, "selector paths must partition the rows"
     col = c.num_gp_vars + c.num_lookup_vars
+    ccol = c.num_constant_cols - sum(g.reps * g.const_stride for g in c.specialized_gates)      # their constants: the last columns
     for g in c.specialized_gates:                       # every row, no selector
         for r in range(g.reps):
-            for t in g.program.evaluate_columns(var[col + r * g.var_stride: col + (r + 1) * g.var_stride], []):
+            ccols = [consts[ccol + r * g.const_stride + k] for k in range(g.const_stride)]
+            for t in g.program.evaluate_columns(var[col + r * g.var_stride: col + (r + 1) * g.var_stride], ccols):
                 assert not t.any(), "%s over specialized columns unsatisfied" % g.name
         col += g.reps * g.var_stride
+        ccol += g.reps * g.const_stride
     # copy constraints: sigma(c, r) = id(c', r')  =>  var[c, r] == var[c', r']
     ks = np.array(c.non_residues, dtype=np.uint64)
     om = F.powers(F.omega(c.log_n), n)

@@ -432,9 +432,13 @@ typedef struct bj_circuit {
     /* Gates placed with GatePlacementStrategy::UseSpecializedColumns (gate.rs; evaluator.rs:190-236, prover.rs:635-800):
      * no selector, applied on every row to their own variable columns, which follow the lookup columns in declaration
      * order (num_repetitions * var_stride columns each; num_vars counts them).  Each is an op list (kind BJ_GATE_PROGRAM,
-     * path_len 0) that reads no constant column — e.g. BooleanConstraintGate, the usual one.  Their quotient terms sit
-     * between the lookup terms and the general-purpose gates' terms in the order of the alpha powers (prover.rs:599-625).
-     * 0 / NULL when there are none. */
+     * path_len 0).  One that reads constants (share_constants = false: every repetition has its own principal_width.num_constants
+     * columns, const_stride = per_repetition_offset.constants_offset, evaluator_data.rs:196-238) finds them in the LAST constant
+     * columns — behind the general-purpose gates' constants and the table-id column, which is the first special-purpose
+     * constant (setup.rs:963-1010) — num_repetitions * const_stride columns per gate in declaration order (prover.rs:748-772);
+     * num_constant_cols counts them.  Constants shared by the repetitions are refused (the reference hands such an evaluator an
+     * empty constant range).  Their quotient terms sit between the lookup terms and the general-purpose gates' terms in the
+     * order of the alpha powers (prover.rs:599-625).  0 / NULL when there are none. */
     unsigned num_specialized_gates;
     const bj_gate_desc *specialized_gates;
 } bj_circuit;

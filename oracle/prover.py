@@ -129,12 +129,17 @@ def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec, wits_q=No
             s0, s1, aoff = weighted(prog, vcols, ccols, a_gates, aoff, wcols)
             acc0, acc1 = F.add(acc0, F.mul(s0, sel)), F.add(acc1, F.mul(s1, sel))
     col, aoff = c.num_gp_vars + c.lookup_reps * c.lookup_width, 0
+    # constants of the gates over specialized columns: the LAST constant columns (behind the general-purpose gates' ones and the
+    # table-id column), reps * const_stride per gate — every repetition its own (prover.rs:748-772, evaluator_data.rs:196-238)
+    ccol = c.num_constant_cols - sum(g.reps * g.const_stride for g in spec_gates)
     for g in spec_gates:
         for r in range(g.reps):
             vcols = [vars_q[col + r * g.var_stride + k] for k in range(g.var_stride)]
-            s0, s1, aoff = weighted(g.program, vcols, [], a_spec, aoff)
+            ccols = [con_q[ccol + r * g.const_stride + k] for k in range(g.const_stride)]
+            s0, s1, aoff = weighted(g.program, vcols, ccols, a_spec, aoff)
             acc0, acc1 = F.add(acc0, s0), F.add(acc1, s1)
         col += g.reps * g.var_stride
+        ccol += g.reps * g.const_stride
     return acc0, acc1
 
 

@@ -234,14 +234,17 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
     # gates over specialized columns: no selector, their own variable columns after the lookup ones (verifier.rs:1560-1638)
     from oracle.gates import EVALUATORS
     col, off = vk.num_gp_vars + vk.lookup_reps * vk.lookup_width, 0
+    ccol = vk.num_constant_cols - sum(g.reps * g.const_stride for g in vk.specialized_gates)   # their constants: the last columns
     for g in vk.specialized_gates:
         width, fn = EVALUATORS[g.name][0], EVALUATORS[g.name][5]
         for r in range(g.reps):
-            for term in fn(var_z[col + r * g.var_stride: col + r * g.var_stride + width], []):
+            cons = con_z[ccol + r * g.const_stride: ccol + (r + 1) * g.const_stride]   # its own per repetition (verifier.rs:1609-1633)
+            for term in fn(var_z[col + r * g.var_stride: col + r * g.var_stride + width], cons):
                 T = eadd(T, emul(term, a_spec[off]))
                 off += 1
         col += g.reps * g.var_stride
-    if off != n_spec_terms or col != vk.num_vars:
+        ccol += g.reps * g.const_stride
+    if off != n_spec_terms or col != vk.num_vars or ccol != vk.num_constant_cols:
         return fail("specialized gate bookkeeping")
     # gates (verifier.rs:1640-1720)
     off = 0

@@ -271,7 +271,7 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
         }
         // ---- gates over specialized columns (evaluator.rs:190-236): op lists without a selector ----
         let mut spec: Vec<bj_gate_desc> = Vec::new();
-        for ev in self.evaluation_data_over_specialized_columns.evaluators_over_specialized_columns.iter() {
+        for (idx, ev) in self.evaluation_data_over_specialized_columns.evaluators_over_specialized_columns.iter().enumerate() {
             if !matches!(ev.gate_purpose, GatePurpose::Evaluatable { .. }) {
                 continue; // the lookup marker
             }
@@ -289,6 +289,10 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
                 GatePlacementType::MultipleOnRow { per_chunk_offset } => per_chunk_offset.variables_offset as c_uint,
                 GatePlacementType::UniqueOnRow => capture_principal_width(capture) as c_uint,
             };
+            // its own constant columns per repetition (share_constants = false): per_repetition_offset.constants_offset of
+            // offsets_for_specialized_evaluators (evaluator_data.rs:196-238); the library finds the columns behind the table-id one
+            let (_initial, per_repetition, _available) = self.evaluation_data_over_specialized_columns.offsets_for_specialized_evaluators[idx];
+            d.const_stride = per_repetition.constants_offset as c_uint;
             d.program = &p.raw;
             programs.push(p);
             spec.push(d);

@@ -425,3 +425,46 @@ def test_dumps_with_witness_columns_through_the_c_abi():
     with pytest.raises(E.BoojumHipError, match="DenseWitnessCopyHint"):
         b.prove_from_dumps(wit_dump, M.write_variables_hint(var_ids))
     a.close(); b.close()
+
+
+def test_specialized_gate_with_its_own_constant_columns_equals_oracle_proof():
+    """Gates over specialized columns whose repetitions read their own CONSTANT columns (UseSpecializedColumns with
+    share_constants = false, prover.rs:700-790: constants_for_gates_over_general_purpose_columns + initial_offset.constants_offset,
+    per_repetition_offset.constants_offset): a BooleanConstraintGate over 2 columns and a ConstantsAllocatorGate over 3, whose
+    constants are the last three constant columns behind the table-id column.  The HIP proof equals the oracle prover's byte
+    for byte and the verifier restatement accepts it; a changed constant is reported by the prover's own check; descriptors that
+    would put the constants anywhere else are refused."""
+    import copy
+    from oracle import prover as OP
+    from oracle import verifier as OV
+    from test_gpu_prover import _compare
+    c = S.sha_shaped_circuit(10, seed=33, table_bits=2, boolean_columns=2, specialized_constant_columns=3)
+    assert c.num_vars == 60 + 32 + 5 and c.num_constant_cols == c.table_id_col + 4 and S.check_satisfied(c)
+    osetup = OP.Setup(c, 8, 16, threads=8)
+    po = OP.prove(c, osetup, 8, 16, security_level=30, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=30)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    gsetup.close()
+    bad = copy.copy(c)                                  # the same cells against another constant: the quotient is not a polynomial
+    bad.constants = c.constants.copy()
+    bad.constants[-1, 5] ^= np.uint64(1)
+    bsetup = E.ProverSetup(ctx(), bad, 8, 16, 30)
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        bsetup.prove()
+    bsetup.close()
+    wrong = copy.copy(c)                                # constant columns that do not add up to num_constant_cols
+    wrong.specialized_gates = [copy.copy(g) for g in c.specialized_gates]
+    wrong.specialized_gates[1].const_stride = 2
+    with pytest.raises(E.BoojumHipError, match="constant columns declared"):
+        E.ProverSetup(ctx(), wrong, 8, 16, 30)
+    shared = copy.copy(c)                               # share_constants = true with constants: refused, as the reference's own
+    shared.specialized_gates = [copy.copy(g) for g in c.specialized_gates]   # prover hands such an evaluator an empty range
+    shared.specialized_gates[1].const_stride = 0
+    shared.constants = c.constants[:-3]
+    shared.num_constant_cols = c.num_constant_cols - 3
+    with pytest.raises(E.BoojumHipError, match="share_constants = false"):
+        E.ProverSetup(ctx(), shared, 8, 16, 30)

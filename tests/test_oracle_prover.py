@@ -113,3 +113,34 @@ def test_coset_streaming_restatement_with_claimed_caps(small_case):
     got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, cap_cosets=(5,), claimed_caps=bad)
     assert not np.array_equal(got["cap_fragments"]["witness_oracle_cap"][5], np.asarray(bad["witness_oracle_cap"], dtype=np.uint64)[10:12])
     assert got["values_at_z"] != proof["values_at_z"]
+
+
+def test_specialized_gate_with_its_own_constant_columns():
+    """GatePlacementStrategy::UseSpecializedColumns { share_constants: false } for an evaluator that reads a constant inside
+    evaluate_once (ConstantsAllocatorGate): every repetition owns a variable column and a CONSTANT column; the constant columns
+    are the last ones, behind the general-purpose gates' constants and the table-id column (evaluator_data.rs:196-238,
+    prover.rs:748-772, verifier.rs:1609-1633).  The oracle prover's proof is accepted by the verifier restatement; a
+    verifier that places those constants one column off rejects it, and a changed constant makes the witness unsatisfying."""
+    from era_boojum_amd import synthetic as S
+    c = S.sha_shaped_circuit(8, seed=91, table_bits=2, boolean_columns=2, specialized_constant_columns=3)
+    assert c.num_vars == 60 + 32 + 2 + 3 and c.num_constant_cols == c.table_id_col + 1 + 3
+    assert [g.name for g in c.specialized_gates] == ["BooleanConstraintGate", "ConstantsAllocatorGate"]
+    assert S.check_satisfied(c)
+    setup = OP.Setup(c, 8, 16, threads=4)
+    proof = OP.prove(c, setup, 8, 16, security_level=20, threads=4)
+    vk = OV.VerificationKey(c, setup.cap, 8, 16)
+    assert OV.verify(vk, proof, verbose=True)
+    import copy
+    swapped = dict(proof)                                       # the openings of the last two constant columns exchanged: the
+    vz = [list(v) for v in proof["values_at_z"]]                # repetitions then read each other's constant
+    i = c.num_vars + c.num_constant_cols - 1
+    vz[i], vz[i - 1] = vz[i - 1], vz[i]
+    swapped["values_at_z"] = vz
+    assert not OV.verify(vk, swapped)
+    bad = copy.copy(c)
+    bad.constants = c.constants.copy()
+    bad.constants[-2, 17] ^= np.uint64(1)
+    with pytest.raises(AssertionError):
+        S.check_satisfied(bad)
+    with pytest.raises(AssertionError, match="unsatisfied"):
+        OP.prove(bad, OP.Setup(bad, 8, 16, threads=4), 8, 16, security_level=20, threads=4)
