@@ -241,7 +241,7 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be collected from inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh) is used when it matches the launch shape
     traffic, traffic_src, valu = None, None, None
-    for prof in ("r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
+    for prof in ("r04_pmc_bench_2p22_leaf_traffic.json", "r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
             if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
@@ -343,7 +343,7 @@ def main():
                       "achieved": round(nb / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": round(nb / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nb,
                       "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
-        for prof in ("r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
+        for prof in ("r04_cfg2_ntt_summary.json", "r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
             try:   # counters of the same two kernels from the committed rocprofv3 passes over tools/cfg2_ntt.py --cfg2-only
                 cs = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 out["ntt"]["pmc_from_committed_profile"] = {
@@ -351,6 +351,15 @@ def main():
                     "kernels": {k.split("(")[0].replace("void ", ""): {f: v[f] for f in
                                 ("avg_ms", "SQ_INSTS_VALU", "cycles_per_valu_instruction_per_simd", "valu_busy_estimate",
                                  "traffic_bytes", "traffic_over_algorithmic") if f in v} for k, v in cs["kernels"].items()}}
+                # the VALU roofline next to the HBM one: the passes are issue-bound (traffic = algorithmic bytes), so the fraction
+                # that says how close they are to THEIR ceiling is mix cost / measured cycles per wave instruction per SIMD
+                ks = out["ntt"]["pmc_from_committed_profile"]["kernels"]
+                out["ntt"]["valu_roofline_from_committed_profile"] = {
+                    "bound": "valu (integer issue)", "unit": "cycles per wave64 VALU instruction per SIMD",
+                    "mix_cost": 3.8, "measured": {k: v.get("cycles_per_valu_instruction_per_simd") for k, v in ks.items()},
+                    "frac": {k: v.get("valu_busy_estimate") for k, v in ks.items()},
+                    "note": "mix cost of a lazy butterfly from tools/microbench_ops.hip (6 v_mad_u64_u32 at ~4.3, 9 carry-class at ~4.4 "
+                            "per pair, 6 plain at ~2.6); the part runs these kernels at ~1.85 GHz (power), DESIGN.md §5"}
                 break
             except (OSError, KeyError, ValueError):
                 pass

@@ -17,7 +17,7 @@ struct EnvConfig {
     bool ntt_first_narrow = false, ntt_generic = false, ntt_generic_remainder = false, bitrev_gather = false;
     int ntt_front = 4;                  // BJ_NTT_FRONT: 0 remainder passes only, 5 first5 wherever it applies, default 4
     int ntt_first4_v = 2;               // BJ_NTT_FIRST4_V: indices per lane of the four-round front pass
-    int ntt_first4_mode = 3;            // BJ_NTT_FIRST4_MODE: 0 inputs of the front pass kept in registers across the cosets (round 3: two waves per SIMD); 3 / 4: re-read per coset (L2), that many waves
+    int ntt_first4_mode = 0;            // BJ_NTT_FIRST4_MODE: 0 inputs of the front pass kept in registers across the cosets (round 3: two waves per SIMD); 3 / 4: re-read per coset (L2), that many waves
     bool ntt_inv_fused = true;          // BJ_NTT_INV_FUSED=0: inverse transforms end in the separate bit-reversal sweep
     bool gate_no_aot = false, gate_no_fuse = false, gate_no_jit = false;
     bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
