@@ -139,6 +139,12 @@ int DevProgram::upload(bj_ctx *ctx, const bj_gate_program *p) {
     reads_witness = C.wit_extent != 0;
     fp[0] = C.fp[0];
     fp[1] = C.fp[1];
+    // the fingerprint selects build-time kernels and the hand-written Poseidon2 evaluator: a hit whose structural summary is not
+    // the recorded one (a collision of the non-cryptographic mix, accidental or constructed) is not a hit — the program keeps a
+    // fingerprint no table knows and goes to the run-time compiler / interpreter, which work from the op list itself
+    if ((gate_aot_known(fp[0], fp[1]) || gate_is_poseidon2_flattened(fp[0], fp[1])) &&
+        !gate_aot_summary_matches(fp[0], C.num_ops, C.num_slots, C.num_terms, C.var_extent, C.const_extent, C.wit_extent))
+        fp[0] = fp[1] = 0;
     const size_t bytes = rel.size() * sizeof(DevRelation) + vals.size() * 8 + 64;
     if (hipMalloc(&block, bytes) != hipSuccess) return fail(ctx, BJ_ERR_OOM, "gate program: allocation failed");
     char *base = (char *)block;
@@ -240,7 +246,8 @@ extern "C" int bj_gate_program_generated(const bj_gate_program *program) {
     bj::canon::Program C;
     std::string err;
     if (bj::canon::canonicalize(program, &C, &err)) return 0;
-    return (bj::gate_aot_known(C.fp[0], C.fp[1]) || bj::gate_is_poseidon2_flattened(C.fp[0], C.fp[1])) ? 1 : 0;
+    return ((bj::gate_aot_known(C.fp[0], C.fp[1]) || bj::gate_is_poseidon2_flattened(C.fp[0], C.fp[1])) &&
+            bj::gate_aot_summary_matches(C.fp[0], C.num_ops, C.num_slots, C.num_terms, C.var_extent, C.const_extent, C.wit_extent)) ? 1 : 0;
 }
 
 extern "C" int bj_gate_program_eval(bj_ctx *ctx, const bj_gate_program *program, const uint64_t *d_vars, size_t var_stride,

@@ -15,4 +15,7 @@ bool gate_aot_fusable(uint64_t fp0, uint64_t fp1);   // known AND light enough f
 // the fingerprint of the reference's own capture of Poseidon2FlattenedGate<8,12,4> without witness columns
 // (src/cs/gates/poseidon2.rs:166-391): such a program is run by the hand-written evaluator of gate_poseidon2.hip
 bool gate_is_poseidon2_flattened(uint64_t fp0, uint64_t fp1);
+// a fingerprint hit is believed only with the structural summary recorded at build time for that body (gate_aot.hip)
+bool gate_aot_summary_matches(uint64_t fp0, uint32_t num_ops, uint32_t num_slots, uint32_t num_terms, uint32_t var_extent,
+                              uint32_t const_extent, uint32_t wit_extent);
 }  // namespace bj

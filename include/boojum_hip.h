@@ -334,6 +334,11 @@ typedef struct bj_gate_desc {
  * list at bj_setup_create with hiprtc and cached per process (and on disk when BJ_GATE_JIT_CACHE names a directory);
  * (4) without hiprtc, or with BJ_GATE_NO_JIT set, an interpreter kernel runs the canonical schedule.  Same terms every way. */
 
+/* The fingerprint is a NON-CRYPTOGRAPHIC 128-bit mix of the canonical DAG (csrc/gate_canon.cpp): it selects kernels for op lists
+ * that come from a trusted host (the reference's own gpu_synthesizer), it is not a commitment to them.  A hit on a build-time
+ * kernel is believed only together with the program's structural summary (operations, slots, terms, column extents) recorded
+ * at build time, and the run-time compiler's caches are keyed by the emitted source text as well; a program that collides on
+ * purpose can at worst select the interpreter for itself. */
 /* 1 if the library carries a build-time kernel for this program's function (2 above), 0 otherwise.  Host-only, no GPU. */
 int bj_gate_program_generated(const bj_gate_program *program);
 
