@@ -26,8 +26,11 @@ def main():
     if log_n == 0:      # the real SHA-256 circuit of a 100-byte message (2^14 rows)
         from era_boojum_amd import sha256_circuit as SHA
         circuit = SHA.sha256_circuit(SHA.bench_message(100, seed=7))
+    elif log_n < 0:     # the golden proof's circuit class (155 columns, quotient degree 8, Poseidon2 flattened gate, a specialized gate)
+        circuit = S.recursion_like_circuit(-log_n, seed=7)
     else:
-        circuit = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2)
+        circuit = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2,
+                                       **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else {}))
     ctx = E.Context(dev)
     comm = E.TorchComm(ctx)
     setup = E.ProverSetup(ctx, circuit, fri, cap, sec, comm=comm)
