@@ -128,3 +128,24 @@ def combine_residues(residues, a_values):
         for k in range(m):
             out[j * m + k] = sum(Vinv[j][i] * res[i][k] for i in range(q)) % P
     return out
+
+
+def sharded_quotient_monomials(evals_local_bitrev, log_n, log_lde, q, world, rank, ifft_natural_to_natural, bitreverse, device=None):
+    """What prove_impl does for the quotient on W ranks (csrc/prover.hip, round 4): `evals_local_bitrev` = this rank's values of T on
+    the first E = q n / W points of ITS OWN coset range (one array of E words per component), inverse-transformed to the residue
+    T mod (x^E - a_rank), all-gathered (torch.distributed), combined.  Returns the q n coefficients of T per component."""
+    import torch
+    import torch.distributed as dist
+    n, L = 1 << log_n, 1 << log_lde
+    E = q * n // world
+    shift = lde_coset_shift(log_n, log_lde, rank * (L // world))
+    mine = np.stack([np.asarray(residue_from_coset(col, shift, ifft_natural_to_natural, bitreverse), dtype=np.uint64)
+                     for col in evals_local_bitrev])
+    t = torch.from_numpy(mine.view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    res = [o.cpu().numpy().view(np.uint64) for o in out]                       # [world][components][E]
+    a = [pow(lde_coset_shift(log_n, log_lde, r * (L // world)), E, P) for r in range(world)]
+    return np.stack([combine_residues([res[r][comp] for r in range(world)], a) for comp in range(mine.shape[0])])

@@ -104,6 +104,50 @@ def test_coset_sharded_commit_and_column_sharding(world):
             assert np.array_equal(cols, O.fft_batch(mono, 7))
 
 
+def _quotient_worker(rank, world, port, log_n, log_lde, quot_deg, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import oracle as O
+    import sharding_model as sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, L = 1 << log_n, 1 << log_lde
+        rng = np.random.default_rng(321)                   # the same T on every rank: each evaluates ITS points of it
+        T = rng.integers(0, O.P, size=(2, quot_deg * n), dtype=np.uint64)
+        E, per_rank = quot_deg * n // world, L * n // world
+        local = []
+        for comp in range(2):
+            # T on this rank's first E points: its cosets of the size-L*n domain are extensions of the monomials T (zero-padded)
+            mono = np.zeros(L * n, dtype=np.uint64)
+            mono[:quot_deg * n] = T[comp]
+            full = O.fft_natural_to_bitreversed(mono, 7)   # bit-reversed enumeration of 7 * <w_{Ln}>: flat index = coset * n + i
+            local.append(full[rank * per_rank: rank * per_rank + E])
+        got = sharding.sharded_quotient_monomials(local, log_n, log_lde, quot_deg, world, rank, O.ifft_natural_to_natural, O.bitreverse)
+        q.put((rank, np.array_equal(got, T)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_quotient_residues_over_gloo(world):
+    """The quotient's exchange step on W processes (csrc/prover.hip since round 4): every rank evaluates q n / W points of its own
+    cosets (here: reads them off a size-L*n transform of a random T), inverse-transforms its piece, the residues are
+    all-gathered over gloo and combined — every rank ends with the coefficients of T."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_quotient_worker, args=(r, world, port, 5, 3, 4, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in results) == list(range(world)) and all(ok for _, ok in results)
+
+
 def test_partition_helpers():
     import sharding_model as S
     for n_cols in (0, 1, 7, 93, 256):
