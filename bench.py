@@ -437,7 +437,23 @@ def main():
         # the bounded sample: 2^20 rows (BASELINE cfg3's size, a quarter of the bench's; the oracle proves it in ~40 s on 16 cores)
         # unless the calibration says this host would need minutes, then the 2^18 one alone
         est_main = 40.0 * (3.0e6 / max(perm_rate, 1.0)) * (2.0 ** (args.cpu_log_n - 20))
-        main_log = args.cpu_log_n if est_main < 150.0 else min(args.cpu_log_n, args.cpu_micro_log_n)
+        # the full oracle prover keeps every LDE in host memory: ~60 GB at 2^20 rows (x4 per step of log n); leave a wide margin
+        ram_gb = 0.0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable:"):
+                    ram_gb = int(line.split()[1]) / 1e6
+            for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+                try:
+                    text = open(path).read().strip()
+                    if text.isdigit():
+                        ram_gb = min(ram_gb, int(text) / 1e9)
+                except OSError:
+                    pass
+        except OSError:
+            pass
+        need_gb = 64.0 * (2.0 ** (args.cpu_log_n - 20))
+        main_log = args.cpu_log_n if (est_main < 150.0 and ram_gb >= 2.5 * need_gb) else min(args.cpu_log_n, args.cpu_micro_log_n)
         t_cpu, busy_cores = oracle_proof(main_log)
         small = None
         if args.cpu_micro_log_n < main_log:
