@@ -48,11 +48,13 @@ copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     const size_t base = (size_t)blockIdx.x * (256 * RAT_PTS) + threadIdx.x;
     const unsigned j = blockIdx.y;
     gl::e2 num[RAT_PTS], den[RAT_PTS];
-    u64 x[RAT_PTS];
+    u64 xb0[RAT_PTS], xb1[RAT_PTS];       // x * beta, once per point: a column's k_c * x * beta is then two products instead of three
 #pragma unroll
     for (int k = 0; k < RAT_PTS; k++) {
         const size_t r = base + (size_t)k * 256;
-        x[k] = r < n ? omega_pow_nat(tw, log_n, (u32)r) : 0;
+        const u64 x = r < n ? omega_pow_nat(tw, log_n, (u32)r) : 0;
+        xb0[k] = gl::mul_weak(x, beta.c0);
+        xb1[k] = gl::mul_weak(x, beta.c1);
         num[k] = {1, 0};
         den[k] = {1, 0};
     }
@@ -66,8 +68,7 @@ copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
             // once, after the last column, instead of after every operation
             const u64 w = vars[(size_t)i * var_stride + r];
             const u64 wg = gl::add_weak(w, gamma.c0);
-            const u64 kx = gl::mul_weak(kr, x[k]);
-            const gl::e2 a{gl::add_weak(gl::mul_weak(kx, beta.c0), wg), gl::add_weak(gl::mul_weak(kx, beta.c1), gamma.c1)};
+            const gl::e2 a{gl::add_weak(gl::mul_weak(kr, xb0[k]), wg), gl::add_weak(gl::mul_weak(kr, xb1[k]), gamma.c1)};
             const u64 s = sigmas[(size_t)i * sig_stride + r];
             const gl::e2 b{gl::add_weak(gl::mul_weak(s, beta.c0), wg), gl::add_weak(gl::mul_weak(s, beta.c1), gamma.c1)};
             num[k] = gl::e2_mul_weak(num[k], a);
