@@ -399,7 +399,8 @@ int bj_quotient_lookup(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_st
 /* (z - 1) * L1 (prover.rs:1189-1227), the copy-permutation chain compute_quotient_terms_in_extension
  * (copy_permutation.rs:1000-1249) and divide_by_vanishing_for_bitreversed_coset_enumeration (utils.rs:770-817): ADDS the
  * terms to d_out and then multiplies by 1 / (x^n - 1).  Points are the flat LDE indices first_point .. first_point +
- * num_points (whole cosets of 2^log_n, bit-reversed inside); d_stage2 = z, partial products as (c0, c1) columns;
+ * num_points (first_point at a coset boundary, bit-reversed inside a coset; num_points need not be whole cosets: a rank of a
+ * sharded proof evaluates the first q n / world points of its range, bj_combine_residues below); d_stage2 = z, partial products as (c0, c1) columns;
  * h_alphas: 1 (L1 term) + n_chunks powers. */
 int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, const uint64_t *d_sigmas, size_t sig_stride,
                           const uint64_t *d_stage2, size_t stage2_stride, const uint64_t *h_non_residues, unsigned num_vars,
