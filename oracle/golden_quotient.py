@@ -47,7 +47,10 @@ def quotient_identity(geometry, general_gates, specialized_gates, non_residues, 
     w, reps = (lk["width"], lk["num_repetitions"]) if lk else (0, 0)
     n_spec_vars = sum(EVALUATORS[name][0] * r for name, r in specialized_gates)
     V = Vgp + w * reps + n_spec_vars
-    nC = geometry["num_constant_columns"] + geometry["extra_constant_polys_for_selectors"] + len(geometry["table_ids_column_idxes"])
+    # constant columns: general-purpose gates' | table id | per-repetition constants of the gates over specialized columns
+    # (share_constants = false, evaluator_data.rs:196-238; EVALUATORS[name][3] = constants one repetition reads inside evaluate_once)
+    n_spec_consts = sum(EVALUATORS[name][3] * r for name, r in specialized_gates)
+    nC = geometry["num_constant_columns"] + geometry["extra_constant_polys_for_selectors"] + len(geometry["table_ids_column_idxes"]) + n_spec_consts
     n_chunks = (V + q - 1) // q
     it = iter([tuple(v) for v in values_at_z])
     take = lambda k: [next(it) for _ in range(k)]
@@ -94,14 +97,15 @@ def quotient_identity(geometry, general_gates, specialized_gates, non_residues, 
         T = eadd(T, emul(esub(emul(B_z[0], d), mult_z[0]), alphas[pos]))
         pos += 1
     # gates over specialized columns: no selector, own variable columns after the lookup ones (evaluator_data.rs:190-236)
-    off = Vgp + w * reps
+    off, coff = Vgp + w * reps, nC - n_spec_consts
     for name, r in specialized_gates:
         width, _, n_shared, cstride, n_terms, fn = EVALUATORS[name]
         for k in range(r):
-            for term in fn(var_z[off + k * width: off + (k + 1) * width], []):
+            for term in fn(var_z[off + k * width: off + (k + 1) * width], con_z[coff + k * cstride: coff + (k + 1) * cstride]):
                 T = eadd(T, emul(term, alphas[pos]))
                 pos += 1
         off += width * r
+        coff += cstride * r
     # gates over general-purpose columns (verifier.rs:1640-1720)
     for idx, (name, r) in enumerate(zip(general_gates, gp_reps)):
         width, _, n_shared, cstride, n_terms, fn = EVALUATORS[name]

@@ -58,12 +58,15 @@ def vk_from_reference_geometry(geometry, setup_cap, general_gates, specialized_g
     for name, r in specialized_gates:
         g = _Gate()
         g.name, g.kind, g.path, g.reps = name, 0, [], r
-        g.var_stride, g.const_stride, g.num_terms = EVALUATORS[name][0], 0, EVALUATORS[name][4]
+        # per-repetition constants (share_constants = false) of an evaluator that reads them inside evaluate_once: its own columns
+        # behind the table-id column (evaluator_data.rs:196-238); 0 for the BooleanConstraintGate of the golden proof
+        g.var_stride, g.const_stride, g.num_terms = EVALUATORS[name][0], EVALUATORS[name][3], EVALUATORS[name][4]
         vk.specialized_gates.append(g)
     vk.log_n, vk.n = n.bit_length() - 1, n
     vk.num_gp_vars = vgp
     vk.num_vars = vgp + w * reps + sum(g.reps * g.var_stride for g in vk.specialized_gates)
-    vk.num_constant_cols = geometry["num_constant_columns"] + geometry["extra_constant_polys_for_selectors"] + len(geometry["table_ids_column_idxes"])
+    vk.num_constant_cols = (geometry["num_constant_columns"] + geometry["extra_constant_polys_for_selectors"] + len(geometry["table_ids_column_idxes"])
+                            + sum(g.reps * g.const_stride for g in vk.specialized_gates))
     vk.lookup_reps, vk.lookup_width = reps, w
     vk.table_id_col = geometry["table_ids_column_idxes"][0] if lk else 0
     vk.quotient_degree = geometry["quotient_degree"]

@@ -448,6 +448,26 @@ def test_specialized_gate_with_its_own_constant_columns_equals_oracle_proof():
     pg = proof_format.parse(buf, security_level=30)
     _compare(pg, po)
     assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    # the golden-pinned quotient-identity code (oracle/golden_quotient.py), fed with the VerificationKey JSON this repository emits
+    import json
+    import oracle as O
+    from oracle import golden_quotient as GQ
+    from era_boojum_amd import wire_format as W
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, gsetup.cap(), 8, 16)))
+    t = O.Transcript()
+    t.absorb_cap(gsetup.cap())
+    t.absorb(pg["public_inputs"])
+    t.absorb_cap(np.array(pg["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(pg["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(pg["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), [g.name for g in c.gates],
+                                    [("BooleanConstraintGate", 2), ("ConstantsAllocatorGate", 3)], c.non_residues,
+                                    dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    pg["values_at_z"], pg["values_at_z_omega"][0])
+    assert lhs == rhs
     gsetup.close()
     bad = copy.copy(c)                                  # the same cells against another constant: the quotient is not a polynomial
     bad.constants = c.constants.copy()

@@ -130,6 +130,26 @@ def test_specialized_gate_with_its_own_constant_columns():
     proof = OP.prove(c, setup, 8, 16, security_level=20, threads=4)
     vk = OV.VerificationKey(c, setup.cap, 8, 16)
     assert OV.verify(vk, proof, verbose=True)
+    # the quotient-identity code that the reference's own proof pins (oracle/golden_quotient.py), in the reference's VK layout
+    import json
+    import oracle as O
+    from era_boojum_amd import wire_format as W
+    from oracle import golden_quotient as GQ
+    vkj = json.loads(W.dumps(W.vk_to_reference_json(c, setup.cap, 8, 16)))
+    t = O.Transcript()
+    t.absorb_cap(setup.cap)
+    t.absorb(proof["public_inputs"])
+    t.absorb_cap(np.array(proof["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(proof["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(proof["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vkj), [g.name for g in c.gates],
+                                    [("BooleanConstraintGate", 2), ("ConstantsAllocatorGate", 3)], c.non_residues,
+                                    dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    proof["values_at_z"], proof["values_at_z_omega"][0])
+    assert lhs == rhs
     import copy
     swapped = dict(proof)                                       # the openings of the last two constant columns exchanged: the
     vz = [list(v) for v in proof["values_at_z"]]                # repetitions then read each other's constant
