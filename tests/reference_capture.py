@@ -9,6 +9,12 @@ from the reference's `evaluate_once` — under this module's recording context, 
 checks those bodies as FUNCTIONS are independent formulas (oracle/gates.py, pinned by the reference's own proof, and
 tests/test_gate_programs.py).
 
+Round-4 audit: the `evaluate_*` bodies of era_boojum_amd/gate_program.py (and the trait defaults `mul_and_accumulate_into` /
+`small_pow`, field_like.rs:70-106) were read again side by side with the reference's `evaluate_once` for reduction, constants
+allocator, boolean, selection, parallel selection, conditional swap, dot product, quadratic combination, reduction by powers,
+simple non-linearity, u32 add, u32 sub, FMA in the extension and the matrix gate: same calls in the same order, statement by
+statement.  A reference-PRODUCED capture would still be the only pin of the order; no Rust toolchain here can produce one.
+
 `to_program` is the Python mirror of `OwnedProgram::from_capture` in rust/prove_hip.rs (dense renumbering in definition order,
 field constants into the value table); `to_program_raw` keeps the reference's sparse numbers."""
 from era_boojum_amd import gate_program as GP
