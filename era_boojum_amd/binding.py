@@ -132,7 +132,7 @@ def exported_symbols():
 _lib = None
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def load_library():
@@ -556,7 +556,7 @@ class _Circuit(C.Structure):
 
 class _ProofConfig(C.Structure):
     _fields_ = [("fri_lde_factor", C.c_uint), ("cap_size", C.c_uint), ("security_level", C.c_uint), ("pow_bits", C.c_uint),
-                ("transcript", C.c_uint), ("tree_hasher", C.c_uint)]
+                ("transcript", C.c_uint), ("tree_hasher", C.c_uint), ("pow_runner", C.c_uint)]
 
 
 STAGE_NAMES = ["witness_lde_and_tree", "second_stage", "quotient_work_and_lde", "openings_at_z",
@@ -688,8 +688,9 @@ class ProverSetup:
     (bj_setup_create_sharded)."""
 
     def __init__(self, ctx, circuit, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, comm=None,
-                 transcript="poseidon2", setup_base_dump=None):
-        """setup_base_dump: the bytes of the reference's `SetupBaseStorage::write_into_buffer` (bj_setup_create_from_dump): the
+                 transcript="poseidon2", setup_base_dump=None, pow_runner="blake2s"):
+        """pow_runner: "blake2s" | "keccak256" — the PoWRunner (pow.rs), independent of the transcript as in the reference.
+        setup_base_dump: the bytes of the reference's `SetupBaseStorage::write_into_buffer` (bj_setup_create_from_dump): the
         columns, constant-column count, table-id column, selector paths, quotient degree and non-residues then come from the
         dump / are computed by the library, and `circuit` only has to carry the geometry and the gate list."""
         self._ctx, self._lib, self.circuit = ctx, ctx._lib, circuit
@@ -726,7 +727,8 @@ class ProverSetup:
                       cols, rows, len(spec_list), spec if spec_list else None)
         self.transcript_kind = {"poseidon2": 1, "poseidon": 2, "blake2s": 3, "keccak256": 4}[transcript]
         self.hasher_kind = {"blake2s": 2, "keccak256": 3}.get(transcript, 1)      # Transcript::CompatibleCap = TreeHasher::Output
-        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind, self.hasher_kind)
+        cfg = _ProofConfig(fri_lde_factor, cap_size, security_level, pow_bits, self.transcript_kind, self.hasher_kind,
+                           {"blake2s": 1, "keccak256": 2}[pow_runner])
         sig = np.ascontiguousarray(c.sigmas, dtype=np.uint64)
         con = np.ascontiguousarray(c.constants, dtype=np.uint64)
         tab = np.ascontiguousarray(c.tables, dtype=np.uint64)

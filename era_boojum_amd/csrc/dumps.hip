@@ -243,13 +243,14 @@ int bj_setup_create_from_dump(bj_ctx *ctx, const bj_circuit *circuit, const void
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "SetupBaseStorage dump: %zu copy-permutation polynomials, the circuit has %u variable columns",
                         sig.cols.size(), circuit->num_vars);
     const bool lookups = circuit->lookup_reps != 0;
-    if (lookups && (ids.size() != 1 || tab.cols.size() != circuit->lookup_width + 1))
-        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "SetupBaseStorage dump: specialized lookups with a shared table id need one table-id "
+    // one table-id column: UseSpecializedColumnsWithTableIdAsConstant { share_table_id }; none: ..AsVariable (setup.rs:970-990)
+    if (lookups && (ids.size() > 1 || tab.cols.size() != circuit->lookup_width + 1))
+        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "SetupBaseStorage dump: specialized lookups need at most one (shared) table-id "
                         "column and width + 1 table columns (%zu ids, %zu table columns)", ids.size(), tab.cols.size());
     // what the dump knows better than the caller: constant columns, the table-id column, selector paths, the quotient degree
     bj_circuit c = *circuit;
     c.num_constant_cols = (unsigned)con.cols.size();
-    if (lookups) c.table_id_col = (unsigned)ids[0];
+    if (lookups) c.table_id_col = ids.empty() ? BJ_TABLE_ID_AS_VARIABLE : (unsigned)ids[0];
     std::vector<bj_gate_desc> gates(circuit->gates, circuit->gates + circuit->num_gates);
     for (unsigned g = 0; g < circuit->num_gates; g++) {
         if (!walk.seen[g] && gates[g].kind != BJ_GATE_NOP && gates[g].num_terms)

@@ -151,7 +151,35 @@ __global__ void __launch_bounds__(256) keccak_nodes_kernel(const u64 *prev, u64 
     st.store(next + 4 * i);
 }
 
+// Proof of work (impl PoWRunner for Keccak256, src/cs/implementations/pow.rs:139-230): the smallest nonce such that the first
+// 8 digest bytes of Keccak256(seed || le64(nonce)), read as a little-endian u64, have >= pow_bits trailing zeros.  seed = 5 field
+// elements = 40 bytes, so seed || nonce is six lanes of one rate block; lane = nonce, the minimum over the launch.
+struct KeccakPowSeed {
+    u64 w[5];
+};
+__global__ void __launch_bounds__(256) keccak_pow_kernel(KeccakPowSeed seed, unsigned pow_bits, u64 base, u64 count, unsigned long long *result) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u64 nonce = base + i;
+    Keccak st;
+    st.init();
+#pragma unroll
+    for (int k = 0; k < 5; k++) st.a[k] = seed.w[k];
+    st.a[5] = nonce;
+    st.pad_and_permute(6);   // 48 message bytes = 6 lanes
+    const u64 first = st.a[0];
+    const unsigned tz = first ? (unsigned)__builtin_ctzll(first) : 64u;
+    if (tz >= pow_bits) atomicMin(result, (unsigned long long)nonce);
+}
+
 }  // namespace
+
+void launch_keccak_pow(const u64 *seed5, unsigned pow_bits, u64 base, u64 count, u64 *d_result, hipStream_t s) {
+    KeccakPowSeed ps;
+    for (int k = 0; k < 5; k++) ps.w[k] = seed5[k];
+    hipLaunchKernelGGL(keccak_pow_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, ps, pow_bits, base, count,
+                       (unsigned long long *)d_result);
+}
 
 void launch_keccak_leaves(const u64 *d_base, size_t col_stride, const u64 *const *d_col_ptrs, unsigned n_cols,
                           size_t num_leaves, u64 *d_digests, hipStream_t s) {

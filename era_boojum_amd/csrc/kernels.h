@@ -77,6 +77,7 @@ void launch_keccak_leaves(const u64 *d_base, size_t col_stride, const u64 *const
 void launch_keccak_leaves_chunked(const u64 *d_src0, const u64 *d_src1, unsigned n_srcs, unsigned log_e, size_t num_leaves,
                                   u64 *d_digests, hipStream_t s);
 void launch_keccak_node_layers(u64 *d_tree, size_t num_leaves, size_t cap_size, hipStream_t s);
+void launch_keccak_pow(const u64 *seed5, unsigned pow_bits, u64 base, u64 count, u64 *d_result, hipStream_t s);
 // Blake2s proof of work over nonces [base, base + count): atomicMin of the valid ones into *d_result (pre-set to ~0)
 void launch_blake2s_pow(const u64 *seed5, unsigned pow_bits, u64 base, u64 count, u64 *d_result, hipStream_t s);
 

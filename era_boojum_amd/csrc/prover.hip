@@ -72,6 +72,8 @@ struct bj_setup {
     // circuit
     unsigned log_n = 0, V = 0, num_gp_vars = 0, nC = 0, lookup_w = 0, lookup_reps = 0, table_id_col = 0, q = 0;
     unsigned Wc = 0;               // non-copiable witness columns (behind the V variable columns in the witness oracle)
+    bool tid_var = false;          // UseSpecializedColumnsWithTableIdAsVariable: the table id is the last of lookup_cps = lookup_w + 1
+    unsigned lookup_cps = 0;       // variable columns of a sub-argument (specialized_columns_per_subargument, cs/mod.rs:300-312)
     std::vector<unsigned> gate_wit_stride;   // per general-purpose gate: per_chunk_offset.witnesses_offset
     std::vector<int> gates_flat;   // 12 ints per gate
     std::vector<bj::DevProgram> programs;   // per gate; empty (block == nullptr) unless kind == BJ_GATE_PROGRAM
@@ -87,6 +89,7 @@ struct bj_setup {
     std::vector<unsigned> pub_cols, pub_rows;
     // proof config
     unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0, transcript = BJ_TRANSCRIPT_POSEIDON2, hasher = BJ_HASHER_POSEIDON2;
+    unsigned pow_runner = BJ_POW_BLAKE2S256;   // the POW type parameter of prove_cpu_basic (pow.rs:6-31)
     unsigned L = 0, log_L = 0, log_fri = 0, log_q = 0;
     unsigned n_cols = 0;           // V sigmas + nC constants + (w+1) tables
     // shard of the LDE domain held by this GPU: cosets [c0, c0 + cl), i.e. flat indices [c0*n, (c0+cl)*n)
@@ -278,9 +281,15 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
                             i, c->public_input_cols[i], c->public_input_rows[i], c->num_vars, c->log_n);
     if (cfg->pow_bits > 32 || cfg->pow_bits >= cfg->security_level)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: pow_bits must be <= 32 and below the security level (pow.rs:53, prover.rs:2293)");
-    if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || c->table_id_col >= c->num_constant_cols))
+    if (cfg->pow_runner > BJ_POW_KECCAK256)
+        return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: pow_runner %u (0 / BJ_POW_BLAKE2S256 / BJ_POW_KECCAK256)", cfg->pow_runner);
+    // LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (cs/mod.rs:237-241): table_ids_column_idxes is empty (setup.rs:970-971)
+    // and a sub-argument owns width + 1 variable columns, the last one the table id (lookup_argument_in_ext.rs:354-366, 949-1000)
+    const bool tid_var = c->lookup_reps && c->table_id_col == BJ_TABLE_ID_AS_VARIABLE;
+    const unsigned lookup_cps = c->lookup_width + (tid_var ? 1u : 0u);
+    if (c->lookup_reps && (!h_tables || c->lookup_width == 0 || c->lookup_width > 8 || (!tid_var && c->table_id_col >= c->num_constant_cols)))
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad lookup parameters");
-    if (c->num_vars < c->num_gp_vars + c->lookup_width * c->lookup_reps || !c->non_residues)
+    if ((uint64_t)c->num_vars < (uint64_t)c->num_gp_vars + (uint64_t)lookup_cps * c->lookup_reps || !c->non_residues)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: bad column counts");
     if (c->num_vars > 4096)   // the copy-permutation quotient keeps k_c * beta of every column in LDS (16 bytes per column)
         return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_setup_create: %u copiable columns, at most 4096 are supported", c->num_vars);
@@ -316,7 +325,8 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     }
     s->log_n = c->log_n; s->V = c->num_vars; s->num_gp_vars = c->num_gp_vars; s->nC = c->num_constant_cols;
     s->Wc = c->num_witness_cols;
-    s->lookup_w = c->lookup_width; s->lookup_reps = c->lookup_reps; s->table_id_col = c->table_id_col;
+    s->lookup_w = c->lookup_width; s->lookup_reps = c->lookup_reps; s->table_id_col = tid_var ? 0 : c->table_id_col;
+    s->tid_var = tid_var; s->lookup_cps = lookup_cps;
     s->q = c->quotient_degree;
     s->n_gates = c->num_gates;
     if (c->num_gates > 16) {
@@ -384,16 +394,21 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         // in declaration order; their constant columns follow the general-purpose gates' ones and the table-id column (which is the
         // first "special purpose" constant: setup.rs:963-1010), num_repetitions * const_stride columns each — every repetition its
         // own principal_width.num_constants columns (share_constants = false, per_repetition_offset.constants_offset = that width)
-        unsigned col = c->num_gp_vars + c->lookup_width * c->lookup_reps;
-        unsigned spec_consts = 0;
-        for (unsigned g = 0; c->specialized_gates && g < c->num_specialized_gates; g++)
-            spec_consts += c->specialized_gates[g].num_repetitions * c->specialized_gates[g].const_stride;
-        if (spec_consts > c->num_constant_cols || (c->lookup_reps && c->table_id_col + 1 + spec_consts != c->num_constant_cols)) {
-            bj_setup_destroy(s);
-            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: %u constant columns declared; the specialized gates' %u must be the "
-                            "last ones, right behind the table-id column", c->num_constant_cols, spec_consts);
+        // (64-bit sums: the sizes are the caller's, a wrapped 32-bit total must not pass the range checks)
+        uint64_t col = (uint64_t)c->num_gp_vars + (uint64_t)lookup_cps * c->lookup_reps;
+        uint64_t spec_consts = 0;
+        for (unsigned g = 0; c->specialized_gates && g < c->num_specialized_gates; g++) {
+            const uint64_t per_gate = (uint64_t)c->specialized_gates[g].num_repetitions * c->specialized_gates[g].const_stride;
+            if (per_gate > c->num_constant_cols) { spec_consts = (uint64_t)c->num_constant_cols + 1; break; }
+            spec_consts += per_gate;
         }
-        unsigned ccol = c->num_constant_cols - spec_consts;
+        if (spec_consts > c->num_constant_cols ||
+            (c->lookup_reps && !tid_var && (uint64_t)c->table_id_col + 1 + spec_consts != c->num_constant_cols)) {
+            bj_setup_destroy(s);
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: %u constant columns declared; the specialized gates' %llu must be the "
+                            "last ones, right behind the table-id column", c->num_constant_cols, (unsigned long long)spec_consts);
+        }
+        unsigned ccol = c->num_constant_cols - (unsigned)spec_consts;
         s->spec.resize(c->num_specialized_gates);
         for (unsigned g = 0; g < c->num_specialized_gates; g++) {
             const bj_gate_desc &G = c->specialized_gates[g];
@@ -418,16 +433,21 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
                 bj_setup_destroy(s);
                 return prc;
             }
-            sg.reps = G.num_repetitions; sg.width = G.var_stride; sg.terms = G.num_terms; sg.first_col = col;
+            if (col + (uint64_t)G.num_repetitions * G.var_stride > c->num_vars) {
+                bj_setup_destroy(s);
+                return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: specialized gate %u runs past the %u declared variable columns", g,
+                                c->num_vars);
+            }
+            sg.reps = G.num_repetitions; sg.width = G.var_stride; sg.terms = G.num_terms; sg.first_col = (unsigned)col;
             sg.first_const = ccol; sg.const_width = G.const_stride;
-            col += sg.reps * sg.width;
+            col += (uint64_t)sg.reps * sg.width;
             ccol += sg.reps * sg.const_width;
             s->n_spec_terms += sg.reps * sg.terms;
         }
         if (col != c->num_vars) {
             bj_setup_destroy(s);
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create: %u variable columns declared, geometry + lookups + "
-                            "specialized gates make %u", c->num_vars, col);
+                            "specialized gates make %llu", c->num_vars, (unsigned long long)col);
         }
     }
     s->non_residues.assign(c->non_residues, c->non_residues + c->num_vars);
@@ -436,6 +456,7 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         s->pub_rows.push_back(c->public_input_rows[i]);
     }
     s->fri_lde = cfg->fri_lde_factor; s->cap_size = cfg->cap_size; s->security = cfg->security_level; s->pow_bits = cfg->pow_bits;
+    s->pow_runner = cfg->pow_runner ? cfg->pow_runner : BJ_POW_BLAKE2S256;
     s->transcript = cfg->transcript ? cfg->transcript : BJ_TRANSCRIPT_POSEIDON2;
     s->hasher = cfg->tree_hasher ? cfg->tree_hasher : BJ_HASHER_POSEIDON2;
     s->L = s->fri_lde > s->q ? s->fri_lde : s->q;   // used_lde_degree (prover.rs:313)
@@ -748,7 +769,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         challenge2(lbeta);
         challenge2(lgamma);
         u64 *dA = s2_nat.p + (size_t)(2 + 2 * n_part) * n, *dB = dA + (size_t)2 * S->lookup_reps * n;
-        bj::launch_lookup_polys(d_variables + (size_t)S->num_gp_vars * n, n, d_con_nat + (size_t)S->table_id_col * n, d_tab_nat,
+        bj::launch_lookup_polys(d_variables + (size_t)S->num_gp_vars * n, n, S->tid_var ? nullptr : d_con_nat + (size_t)S->table_id_col * n, d_tab_nat,
                                 n, d_multiplicities, S->lookup_reps, S->lookup_w, log_n, lbeta, lgamma, dA, dB, st);
     }
     BJ_CHECK_LAUNCH(ctx);
@@ -834,7 +855,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     }
     if (has_lookup && Qe) {
         const u64 *dA = s2_lde.p + (size_t)(2 + 2 * n_part) * Ln, *dB = dA + (size_t)2 * S->lookup_reps * Ln;
-        bj::launch_quotient_lookup(wit_lde.p + (size_t)S->num_gp_vars * Ln, Ln, d_con_lde + (size_t)S->table_id_col * Ln, d_tab_lde,
+        bj::launch_quotient_lookup(wit_lde.p + (size_t)S->num_gp_vars * Ln, Ln, S->tid_var ? nullptr : d_con_lde + (size_t)S->table_id_col * Ln, d_tab_lde,
                                    Ln, wit_lde.p + (size_t)VW * Ln, dA, dB, Ln, S->lookup_reps, S->lookup_w, lbeta, lgamma,
                                    a_lookup, Qe, t0, t1, st);
     }
@@ -1152,7 +1173,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         ~FriGuard() { bj_fri_destroy(f); }
     } fri_guard{fri_obj};
     tr = trw.t;
-    // ---------------- proof of work (prover.rs:2107-2131; Blake2s256 as PoWRunner, pow.rs:50-133) ----------------
+    // ---------------- proof of work (prover.rs:2107-2131; PoWRunner = Blake2s256, pow.rs:50-133, or Keccak256, pow.rs:139-230) ----------------
     u64 pow_challenge = 0;
     if (new_pow) {
         u64 seed[5];   // 256 / CHAR_BITS = 4, "+1 if not a multiple of CHAR_BITS" -> 5 challenges = 40 seed bytes
@@ -1163,7 +1184,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         u64 found = none;
         for (u64 base = 0; found == none; base += batch) {   // batches in order + minimum inside a batch = the smallest nonce,
             if ((rc = bj::h2d_async(ctx, d_res.p, &none, 8))) return rc;   // i.e. what the reference's serial search returns
-            bj::launch_blake2s_pow(seed, new_pow, base, batch, d_res.p, st);
+            if (S->pow_runner == BJ_POW_KECCAK256) bj::launch_keccak_pow(seed, new_pow, base, batch, d_res.p, st);
+            else bj::launch_blake2s_pow(seed, new_pow, base, batch, d_res.p, st);
             BJ_CHECK_LAUNCH(ctx);
             if ((rc = bj_memcpy_d2h(ctx, &found, d_res.p, 8))) return rc;
             if (base > ((u64)1 << 40)) return bj::fail(ctx, BJ_ERR_HIP, "bj_prove: proof of work did not terminate");

@@ -266,17 +266,20 @@ quotient_lookup_kernel(const u64 *lvars, size_t var_stride, const u64 *table_id,
     Acc160q s0, s1;
     s0.clear();
     s1.clear();
-    const u64 tid = gl::canon(table_id[I]);
+    // table_id == nullptr: the table id is the last of the w + 1 variable columns of every sub-argument
+    // (UseSpecializedColumnsWithTableIdAsVariable, lookup_argument_in_ext.rs:949-1000: capacity = w + 1, no constant column)
+    const unsigned cps = table_id ? w : w + 1;
+    const u64 tid = table_id ? gl::canon(table_id[I]) : 0;
     for (unsigned i = 0; i <= reps; i++) {
         gl::e2 d = la.beta;
         gl::e2 poly;
         u64 minus;
         if (i < reps) {
-            for (unsigned j = 0; j < w; j++) {
-                u64 v = gl::canon(lvars[(size_t)(i * w + j) * var_stride + I]);
+            for (unsigned j = 0; j < cps; j++) {
+                u64 v = gl::canon(lvars[(size_t)(i * cps + j) * var_stride + I]);
                 d = gl::e2_add(d, gl::e2_mul_base(la.gpow[j], v));
             }
-            d = gl::e2_add(d, gl::e2_mul_base(la.gpow[w], tid));
+            if (table_id) d = gl::e2_add(d, gl::e2_mul_base(la.gpow[w], tid));
             poly = {gl::canon(A[((size_t)2 * i) * s2_stride + I]), gl::canon(A[((size_t)2 * i + 1) * s2_stride + I])};
             minus = 1;
         } else {

@@ -222,6 +222,7 @@ void launch_copy_perm_stage2(const u64 *d_vars, size_t var_stride, const u64 *d_
 }
 
 // ---- lookup polynomials: A_i = 1/(beta + sum_j gamma^j col_ij + gamma^w tid),  B = mult/(beta + sum_j gamma^j table_j) ----
+// tid = the shared table-id constant column, or (table_id == nullptr) the (w+1)-th variable column of sub-argument i
 struct LookupArgs {
     gl::e2 beta;
     gl::e2 gpow[9];   // gamma^0 .. gamma^w  (w <= 8)
@@ -231,7 +232,10 @@ lookup_polys_kernel(const u64 *lvars, size_t var_stride, const u64 *table_id, co
                     const u64 *mult, unsigned reps, unsigned w, size_t n, LookupArgs a, u64 *outA, u64 *outB) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const u64 tid = gl::canon(table_id[r]);
+    // table_id == nullptr: UseSpecializedColumnsWithTableIdAsVariable (lookup_argument_in_ext.rs:354-366) — a sub-argument owns
+    // w + 1 variable columns, the last of them the table id; no constant column takes part
+    const unsigned cps = table_id ? w : w + 1;
+    const u64 tid = table_id ? gl::canon(table_id[r]) : 0;
     // the reps + 1 denominators of a row are inverted in groups of up to LK_GROUP with one F_p^2 inversion per group
     constexpr unsigned LK_GROUP = 9;
     for (unsigned g0 = 0; g0 <= reps; g0 += LK_GROUP) {
@@ -243,11 +247,11 @@ lookup_polys_kernel(const u64 *lvars, size_t var_stride, const u64 *table_id, co
             const unsigned i = g0 + k;                       // i == reps -> the table aggregate (B)
             gl::e2 acc = a.beta;
             if (i < reps) {
-                for (unsigned j = 0; j < w; j++) {
-                    u64 v = gl::canon(lvars[(size_t)(i * w + j) * var_stride + r]);
+                for (unsigned j = 0; j < cps; j++) {
+                    u64 v = gl::canon(lvars[(size_t)(i * cps + j) * var_stride + r]);
                     acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[j], v));
                 }
-                acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[w], tid));
+                if (table_id) acc = gl::e2_add(acc, gl::e2_mul_base(a.gpow[w], tid));
             } else {
                 for (unsigned j = 0; j <= w; j++) {
                     u64 v = gl::canon(tables[(size_t)j * tab_stride + r]);

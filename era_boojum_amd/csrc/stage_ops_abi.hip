@@ -81,7 +81,8 @@ int bj_lookup_polys(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_strid
                     const uint64_t *d_tables, size_t table_stride, const uint64_t *d_multiplicities, unsigned reps, unsigned width,
                     unsigned log_n, const uint64_t *h_beta, const uint64_t *h_gamma, uint64_t *d_A, uint64_t *d_B) {
     if (int rc = bj::bind(ctx)) return rc;
-    if (!d_lookup_vars || !d_table_id || !d_tables || !d_multiplicities || !h_beta || !h_gamma || !d_A || !d_B)
+    // d_table_id may be NULL: the table id is then the (width+1)-th variable column of every sub-argument
+    if (!d_lookup_vars || !d_tables || !d_multiplicities || !h_beta || !h_gamma || !d_A || !d_B)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_lookup_polys: null pointer");
     if (reps == 0 || width == 0 || width > 8 || log_n > 30) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_lookup_polys: bad geometry (width 1..8)");
     const size_t n = (size_t)1 << log_n;
@@ -142,8 +143,8 @@ int bj_quotient_lookup(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_st
                        const uint64_t *d_B, size_t stage2_stride, unsigned reps, unsigned width, const uint64_t *h_beta,
                        const uint64_t *h_gamma, const uint64_t *h_alphas, size_t num_points, uint64_t *d_out0, uint64_t *d_out1) {
     if (int rc = bj::bind(ctx)) return rc;
-    if (!d_lookup_vars || !d_table_id || !d_tables || !d_multiplicities || !d_A || !d_B || !h_beta || !h_gamma || !h_alphas ||
-        !d_out0 || !d_out1)
+    if (!d_lookup_vars || !d_tables || !d_multiplicities || !d_A || !d_B || !h_beta || !h_gamma || !h_alphas ||
+        !d_out0 || !d_out1)   // d_table_id may be NULL (table id as the last variable column of a sub-argument)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_quotient_lookup: null pointer");
     if (reps == 0 || width == 0 || width > 8) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_quotient_lookup: bad geometry (width 1..8)");
     if (var_stride < num_points || table_stride < num_points || stage2_stride < num_points)

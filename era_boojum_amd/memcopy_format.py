@@ -103,7 +103,7 @@ def write_setup_base(circuit):
     """`SetupBaseStorage::write_into_buffer` for a Circuit."""
     c = circuit
     gate_index = {id(g): i for i, g in enumerate(c.gates)}
-    ids = [c.table_id_col] if c.lookup_reps else []
+    ids = [c.table_id_col] if (c.lookup_reps and not getattr(c, "table_id_as_variable", False)) else []   # setup.rs:970-990
     out = write_poly_vec(list(c.sigmas)) + write_poly_vec(list(c.constants))
     out += write_poly_vec(list(c.tables) if c.lookup_reps else [])
     out += struct.pack("<Q", len(ids)) + b"".join(struct.pack("<Q", i) for i in ids)
@@ -194,17 +194,23 @@ def circuit_from_dumps(setup_base, witness_vec, variables_hint, gates, num_gp_va
     V, n = sig.shape
     if hint.shape != (V, n):
         raise ValueError("the copy hint is %s, the setup has %d columns of %d rows" % (hint.shape, V, n))
-    if V != num_gp_vars + lookup_width * lookup_reps + sum(g.reps * g.var_stride for g in specialized_gates):
+    # no table-id column among the constants = UseSpecializedColumnsWithTableIdAsVariable: width + 1 variable columns per sub-argument
+    tid_var = bool(lookup_reps) and len(idxes) == 0
+    cps = lookup_width + (1 if tid_var else 0)
+    if V != num_gp_vars + cps * lookup_reps + sum(g.reps * g.var_stride for g in specialized_gates):
         raise ValueError("column count does not match the geometry")
     variables = variables_from_witness_vec(vals, hint)
     max_deg, _ = _stats(tree, 0)
     q = 1
     while q < max_deg - 1:
         q *= 2
+    spec_consts = sum(g.reps * g.const_stride for g in specialized_gates)
     if lookup_reps:
-        if len(idxes) != 1 or tabs is None or tabs.shape[0] != lookup_width + 1:
-            raise ValueError("specialized lookups with a shared table id need one table-id column and width + 1 table columns")
-        table_id_col, consts_for_gates = idxes[0], const.shape[0] - 1
+        if len(idxes) > 1 or tabs is None or tabs.shape[0] != lookup_width + 1:
+            raise ValueError("specialized lookups need at most one table-id column and width + 1 table columns")
+        from .synthetic import TABLE_ID_AS_VARIABLE
+        table_id_col = TABLE_ID_AS_VARIABLE if tid_var else idxes[0]
+        consts_for_gates = const.shape[0] - spec_consts - (0 if tid_var else 1)
         total_len = int(np.count_nonzero(tabs[lookup_width]))
         multiplicities = multiplicity_column(mult, n)
     else:
@@ -212,7 +218,8 @@ def circuit_from_dumps(setup_base, witness_vec, variables_hint, gates, num_gp_va
         tabs = np.zeros((lookup_width + 1, n), dtype=np.uint64)
         multiplicities = np.zeros((1, n), dtype=np.uint64)
     pubs = [(c, r, int(variables[c, r])) for c, r in locs]
-    return Circuit(n.bit_length() - 1, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, const.shape[0],
+    return Circuit(n.bit_length() - 1, num_gp_vars, cps * lookup_reps, lookup_width, lookup_reps, gates, const.shape[0],
                    consts_for_gates, table_id_col, q, variables, multiplicities, sig, const, tabs, non_residues(V, n), pubs,
                    total_len, selector_tree=tree, max_allowed_constraint_degree=max_allowed_constraint_degree,
-                   geometry_constant_cols=geometry_constant_cols, specialized_gates=list(specialized_gates))
+                   geometry_constant_cols=geometry_constant_cols, specialized_gates=list(specialized_gates),
+                   table_id_as_variable=tid_var)

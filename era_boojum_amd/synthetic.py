@@ -226,6 +226,9 @@ def make_tables(bits):
     return [t.astype(np.uint64) for t in (tri, ch, maj, s1, s2)]
 
 
+TABLE_ID_AS_VARIABLE = 0xFFFFFFFF     # bj_circuit.table_id_col = BJ_TABLE_ID_AS_VARIABLE (include/boojum_hip.h)
+
+
 @dataclass
 class Circuit:
     log_n: int
@@ -251,6 +254,14 @@ class Circuit:
     geometry_constant_cols: int = 4    # CSGeometry::num_constant_columns (the rest of num_constants_for_gates are selector extras)
     specialized_gates: list = field(default_factory=list)   # GateDesc with .program: gates over their own columns after the lookup ones
     witness: np.ndarray = None      # [Wc, n] non-copiable witness columns (WitnessSet::witness, witness.rs:25), or None
+    table_id_as_variable: bool = False   # LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (cs/mod.rs:237): every sub-argument
+                                         # has lookup_width + 1 variable columns, the last one the table id; no table-id constant column
+                                         # (table_id_col == TABLE_ID_AS_VARIABLE, table_ids_column_idxes empty: setup.rs:970-971)
+
+    @property
+    def lookup_cols_per_sub(self):
+        """specialized_columns_per_subargument (cs/mod.rs:300-312): variable columns of one lookup sub-argument."""
+        return self.lookup_width + (1 if self.table_id_as_variable else 0)
 
     @property
     def num_witness_cols(self):
@@ -271,14 +282,18 @@ class Circuit:
 
 def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num_gp_vars=60, num_constant_cols=4,
                        lookup_width=4, lookup_reps=8, num_public_inputs=2, extended=False, boolean_columns=0, gates=None,
-                       max_allowed_constraint_degree=4, num_witness_cols=0, specialized_constant_columns=0):
+                       max_allowed_constraint_degree=4, num_witness_cols=0, specialized_constant_columns=0,
+                       table_id_as_variable=False):
     """Random satisfiable circuit with the SHA bench geometry.  mix = fractions of rows for
     (ConstantsAllocator, FMA, Reduction); the rest are Nop rows.  boolean_columns > 0 adds a BooleanConstraintGate placed
     over that many specialized columns (GatePlacementStrategy::UseSpecializedColumns, boolean_allocator.rs): every row of
     those columns holds a bit, some of them linked to a copy of themselves in another boolean column.
     specialized_constant_columns > 0 adds, after it, a ConstantsAllocatorGate over that many specialized columns with
     share_constants = false: every repetition has its own variable column and its own CONSTANT column (the last constant
-    columns, behind the table-id one: evaluator_data.rs:196-238, prover.rs:748-772), cell = constant on every row."""
+    columns, behind the table-id one: evaluator_data.rs:196-238, prover.rs:748-772), cell = constant on every row.
+    table_id_as_variable: the lookup argument in its UseSpecializedColumnsWithTableIdAsVariable mode — lookup_width + 1 variable
+    columns per sub-argument, the last one holding the id of the table THAT sub-argument looks up on that row (so the eight
+    sub-arguments of a row may use eight different tables), and no table-id constant column."""
     n = 1 << log_n
     rng = np.random.default_rng(seed)
     rand_f = lambda shape: rng.integers(0, P, size=shape, dtype=np.uint64)
@@ -291,9 +306,10 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     q = 1
     while q < max_deg - 1:
         q *= 2
-    table_id_col = consts_for_gates
-    Kc = consts_for_gates + 1 + specialized_constant_columns
-    V = num_gp_vars + lookup_width * lookup_reps + boolean_columns + specialized_constant_columns
+    table_id_col = TABLE_ID_AS_VARIABLE if table_id_as_variable else consts_for_gates
+    Kc = consts_for_gates + (0 if table_id_as_variable else 1) + specialized_constant_columns
+    cps = lookup_width + (1 if table_id_as_variable else 0)
+    V = num_gp_vars + cps * lookup_reps + boolean_columns + specialized_constant_columns
     variables = np.zeros((V, n), dtype=np.uint64)
     witness = rand_f((num_witness_cols, n)) if num_witness_cols else None   # unconstrained cells hold anything: they are committed and opened all the same
     constants = np.zeros((Kc, n), dtype=np.uint64)
@@ -480,20 +496,25 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
         offs.append(o)
         o += t.shape[0]
     tid = rng.integers(0, len(tabs), size=n)
-    constants[table_id_col] = (tid + 1).astype(np.uint64)
+    if not table_id_as_variable:
+        constants[table_id_col] = (tid + 1).astype(np.uint64)
     sizes = np.array([t.shape[0] for t in tabs])
     offs = np.array(offs)
     mult = np.zeros(n, dtype=np.uint64)
     small = np.ascontiguousarray(tables[:lookup_width, :total_len])
     for rep in range(lookup_reps):
+        if table_id_as_variable and rep:               # every sub-argument its own table on every row
+            tid = rng.integers(0, len(tabs), size=n)
         pick = offs[tid] + (rng.integers(0, 1 << 62, size=n) % sizes[tid])
         for j in range(lookup_width):
-            variables[num_gp_vars + rep * lookup_width + j] = small[j][pick]
+            variables[num_gp_vars + rep * cps + j] = small[j][pick]
+        if table_id_as_variable:
+            variables[num_gp_vars + rep * cps + lookup_width] = (tid + 1).astype(np.uint64)
         mult += np.bincount(pick, minlength=n).astype(np.uint64)
     specialized = []
     if boolean_columns:
         from .gate_program import boolean_program
-        first = num_gp_vars + lookup_width * lookup_reps
+        first = num_gp_vars + cps * lookup_reps
         bits = rng.integers(0, 2, size=(boolean_columns, n)).astype(np.uint64)
         if boolean_columns >= 2:                       # column 1 repeats column 0 on the first half: copy constraints
             bits[1, : n // 2] = bits[0, : n // 2]
@@ -526,10 +547,11 @@ def sha_shaped_circuit(log_n, seed=42, table_bits=4, mix=(0.05, 0.45, 0.35), num
     for i in range(num_public_inputs):
         col, row = (7 * i + 3) % num_gp_vars, (11 * i + 5) % n
         pubs.append((col, row, int(variables[col, row])))
-    return Circuit(log_n, num_gp_vars, lookup_width * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
+    return Circuit(log_n, num_gp_vars, cps * lookup_reps, lookup_width, lookup_reps, gates, Kc, consts_for_gates,
                    table_id_col, q, variables, mult.reshape(1, n), sigmas, constants, tables, ks, pubs, total_len,
                    selector_tree=getattr(place_selectors, "last_tree", None), geometry_constant_cols=num_constant_cols,
-                   specialized_gates=specialized, max_allowed_constraint_degree=max_allowed_constraint_degree, witness=witness)
+                   specialized_gates=specialized, max_allowed_constraint_degree=max_allowed_constraint_degree, witness=witness,
+                   table_id_as_variable=table_id_as_variable)
 
 
 def check_satisfied(c: Circuit):
@@ -600,7 +622,8 @@ def check_satisfied(c: Circuit):
         lut[table_keys[r]] = r
     count = np.zeros(n, dtype=np.uint64)
     for rep in range(c.lookup_reps):
-        cols = [var[c.num_gp_vars + rep * w + j] for j in range(w)] + [consts[c.table_id_col]]
+        cps = c.lookup_cols_per_sub
+        cols = [var[c.num_gp_vars + rep * cps + j] for j in range(cps)] + ([] if c.table_id_as_variable else [consts[c.table_id_col]])
         keys = enc(cols)
         for k in keys:
             count[lut[k]] += 1

@@ -75,7 +75,11 @@ def _tree(node, gate_index):
 def vk_to_reference_json(circuit, setup_cap, fri_lde_factor, cap_size):
     """serde layout of `VerificationKey` for a circuit of era_boojum_amd.synthetic.Circuit shape."""
     c = circuit
-    if c.lookup_reps:
+    tid_var = bool(getattr(c, "table_id_as_variable", False))
+    if c.lookup_reps and tid_var:     # cs/mod.rs:237-241; share_table_id is not read by the prover in this mode (lookup_argument_in_ext.rs:357)
+        lookup = {"UseSpecializedColumnsWithTableIdAsVariable": {"width": c.lookup_width, "num_repetitions": c.lookup_reps,
+                                                                 "share_table_id": False}}
+    elif c.lookup_reps:
         lookup = {"UseSpecializedColumnsWithTableIdAsConstant": {"width": c.lookup_width, "num_repetitions": c.lookup_reps,
                                                                  "share_table_id": True}}
     else:
@@ -91,7 +95,7 @@ def vk_to_reference_json(circuit, setup_cap, fri_lde_factor, cap_size):
             "total_tables_len": c.total_tables_len if c.lookup_reps else 0,
             "public_inputs_locations": [[int(col), int(row)] for col, row, _ in c.public_inputs],
             "extra_constant_polys_for_selectors": c.num_constants_for_gates - c.geometry_constant_cols,
-            "table_ids_column_idxes": [c.table_id_col] if c.lookup_reps else [],
+            "table_ids_column_idxes": [c.table_id_col] if (c.lookup_reps and not tid_var) else [],
             "quotient_degree": c.quotient_degree,
             "selectors_placement": _tree(c.selector_tree, gate_index),
             "fri_lde_factor": fri_lde_factor,

@@ -42,8 +42,9 @@ typedef enum bj_status {
  * reference's `Worker` (src/worker/mod.rs:5-87, a rayon pool) + `P::Context` at the call sites. */
 typedef struct bj_ctx bj_ctx;
 
-/* 2: bj_gate_desc.wit_stride, bj_comm.all_gather_stream (round 2); 3: op lists in any numbering, run-time compiled gates */
-#define BJ_ABI_VERSION 3
+/* 2: bj_gate_desc.wit_stride, bj_comm.all_gather_stream (round 2); 3: op lists in any numbering, run-time compiled gates;
+ * 4: bj_proof_config.pow_runner, bj_circuit.table_id_col = BJ_TABLE_ID_AS_VARIABLE (round 5) */
+#define BJ_ABI_VERSION 4
 int bj_abi_version(void);
 int bj_device_count(void);
 const char *bj_status_string(int status);
@@ -228,6 +229,9 @@ typedef struct bj_transcript bj_transcript;
 #define BJ_HASHER_POSEIDON2 1 /* GoldilocksPoseidon2Sponge<AbsorptionModeOverwrite>: four canonical field elements */
 #define BJ_HASHER_BLAKE2S 2   /* blake2::Blake2s256: the 32 digest bytes, little-endian packed into the four words */
 #define BJ_HASHER_KECCAK256 3 /* sha3::Keccak256 (original 0x01 padding, oracle/mod.rs:247-312): digest bytes as above */
+/* bj_proof_config.pow_runner: the PoWRunner implementations of src/cs/implementations/pow.rs */
+#define BJ_POW_BLAKE2S256 1   /* pow.rs:50-133 */
+#define BJ_POW_KECCAK256 2    /* pow.rs:139-230 (original Keccak padding, as the tree hasher) */
 int bj_transcript_create(int kind, bj_transcript **out);
 void bj_transcript_destroy(bj_transcript *t);
 int bj_transcript_absorb(bj_transcript *t, const uint64_t *els, size_t n);
@@ -379,7 +383,9 @@ int bj_copy_perm_stage2(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, 
                         const uint64_t *h_beta, const uint64_t *h_gamma, uint64_t *d_z, uint64_t *d_partials);
 /* compute_lookup_poly_pairs_specialized (src/cs/implementations/lookup_argument_in_ext.rs:320-700): A_i = 1 / (beta +
  * sum_j gamma^j col_ij + gamma^width table_id), B = multiplicity / (beta + sum_j gamma^j table_j) per row.
- * d_lookup_vars [reps*width][n], d_tables [width+1][n]; out d_A [reps][2][n], d_B [2][n]. */
+ * d_lookup_vars [reps*width][n], d_tables [width+1][n]; out d_A [reps][2][n], d_B [2][n].
+ * d_table_id == NULL selects LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (:354-366): d_lookup_vars is
+ * [reps*(width+1)][n], the last column of every sub-argument carries its table id and no constant column takes part. */
 int bj_lookup_polys(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_stride, const uint64_t *d_table_id,
                     const uint64_t *d_tables, size_t table_stride, const uint64_t *d_multiplicities, unsigned reps, unsigned width,
                     unsigned log_n, const uint64_t *h_beta, const uint64_t *h_gamma, uint64_t *d_A, uint64_t *d_B);
@@ -391,7 +397,8 @@ int bj_quotient_gates(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, un
                       size_t const_stride, unsigned num_constant_cols, const bj_gate_desc *gates, unsigned num_gates,
                       const uint64_t *h_alphas, size_t num_points, uint64_t *d_out0, uint64_t *d_out1);
 /* compute_quotient_terms_for_lookup_specialized (lookup_argument_in_ext.rs:949-1319): ADDS sum_i alpha_i * (A_i * denom_i - 1)
- * + alpha_reps * (B * denom_table - multiplicity) to d_out.  h_alphas: reps + 1 powers. */
+ * + alpha_reps * (B * denom_table - multiplicity) to d_out.  h_alphas: reps + 1 powers.  d_table_id == NULL: table id as the
+ * (width+1)-th variable column of every sub-argument, as for bj_lookup_polys. */
 int bj_quotient_lookup(bj_ctx *ctx, const uint64_t *d_lookup_vars, size_t var_stride, const uint64_t *d_table_id,
                        const uint64_t *d_tables, size_t table_stride, const uint64_t *d_multiplicities, const uint64_t *d_A,
                        const uint64_t *d_B, size_t stage2_stride, unsigned reps, unsigned width, const uint64_t *h_beta,
@@ -415,6 +422,8 @@ int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride
 int bj_combine_residues(bj_ctx *ctx, const uint64_t *d_residues, unsigned world, size_t residue_len, unsigned num_cols,
                         const uint64_t *h_moduli, uint64_t *d_out);
 
+#define BJ_TABLE_ID_AS_VARIABLE 0xFFFFFFFFu   /* bj_circuit.table_id_col: the table id is a variable column, see below */
+
 typedef struct bj_circuit {
     unsigned log_n;              /* trace length 2^log_n */
     unsigned num_vars;           /* all variable columns: general purpose first, then the specialized lookup columns, then the
@@ -425,9 +434,13 @@ typedef struct bj_circuit {
                                   * opened after them, and readable only by op-list gates (BJ_IDX_WITNESS_POLY).  bj_prove / bj_prove_dev
                                   * take them right behind the variable columns: [num_vars + num_witness_cols][n] */
     unsigned num_constant_cols;  /* selector/gate constants + (lookups) the table-id column */
-    unsigned lookup_width;       /* LookupParameters::UseSpecializedColumnsWithTableIdAsConstant { width, .. } */
+    unsigned lookup_width;       /* LookupParameters::UseSpecializedColumnsWithTableIdAs{Constant,Variable} { width, .. } (cs/mod.rs:237-246) */
     unsigned lookup_reps;        /* num_repetitions; 0 = no lookup argument */
-    unsigned table_id_col;       /* vk.fixed_parameters.table_ids_column_idxes[0] */
+    unsigned table_id_col;       /* ..AsConstant { share_table_id: true }: vk.fixed_parameters.table_ids_column_idxes[0];
+                                  * ..AsVariable (table_ids_column_idxes is empty, setup.rs:970-971): BJ_TABLE_ID_AS_VARIABLE — every
+                                  * sub-argument then owns lookup_width + 1 variable columns, the last one holding the table id of
+                                  * the row (lookup_argument_in_ext.rs:354-366, 949-1000; verifier.rs:1402-1464), num_vars counts them
+                                  * and there is no table-id column among the constants */
     unsigned quotient_degree;    /* vk.fixed_parameters.quotient_degree (power of two) */
     unsigned num_gates;          /* evaluators over general purpose columns, in evaluator order (<= 16) */
     const bj_gate_desc *gates;
@@ -453,10 +466,15 @@ typedef struct bj_proof_config { /* ProofConfig, prover.rs:55-73 */
     unsigned fri_lde_factor;
     unsigned cap_size;
     unsigned security_level;
-    unsigned pow_bits; /* Blake2s proof of work (PoWRunner for Blake2s256, pow.rs:50-133), <= 32; 0 = off as in the benches */
+    unsigned pow_bits; /* proof of work (pow.rs), <= 32; 0 = off as in the benches (NoPow).  The runner is pow_runner below */
     unsigned transcript;  /* 0 or BJ_TRANSCRIPT_POSEIDON2 (default), BJ_TRANSCRIPT_POSEIDON, BJ_TRANSCRIPT_BLAKE2S, _KECCAK256 */
     unsigned tree_hasher; /* 0 or BJ_HASHER_POSEIDON2 (default, with an algebraic transcript), BJ_HASHER_BLAKE2S /
                            * BJ_HASHER_KECCAK256 (with a byte transcript): the transcript's CompatibleCap must be the hasher's Output */
+    unsigned pow_runner;  /* the POW type parameter of prove_cpu_basic (prover.rs:153-168; trait PoWRunner, pow.rs:6-31), independent of
+                           * the transcript and the tree hasher as in the reference: 0 or BJ_POW_BLAKE2S256 (impl PoWRunner for
+                           * Blake2s256, pow.rs:50-133), BJ_POW_KECCAK256 (impl PoWRunner for Keccak256, pow.rs:139-230).  Both search
+                           * the smallest nonce whose H(seed || le64(nonce)) starts with pow_bits trailing zero bits; read only when
+                           * pow_bits != 0 */
 } bj_proof_config;
 
 typedef struct bj_setup bj_setup; /* device-resident SetupStorage + setup Merkle tree + VK cap; reusable across proofs */

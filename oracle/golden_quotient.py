@@ -35,6 +35,21 @@ def geometry_from_vk_json(vk):
             "selectors_placement": fp["selectors_placement"]}
 
 
+def lookup_parameters(geometry):
+    """(parameters dict or None, width, num_repetitions, variable columns per sub-argument) of vk.fixed_parameters.lookup_parameters:
+    the two specialized-columns modes of cs/mod.rs:237-246.  With the table id as a VARIABLE a sub-argument owns width + 1 variable
+    columns and table_ids_column_idxes is empty (setup.rs:970-971; verifier.rs:675-678, 1402-1409)."""
+    lookup = geometry["lookup"] if isinstance(geometry["lookup"], dict) else {}
+    lk = lookup.get("UseSpecializedColumnsWithTableIdAsConstant")
+    if lk:
+        return lk, lk["width"], lk["num_repetitions"], lk["width"]
+    lk = lookup.get("UseSpecializedColumnsWithTableIdAsVariable")
+    if lk:
+        assert not geometry["table_ids_column_idxes"], "table id as a variable: no table-id constant column"
+        return lk, lk["width"], lk["num_repetitions"], lk["width"] + 1
+    return None, 0, 0, 0
+
+
 def quotient_identity(geometry, general_gates, specialized_gates, non_residues, challenges, values_at_z, value_z_omega,
                       verbose=False):
     """geometry: the fixture's `geometry` dict (vk.fixed_parameters); general_gates: evaluator names in gate_idx order;
@@ -43,10 +58,9 @@ def quotient_identity(geometry, general_gates, specialized_gates, non_residues, 
     n = geometry["domain_size"]
     Vgp = geometry["num_variable_columns"]
     q = geometry["quotient_degree"]
-    lk = geometry["lookup"].get("UseSpecializedColumnsWithTableIdAsConstant") if isinstance(geometry["lookup"], dict) else None
-    w, reps = (lk["width"], lk["num_repetitions"]) if lk else (0, 0)
+    lk, w, reps, cps = lookup_parameters(geometry)
     n_spec_vars = sum(EVALUATORS[name][0] * r for name, r in specialized_gates)
-    V = Vgp + w * reps + n_spec_vars
+    V = Vgp + cps * reps + n_spec_vars
     # constant columns: general-purpose gates' | table id | per-repetition constants of the gates over specialized columns
     # (share_constants = false, evaluator_data.rs:196-238; EVALUATORS[name][3] = constants one repetition reads inside evaluate_once)
     n_spec_consts = sum(EVALUATORS[name][3] * r for name, r in specialized_gates)
@@ -80,15 +94,15 @@ def quotient_identity(geometry, general_gates, specialized_gates, non_residues, 
     beta, gamma, z = challenges["beta"], challenges["gamma"], challenges["z"]
     if lk:
         lb, lg = challenges["lookup_beta"], challenges["lookup_gamma"]
-        tid = geometry["table_ids_column_idxes"][0]
         gp = [ONE]
         for _ in range(w):
             gp.append(emul(gp[-1], lg))
         for i in range(reps):
             d = lb
-            for j in range(w):
-                d = eadd(d, emul(gp[j], var_z[Vgp + i * w + j]))
-            d = eadd(d, emul(gp[w], con_z[tid]))
+            for j in range(cps):
+                d = eadd(d, emul(gp[j], var_z[Vgp + i * cps + j]))
+            if cps == w:                                   # table id in a constant column (verifier.rs:1447-1453)
+                d = eadd(d, emul(gp[w], con_z[geometry["table_ids_column_idxes"][0]]))
             T = eadd(T, emul(esub(emul(A_z[i], d), ONE), alphas[pos]))
             pos += 1
         d = lb
@@ -97,7 +111,7 @@ def quotient_identity(geometry, general_gates, specialized_gates, non_residues, 
         T = eadd(T, emul(esub(emul(B_z[0], d), mult_z[0]), alphas[pos]))
         pos += 1
     # gates over specialized columns: no selector, own variable columns after the lookup ones (evaluator_data.rs:190-236)
-    off, coff = Vgp + w * reps, nC - n_spec_consts
+    off, coff = Vgp + cps * reps, nC - n_spec_consts
     for name, r in specialized_gates:
         width, _, n_shared, cstride, n_terms, fn = EVALUATORS[name]
         for k in range(r):

@@ -53,11 +53,22 @@ def copy_perm_stage2(variables, sigmas, non_res, log_n, chunk, beta, gamma, thre
     return z, partials[:n_chunks - 1]
 
 
+def lookup_cols_per_sub(c):
+    """specialized_columns_per_subargument (cs/mod.rs:300-312): width, + 1 when the table id is a variable column."""
+    return c.lookup_width + (1 if getattr(c, "table_id_as_variable", False) else 0)
+
+
+def lookup_table_id(c, constants):
+    """The table-id constant column, or None in the UseSpecializedColumnsWithTableIdAsVariable mode."""
+    return None if getattr(c, "table_id_as_variable", False) else constants[c.table_id_col]
+
+
 def lookup_polys(lookup_vars, table_id, tables, mult, reps, w, log_n, beta, gamma, threads=1):
+    """table_id None: UseSpecializedColumnsWithTableIdAsVariable — lookup_vars holds w + 1 columns per sub-argument."""
     n = 1 << log_n
     A = np.zeros((reps, 2, n), dtype=np.uint64)
     B = np.zeros((2, n), dtype=np.uint64)
-    lib().orc_lookup_polys(_p(_arr(lookup_vars)), _p(_arr(table_id)), _p(_arr(tables)), _p(_arr(mult)), C.c_size_t(reps),
+    lib().orc_lookup_polys(_p(_arr(lookup_vars)), _p(_arr(table_id)) if table_id is not None else None, _p(_arr(tables)), _p(_arr(mult)), C.c_size_t(reps),
                            C.c_size_t(w), C.c_uint(log_n), _p(_arr(beta)), _p(_arr(gamma)), _p(A), _p(B), C.c_int(threads))
     return A, B
 
@@ -75,7 +86,8 @@ def quotient(vars_q, consts_q, sigmas_q, z_q, partials_q, A_q, B_q, mult_q, tabl
                        _p(partials_q if partials_q.size else dummy), C.c_size_t(npart),
                        _p(A_q if A_q.size else dummy), _p(B_q if B_q.size else dummy), _p(mult_q if mult_q.size else dummy),
                        _p(tables_q if tables_q.size else dummy), C.c_size_t(circuit.lookup_reps),
-                       C.c_size_t(circuit.lookup_width), C.c_size_t(circuit.num_gp_vars), C.c_size_t(circuit.table_id_col),
+                       C.c_size_t(circuit.lookup_width), C.c_size_t(circuit.num_gp_vars),
+                       C.c_size_t(-1 if getattr(circuit, "table_id_as_variable", False) else circuit.table_id_col),
                        gf.ctypes.data_as(C.POINTER(C.c_int)), C.c_size_t(len(circuit.gates)),
                        _p(_arr(circuit.non_residues)), C.c_size_t(circuit.quotient_degree), C.c_uint(circuit.log_n),
                        C.c_uint(log_q), C.c_uint(coset_begin), _p(_arr(alphas).reshape(-1)), C.c_size_t(len(alphas)),
@@ -128,7 +140,7 @@ def _op_list_gate_terms(c, spec_gates, vars_q, con_q, a_gates, a_spec, wits_q=No
             wcols = [wits_q[k] for k in range(r * ws, wits_q.shape[0])] if (ws and wits_q is not None) else ()
             s0, s1, aoff = weighted(prog, vcols, ccols, a_gates, aoff, wcols)
             acc0, acc1 = F.add(acc0, F.mul(s0, sel)), F.add(acc1, F.mul(s1, sel))
-    col, aoff = c.num_gp_vars + c.lookup_reps * c.lookup_width, 0
+    col, aoff = c.num_gp_vars + c.lookup_reps * lookup_cols_per_sub(c), 0
     # constants of the gates over specialized columns: the LAST constant columns (behind the general-purpose gates' ones and the
     # table-id column), reps * const_stride per gate — every repetition its own (prover.rs:748-772, evaluator_data.rs:196-238)
     ccol = c.num_constant_cols - sum(g.reps * g.const_stride for g in spec_gates)
@@ -148,19 +160,33 @@ def pow_seed(t):
     return b"".join(int(t.challenge()).to_bytes(8, "little") for _ in range(5))
 
 
-def pow_ok(seed, pow_bits, nonce):
+def _pow_first_words(seed, nonces, runner):
+    """First 8 digest bytes (little-endian u64) of H(seed || le64(nonce)) for every nonce; runner 1 = Blake2s256 (pow.rs:50-133,
+    hashlib), 2 = Keccak256 (pow.rs:139-230: the original Keccak padding, oracle/keccak.py — pinned through hashlib.sha3_256)."""
+    if runner == 2:
+        from oracle import keccak as K
+        words = np.empty((len(nonces), 6), dtype=np.uint64)
+        words[:, :5] = np.frombuffer(seed, dtype="<u8")
+        words[:, 5] = np.asarray(nonces, dtype=np.uint64)
+        return [int(x) for x in K.hash_words(words)[:, 0]]
     import hashlib
-    first = int.from_bytes(hashlib.blake2s(seed + int(nonce).to_bytes(8, "little")).digest()[:8], "little")
+    return [int.from_bytes(hashlib.blake2s(seed + int(nonce).to_bytes(8, "little")).digest()[:8], "little") for nonce in nonces]
+
+
+def pow_ok(seed, pow_bits, nonce, runner=1):
+    first = _pow_first_words(seed, [nonce], runner)[0]
     tz = 64 if first == 0 else (first & -first).bit_length() - 1
     return tz >= pow_bits
 
 
-def pow_search(seed, pow_bits):
-    """The serial search of pow.rs:60-73: the smallest valid nonce."""
-    nonce = 0
-    while not pow_ok(seed, pow_bits, nonce):
-        nonce += 1
-    return nonce
+def pow_search(seed, pow_bits, runner=1):
+    """The serial search of pow.rs:60-73 / 149-162: the smallest valid nonce (in batches: the first hit of the first batch with one)."""
+    base, batch = 0, 1 << 12
+    while True:
+        for i, first in enumerate(_pow_first_words(seed, range(base, base + batch), runner)):
+            if (64 if first == 0 else (first & -first).bit_length() - 1) >= pow_bits:
+                return base + i
+        base += batch
 
 
 def hashing_layer(hasher):
@@ -197,7 +223,7 @@ class Setup:
 
 
 def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow_bits=0, threads=1, return_aux=False,
-          transcript_kind=1):
+          transcript_kind=1, pow_runner=1):
     c = circuit
     n, log_n = c.n, c.log_n
     V = c.num_vars
@@ -237,7 +263,7 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     lbeta = lgamma = (0, 0)
     if has_lookup:
         lbeta, lgamma = t.challenge_ext(), t.challenge_ext()
-        A_nat, B_nat = lookup_polys(c.variables[c.num_gp_vars:], c.constants[c.table_id_col], c.tables, c.multiplicities[0],
+        A_nat, B_nat = lookup_polys(c.variables[c.num_gp_vars:], lookup_table_id(c, c.constants), c.tables, c.multiplicities[0],
                                     c.lookup_reps, c.lookup_width, log_n, lbeta, lgamma, threads)
         stage2 += [A_nat[i][k] for i in range(c.lookup_reps) for k in range(2)] + [B_nat[0], B_nat[1]]
     s2_lde, s2_view, s2_tree, s2_cap = commit(np.stack(stage2))
@@ -370,10 +396,11 @@ def prove(circuit, setup, fri_lde_factor=8, cap_size=16, security_level=100, pow
     # ---- round 5b: FRI (prover.rs:2075-2105)
     new_pow, num_queries, sched, final_degree = O.fri_schedule(security_level, cap_size, pow_bits, log_fri, log_n)
     fri = H.do_fri(d0, d1, log_fri, sched, cap_size, t, threads)
-    # ---- proof of work (prover.rs:2107-2131; PoWRunner = Blake2s256, pow.rs:50-133; hashlib is the hash)
+    # ---- proof of work (prover.rs:2107-2131; the POW type parameter: 1 = Blake2s256, pow.rs:50-133, hashlib is the hash;
+    # 2 = Keccak256, pow.rs:139-230)
     pow_challenge = 0
     if new_pow:
-        pow_challenge = pow_search(pow_seed(t), new_pow)
+        pow_challenge = pow_search(pow_seed(t), new_pow, pow_runner)
         t.absorb([pow_challenge & 0xFFFFFFFF, pow_challenge >> 32])
     # ---- round 6: queries (prover.rs:2161-2266)
     qi = H.QueryIndexer(log_n, log_fri)

@@ -70,7 +70,10 @@ void orc_copy_perm_stage2(const uint64_t *vars, const uint64_t *sigmas, const ui
 }
 
 /* A_i = 1 / (beta + sum_j gamma^j * col_{i,j} + gamma^w * table_id),  B = mult / (beta + sum_j gamma^j * table_j)
- * lookup_vars: [reps*w][n]; table_id: [n]; tables: [w+1][n]; out_A: [reps][2][n]; out_B: [2][n] */
+ * lookup_vars: [reps*w][n]; table_id: [n]; tables: [w+1][n]; out_A: [reps][2][n]; out_B: [2][n].
+ * table_id == NULL is LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (lookup_argument_in_ext.rs:354-366): every
+ * sub-argument owns w + 1 variable columns, the last of them carrying the table id — lookup_vars is [reps*(w+1)][n] and no
+ * constant column takes part (table_id_column_idxes is empty, setup.rs:970-971). */
 void orc_lookup_polys(const uint64_t *lookup_vars, const uint64_t *table_id, const uint64_t *tables, const uint64_t *mult,
                       size_t reps, size_t w, unsigned log_n, const uint64_t *beta2, const uint64_t *gamma2,
                       uint64_t *out_A, uint64_t *out_B, int threads) {
@@ -83,8 +86,9 @@ void orc_lookup_polys(const uint64_t *lookup_vars, const uint64_t *table_id, con
     for (size_t r = 0; r < n; r++) {
         for (size_t i = 0; i < reps; i++) {
             gl2_t acc = beta;
-            for (size_t j = 0; j < w; j++) acc = gl2_add(acc, gl2_mul_base(gp[j], gl_canon(lookup_vars[(i * w + j) * n + r])));
-            acc = gl2_add(acc, gl2_mul_base(gp[w], gl_canon(table_id[r])));
+            const size_t cps = table_id ? w : w + 1;   /* variable columns per sub-argument */
+            for (size_t j = 0; j < cps; j++) acc = gl2_add(acc, gl2_mul_base(gp[j], gl_canon(lookup_vars[(i * cps + j) * n + r])));
+            if (table_id) acc = gl2_add(acc, gl2_mul_base(gp[w], gl_canon(table_id[r])));
             gl2_t a = gl2_inv(acc);
             out_A[(2 * i) * n + r] = a.c0; out_A[(2 * i + 1) * n + r] = a.c1;
         }
@@ -206,9 +210,13 @@ void orc_quotient(const uint64_t *vars, size_t V, const uint64_t *consts, size_t
         if (lookup_reps) {
             for (size_t i = 0; i < lookup_reps; i++) {
                 gl2_t d = lbeta;
-                for (size_t j = 0; j < lookup_w; j++)
-                    d = gl2_add(d, gl2_mul_base(lgp[j], vars[(lookup_var_offset + i * lookup_w + j) * Q + I]));
-                d = gl2_add(d, gl2_mul_base(lgp[lookup_w], consts[table_id_col * Q + I]));
+                /* table_id_col == (size_t)-1: the table id is the (w+1)-th variable column of the sub-argument
+                 * (UseSpecializedColumnsWithTableIdAsVariable, lookup_argument_in_ext.rs:949-1000: capacity = w + 1, no constant) */
+                const int tid_var = table_id_col == (size_t)-1;
+                const size_t cps = tid_var ? lookup_w + 1 : lookup_w;
+                for (size_t j = 0; j < cps; j++)
+                    d = gl2_add(d, gl2_mul_base(lgp[j], vars[(lookup_var_offset + i * cps + j) * Q + I]));
+                if (!tid_var) d = gl2_add(d, gl2_mul_base(lgp[lookup_w], consts[table_id_col * Q + I]));
                 gl2_t t = gl2_mul(gl2_make(lookA[(2 * i) * Q + I], lookA[(2 * i + 1) * Q + I]), d);
                 t.c0 = gl_sub(t.c0, 1);
                 acc = gl2_add(acc, gl2_mul(t, gl2_make(a_lookup[2 * i], a_lookup[2 * i + 1])));

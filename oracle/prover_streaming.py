@@ -81,7 +81,7 @@ def commitments_and_openings(circuit, setup_cap, fri_lde_factor=8, cap_size=16, 
     lbeta = lgamma = (0, 0)
     if has_lookup:
         lbeta, lgamma = t.challenge_ext(), t.challenge_ext()
-        A_nat, B_nat = OP.lookup_polys(c.variables[c.num_gp_vars:], c.constants[c.table_id_col], c.tables, c.multiplicities[0],
+        A_nat, B_nat = OP.lookup_polys(c.variables[c.num_gp_vars:], OP.lookup_table_id(c, c.constants), c.tables, c.multiplicities[0],
                                        c.lookup_reps, c.lookup_width, log_n, lbeta, lgamma, threads)
         stage2 += [A_nat[i][k] for i in range(c.lookup_reps) for k in range(2)] + [B_nat[0], B_nat[1]]
     s2_mono = O.ifft_batch(np.stack(stage2), 1, threads)

@@ -22,6 +22,9 @@ class VerificationKey:
         self.num_constant_cols = c.num_constant_cols
         self.lookup_reps, self.lookup_width = c.lookup_reps, c.lookup_width
         self.table_id_col = c.table_id_col
+        # LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (verifier.rs:675-678, 1397-1470): width + 1 variable columns per
+        # sub-argument, no table-id constant (vk.fixed_parameters.table_ids_column_idxes is empty)
+        self.table_id_as_variable = bool(getattr(c, "table_id_as_variable", False))
         self.gates = c.gates
         self.specialized_gates = list(getattr(c, "specialized_gates", []) or [])   # (evaluator_data.rs:190-236)
         self.quotient_degree = c.quotient_degree
@@ -43,8 +46,8 @@ def vk_from_reference_geometry(geometry, setup_cap, general_gates, specialized_g
     from oracle.golden_quotient import _paths
     vk = VerificationKey.__new__(VerificationKey)
     n = geometry["domain_size"]
-    lk = geometry["lookup"].get("UseSpecializedColumnsWithTableIdAsConstant") if isinstance(geometry["lookup"], dict) else None
-    w, reps = (lk["width"], lk["num_repetitions"]) if lk else (0, 0)
+    from oracle.golden_quotient import lookup_parameters
+    lk, w, reps, cps = lookup_parameters(geometry)
     vgp = geometry["num_variable_columns"]
     paths = {}
     _paths(geometry["selectors_placement"], [], paths)
@@ -64,11 +67,12 @@ def vk_from_reference_geometry(geometry, setup_cap, general_gates, specialized_g
         vk.specialized_gates.append(g)
     vk.log_n, vk.n = n.bit_length() - 1, n
     vk.num_gp_vars = vgp
-    vk.num_vars = vgp + w * reps + sum(g.reps * g.var_stride for g in vk.specialized_gates)
+    vk.num_vars = vgp + cps * reps + sum(g.reps * g.var_stride for g in vk.specialized_gates)
     vk.num_constant_cols = (geometry["num_constant_columns"] + geometry["extra_constant_polys_for_selectors"] + len(geometry["table_ids_column_idxes"])
                             + sum(g.reps * g.const_stride for g in vk.specialized_gates))
     vk.lookup_reps, vk.lookup_width = reps, w
-    vk.table_id_col = geometry["table_ids_column_idxes"][0] if lk else 0
+    vk.table_id_as_variable = cps != w
+    vk.table_id_col = geometry["table_ids_column_idxes"][0] if (lk and not vk.table_id_as_variable) else 0
     vk.quotient_degree = geometry["quotient_degree"]
     vk.non_residues = list(non_residues)
     vk.public_input_locations = [tuple(x) for x in geometry["public_inputs_locations"]]
@@ -143,7 +147,7 @@ def _gate_terms_at(vk, var, con, wit=()):
     return out
 
 
-def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
+def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False, pow_runner=1):
     """partial_queries: the proof carries only the FIRST k of the query openings (the golden fixture keeps 6 of 100);
     indices are drawn in order, so the first k can be checked on their own."""
     def fail(msg):
@@ -224,11 +228,14 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
         gp = [one]
         for _ in range(vk.lookup_width):
             gp.append(emul(gp[-1], lgamma))
+        tid_var = getattr(vk, "table_id_as_variable", False)
+        cps = vk.lookup_width + (1 if tid_var else 0)     # specialized_columns_per_subargument (verifier.rs:1402-1409)
         for i in range(vk.lookup_reps):
             d = lbeta
-            for j in range(vk.lookup_width):
-                d = eadd(d, emul(gp[j], var_z[vk.num_gp_vars + i * vk.lookup_width + j]))
-            d = eadd(d, emul(gp[vk.lookup_width], con_z[vk.table_id_col]))
+            for j in range(cps):
+                d = eadd(d, emul(gp[j], var_z[vk.num_gp_vars + i * cps + j]))
+            if not tid_var:                               # witness_columns.chain(table_id) (verifier.rs:1447-1464)
+                d = eadd(d, emul(gp[vk.lookup_width], con_z[vk.table_id_col]))
             T = eadd(T, emul(esub(emul(A_z[i], d), one), a_lookup[i]))
         d = lbeta
         for j in range(vk.lookup_width + 1):
@@ -236,7 +243,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
         T = eadd(T, emul(esub(emul(B_z[0], d), mult_z[0]), a_lookup[vk.lookup_reps]))
     # gates over specialized columns: no selector, their own variable columns after the lookup ones (verifier.rs:1560-1638)
     from oracle.gates import EVALUATORS
-    col, off = vk.num_gp_vars + vk.lookup_reps * vk.lookup_width, 0
+    col, off = vk.num_gp_vars + vk.lookup_reps * (vk.lookup_width + (1 if getattr(vk, "table_id_as_variable", False) else 0)), 0
     ccol = vk.num_constant_cols - sum(g.reps * g.const_stride for g in vk.specialized_gates)   # their constants: the last columns
     for g in vk.specialized_gates:
         width, fn = EVALUATORS[g.name][0], EVALUATORS[g.name][5]
@@ -296,7 +303,7 @@ def verify(vk, proof, verbose=False, transcript_kind=1, partial_queries=False):
     if new_pow:          # verifier.rs:1957-1983: the nonce must solve the puzzle seeded by the transcript, then it is absorbed
         from oracle.prover import pow_seed, pow_ok
         nonce = int(proof["pow_challenge"])
-        if not pow_ok(pow_seed(t), new_pow, nonce):
+        if not pow_ok(pow_seed(t), new_pow, nonce, pow_runner):     # POW::verify_from_field_elements (pow.rs:16-31)
             return fail("invalid proof of work")
         t.absorb([nonce & 0xFFFFFFFF, nonce >> 32])
     if len(proof["queries_per_fri_repetition"]) != num_queries and not (

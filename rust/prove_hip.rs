@@ -202,7 +202,9 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
     /// evaluator that has no hand-written kernel (`GatesSetForGPU::add_gate::<G>(params)` for each such gate, in any
     /// order; matched by `evaluator_name`).  `comm` = `Some(bj_comm)` from `bj_comm_rccl_create` shards the proof by LDE
     /// cosets over the processes of the communicator (one GPU each).
-    pub fn hip_setup<H: TreeHasher<F>>(
+    /// `POW` is the proof-of-work type parameter of `prove_cpu_basic` (prover.rs:153-168; `NoPow`, `Blake2s256` or `Keccak256`,
+    /// pow.rs): it travels to the library as `bj_proof_config.pow_runner` and is read only when `proof_config.pow_bits != 0`.
+    pub fn hip_setup<H: TreeHasher<F>, POW: crate::cs::implementations::pow::PoWRunner>(
         &self,
         ctx: &HipCtx,
         setup_base: &SetupBaseStorage<F, P>,
@@ -216,13 +218,21 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
         let n = self.max_trace_len;
         let geometry: &CSGeometry = &vk.fixed_parameters.parameters;
         let fixed = &vk.fixed_parameters;
-        let (lookup_width, lookup_reps) = match fixed.lookup_parameters {
-            LookupParameters::NoLookup => (0u32, 0usize),
+        // (width, repetitions, table id as a variable column?).  The two modes over general-purpose columns are left unimplemented by the
+        // reference's own prover (prover.rs:412-437) and stay refused here.
+        let (lookup_width, lookup_reps, table_id_as_variable) = match fixed.lookup_parameters {
+            LookupParameters::NoLookup => (0u32, 0usize, false),
             LookupParameters::UseSpecializedColumnsWithTableIdAsConstant { width, num_repetitions, share_table_id } => {
-                assert!(share_table_id, "the specialized lookup argument is supported with a shared table-id constant column");
-                (width, num_repetitions)
+                assert!(share_table_id, "a table id in constant columns must be shared (lookup_argument_in_ext.rs:371)");
+                assert_eq!(fixed.table_ids_column_idxes.len(), 1);
+                (width, num_repetitions, false)
             }
-            other => panic!("lookup mode {other:?} is not supported by libboojum_hip (specialized columns with the table id as a constant only)"),
+            // width + 1 variable columns per sub-argument, the last one the table id; no table-id constant (setup.rs:970-971)
+            LookupParameters::UseSpecializedColumnsWithTableIdAsVariable { width, num_repetitions, .. } => {
+                assert!(fixed.table_ids_column_idxes.is_empty());
+                (width, num_repetitions, true)
+            }
+            other => panic!("lookup mode {other:?}: the reference's prover does not implement lookups over general-purpose columns either"),
         };
         // ---- evaluators over general purpose columns, in evaluator order, with their selector paths (prover.rs:995-1013) ----
         let mut programs: Vec<Box<OwnedProgram>> = Vec::new();
@@ -311,7 +321,7 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
             num_constant_cols: setup_base.constant_columns.len() as c_uint,
             lookup_width,
             lookup_reps: lookup_reps as c_uint,
-            table_id_col: fixed.table_ids_column_idxes.first().copied().unwrap_or(0) as c_uint,
+            table_id_col: if table_id_as_variable { BJ_TABLE_ID_AS_VARIABLE } else { fixed.table_ids_column_idxes.first().copied().unwrap_or(0) as c_uint },
             quotient_degree: fixed.quotient_degree as c_uint,
             num_gates: gates.len() as c_uint,
             gates: gates.as_ptr(),
@@ -329,6 +339,18 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
             pow_bits: proof_config.pow_bits,
             transcript: transcript_kind,
             tree_hasher: tree_hasher_kind,
+            pow_runner: {
+                use std::any::TypeId;
+                let id = TypeId::of::<POW>();
+                if id == TypeId::of::<sha3::Keccak256>() {
+                    BJ_POW_KECCAK256
+                } else if id == TypeId::of::<blake2::Blake2s256>() {
+                    BJ_POW_BLAKE2S256
+                } else {
+                    assert_eq!(proof_config.pow_bits, 0, "NoPow (or an unknown PoWRunner) with pow_bits != 0");
+                    0
+                }
+            },
         };
         assert!(proof_config.fri_folding_schedule.is_none(), "libboojum_hip computes the schedule (compute_fri_schedule, prover.rs:2281-2372)");
         let sigmas = flatten(setup_base.copy_permutation_polys.iter().map(|p| &p.storage[..]), n);

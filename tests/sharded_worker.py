@@ -30,7 +30,8 @@ def main():
         circuit = S.recursion_like_circuit(-log_n, seed=7)
     else:
         circuit = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2,
-                                       **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else {}))
+                                       **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else
+                                    {"table_id_as_variable": True, "boolean_columns": 2} if log_n == 13 else {}))
     ctx = E.Context(dev)
     comm = E.TorchComm(ctx)
     setup = E.ProverSetup(ctx, circuit, fri, cap, sec, comm=comm)

@@ -118,6 +118,86 @@ def test_golden_pinned_quotient_identity_accepts_hip_proof():
     gsetup.close()
 
 
+def _golden_identity_holds(c, cap, pg, specialized=()):
+    """The quotient-identity code pinned by the reference's own proof (oracle/golden_quotient.py) on a proof of circuit c, fed with
+    the VerificationKey JSON this repository emits for it."""
+    import json
+    import oracle as O
+    from oracle import golden_quotient as GQ
+    from era_boojum_amd import wire_format as W
+    vk = json.loads(W.dumps(W.vk_to_reference_json(c, cap, 8, 16)))
+    t = O.Transcript()
+    t.absorb_cap(cap)
+    t.absorb(pg["public_inputs"])
+    t.absorb_cap(np.array(pg["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(pg["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(pg["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vk), [g.name for g in c.gates], list(specialized), c.non_residues,
+                                    dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    pg["values_at_z"], pg["values_at_z_omega"][0])
+    return lhs == rhs, vk
+
+
+@pytest.mark.parametrize("log_n,kw", [(10, {}), (12, dict(boolean_columns=2, specialized_constant_columns=3)),
+                                      (9, dict(num_gp_vars=24, num_constant_cols=6, lookup_width=3, lookup_reps=11))])
+def test_lookup_with_the_table_id_as_a_variable_column_equals_oracle_proof(log_n, kw):
+    """LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (cs/mod.rs:237-241; compute_lookup_poly_pairs_specialized and
+    compute_quotient_terms_for_lookup_specialized, lookup_argument_in_ext.rs:354-366, 949-1000; verifier.rs:1402-1464): width + 1
+    variable columns per sub-argument, the last one the table id of THAT sub-argument on that row (the synthetic circuit gives
+    every sub-argument its own table per row), no table-id constant column.  The HIP proof equals the oracle prover's byte for
+    byte, the verifier restatement and the golden-pinned identity code accept it, the SetupBaseStorage dump (empty
+    table_ids_column_idxes) selects the mode by itself, and a wrong table id breaks the verifier's lookup sumcheck."""
+    import copy
+    c = S.sha_shaped_circuit(log_n, seed=700 + log_n, table_bits=2, table_id_as_variable=True, **kw)
+    w, reps = c.lookup_width, c.lookup_reps
+    assert c.table_id_col == S.TABLE_ID_AS_VARIABLE and c.num_lookup_vars == (w + 1) * reps and S.check_satisfied(c)
+    assert c.num_constant_cols == c.num_constants_for_gates + sum(g.reps * g.const_stride for g in c.specialized_gates)
+    osetup = OP.Setup(c, 8, 16, threads=8)
+    po = OP.prove(c, osetup, 8, 16, security_level=30, threads=8)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 30)
+    assert np.array_equal(gsetup.cap(), osetup.cap)
+    buf, _ = gsetup.prove()
+    pg = proof_format.parse(buf, security_level=30)
+    _compare(pg, po)
+    assert OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), pg, verbose=True)
+    spec = [(g.name, g.reps) for g in c.specialized_gates]
+    ok, vk_json = _golden_identity_holds(c, gsetup.cap(), pg, spec)
+    assert ok and "UseSpecializedColumnsWithTableIdAsVariable" in vk_json["fixed_parameters"]["lookup_parameters"]
+    assert vk_json["fixed_parameters"]["table_ids_column_idxes"] == []
+    # the verifier restatement built from that JSON alone (the reference's layout) accepts the proof too
+    from oracle import golden_quotient as GQ
+    vk2 = OV.vk_from_reference_geometry(GQ.geometry_from_vk_json(vk_json), gsetup.cap(), [g.name for g in c.gates], spec,
+                                        c.non_residues, 8, 16)
+    assert vk2.table_id_as_variable and vk2.num_vars == c.num_vars and vk2.num_constant_cols == c.num_constant_cols
+    assert OV.verify(vk2, pg)
+    if not c.specialized_gates:             # the dump reader takes the mode from the dump: no table-id column in it
+        from era_boojum_amd import memcopy_format as M
+        bare = copy.copy(c)
+        bare.gates = [copy.copy(g) for g in c.gates]
+        for g in bare.gates:
+            g.path = []
+        b = E.ProverSetup(ctx(), bare, 8, 16, 30, setup_base_dump=M.write_setup_base(c))
+        assert np.array_equal(b.cap(), gsetup.cap())
+        pb, _ = b.prove()
+        assert np.array_equal(pb, buf)
+        b.close()
+    bad = c.variables.copy()                # a table id that names no table: the tuple of that sub-argument is in none
+    col = c.num_gp_vars + (reps - 1) * (w + 1) + w
+    bad[col, 7] = np.uint64(77)
+    # every lookup term of the quotient vanishes by construction (A_i = 1 / denominator): the wrong tuple breaks the sum the
+    # verifier checks at 0 (verifier.rs:1236-1256), as with the reference's prover
+    bbuf, _ = gsetup.prove(variables=bad)
+    assert not OV.verify(OV.VerificationKey(c, gsetup.cap(), 8, 16), proof_format.parse(bbuf, security_level=30))
+    gsetup.close()
+    wrong = copy.copy(c)                    # the table id declared as a constant column that does not exist
+    wrong.table_id_col = c.num_constant_cols
+    with pytest.raises(E.BoojumHipError):
+        E.ProverSetup(ctx(), wrong, 8, 16, 30)
+
+
 def test_poseidon_v1_transcript_proof_equals_oracle_proof():
     """The bench script's pairing: Poseidon2 tree hasher + Poseidon (v1) transcript (gadgets/sha256/mod.rs:289-293)."""
     c = S.sha_shaped_circuit(10, seed=41, table_bits=2)
@@ -135,15 +215,20 @@ def test_poseidon_v1_transcript_proof_equals_oracle_proof():
     gsetup.close()
 
 
-@pytest.mark.parametrize("pow_bits,transcript,kind", [(10, "poseidon2", 1), (17, "poseidon", 2), (12, "blake2s", 3)])
-def test_proof_of_work(pow_bits, transcript, kind):
-    """Blake2s PoW (pow.rs:50-133) after the FRI commit phase: fewer queries (compute_fri_schedule), the smallest valid nonce
-    (what the reference's serial search returns), nonce absorbed as (low, high); proof identical to the oracle prover's
-    (whose PoW runs on hashlib) and accepted by the verifier restatement; a wrong nonce is rejected."""
+@pytest.mark.parametrize("pow_bits,transcript,kind,runner", [(10, "poseidon2", 1, "blake2s"), (17, "poseidon", 2, "blake2s"),
+                                                             (12, "blake2s", 3, "blake2s"), (4, "keccak256", 4, "keccak256"),
+                                                             (18, "keccak256", 4, "keccak256"), (11, "poseidon2", 1, "keccak256")])
+def test_proof_of_work(pow_bits, transcript, kind, runner):
+    """PoW after the FRI commit phase with either runner of pow.rs — Blake2s256 (:50-133) or Keccak256 (:139-230), a type parameter
+    independent of the transcript in the reference, so both the Keccak transcript / hasher pairing and a Poseidon2 transcript are
+    run with the Keccak runner: fewer queries (compute_fri_schedule), the smallest valid nonce (what the reference's serial
+    search returns), nonce absorbed as (low, high); proof identical to the oracle prover's (whose PoW runs on hashlib / the
+    hashlib-pinned Keccak sponge) and accepted by the verifier restatement; a wrong nonce and the other runner are rejected."""
+    rk = {"blake2s": 1, "keccak256": 2}[runner]
     c = S.sha_shaped_circuit(9, seed=60 + pow_bits, table_bits=2)
-    osetup = OP.Setup(c, 8, 16, threads=4, hasher=2 if kind == 3 else 1)
-    po = OP.prove(c, osetup, 8, 16, security_level=40, pow_bits=pow_bits, threads=4, transcript_kind=kind)
-    gsetup = E.ProverSetup(ctx(), c, 8, 16, 40, pow_bits=pow_bits, transcript=transcript)
+    osetup = OP.Setup(c, 8, 16, threads=4, hasher={3: 2, 4: 3}.get(kind, 1))
+    po = OP.prove(c, osetup, 8, 16, security_level=40, pow_bits=pow_bits, threads=4, transcript_kind=kind, pow_runner=rk)
+    gsetup = E.ProverSetup(ctx(), c, 8, 16, 40, pow_bits=pow_bits, transcript=transcript, pow_runner=runner)
     buf, _ = gsetup.prove()
     pg = proof_format.parse(buf, security_level=40)
     assert pg["proof_config"]["pow_bits"] == pow_bits
@@ -152,10 +237,15 @@ def test_proof_of_work(pow_bits, transcript, kind):
     p0 = OP.prove(c, osetup, 8, 16, security_level=40, pow_bits=0, threads=4, transcript_kind=kind)
     assert len(pg["queries_per_fri_repetition"]) < len(p0["queries_per_fri_repetition"])
     vk = OV.VerificationKey(c, gsetup.cap(), 8, 16)
-    assert OV.verify(vk, pg, verbose=True, transcript_kind=kind)
-    bad = dict(pg)
-    bad["pow_challenge"] = pg["pow_challenge"] + 1
-    assert not OV.verify(vk, bad, transcript_kind=kind)
+    assert OV.verify(vk, pg, verbose=True, transcript_kind=kind, pow_runner=rk)
+    if pow_bits >= 10:      # the other hash accepts this nonce with probability 2^-pow_bits
+        assert not OV.verify(vk, pg, transcript_kind=kind, pow_runner=3 - rk)
+    wrong = []
+    for k in (1, 2, 3):      # a neighbouring nonce solves the puzzle too with probability 2^-pow_bits: not all three
+        bad = dict(pg)
+        bad["pow_challenge"] = pg["pow_challenge"] + k
+        wrong.append(OV.verify(vk, bad, transcript_kind=kind, pow_runner=rk))
+    assert not all(wrong)
     gsetup.close()
 
 

@@ -31,8 +31,9 @@ def _free_port():
 # log_n = 0: the real SHA-256 circuit (2^14 rows) on 8 ranks, the bench's multi-GPU configuration in small
 # log_n < 0: the recursion-class circuit (quotient degree 8: a rank's quotient piece is two cosets at 4 ranks, one at 8) at 2^-log_n rows
 # log_n = 12: the bench geometry + gates over specialized columns, one of them with its own constant columns
+# log_n = 13: lookups with the table id as a VARIABLE column (UseSpecializedColumnsWithTableIdAsVariable) + a gate over specialized columns
 @pytest.mark.parametrize("world,log_n,fri_lde,cap,sec", [(2, 10, 8, 16, 30), (4, 10, 8, 16, 30), (8, 11, 8, 16, 40), (2, 9, 4, 8, 20),
-                                                         (8, 0, 8, 16, 30), (4, -10, 8, 16, 30), (8, -10, 8, 16, 30), (4, 12, 8, 16, 30)])
+                                                         (8, 0, 8, 16, 30), (4, -10, 8, 16, 30), (8, -10, 8, 16, 30), (4, 12, 8, 16, 30), (4, 13, 8, 16, 30)])
 def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, log_n, fri_lde, cap, sec):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
@@ -47,7 +48,8 @@ def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, log_n, fri_lde, 
         c = S.recursion_like_circuit(-log_n, seed=7)
     else:
         c = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2,
-                                 **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else {}))
+                                 **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else
+                                    {"table_id_as_variable": True, "boolean_columns": 2} if log_n == 13 else {}))
     single = E.ProverSetup(ctx(), c, fri_lde, cap, sec)
     ref, _ = single.prove()
     for rank in range(world):

@@ -68,16 +68,26 @@ def test_copy_permutation_with_noncanonical_inputs_and_strided_columns():
         d.free()
 
 
+def _lookup_vars(c):
+    """The lookup sub-arguments' variable columns: width per sub-argument, width + 1 with the table id as a variable."""
+    return np.ascontiguousarray(c.variables[c.num_gp_vars:c.num_gp_vars + c.lookup_reps * c.lookup_cols_per_sub])
+
+
+# table_id_as_variable: LookupParameters::UseSpecializedColumnsWithTableIdAsVariable (lookup_argument_in_ext.rs:354-366) — the
+# operators take d_table_id = NULL and read the id from the (width+1)-th variable column of every sub-argument
 @pytest.mark.parametrize("log_n,kw", [(8, {}), (12, {}), (10, dict(num_gp_vars=24, lookup_width=3, lookup_reps=4, num_public_inputs=0)),
-                                      (9, dict(num_gp_vars=20, lookup_width=4, lookup_reps=1, num_public_inputs=0))])
+                                      (9, dict(num_gp_vars=20, lookup_width=4, lookup_reps=1, num_public_inputs=0)),
+                                      (11, dict(table_id_as_variable=True)),
+                                      (9, dict(num_gp_vars=20, lookup_width=2, lookup_reps=11, num_public_inputs=0, table_id_as_variable=True))])
 def test_lookup_polynomials(log_n, kw):
     c = _circuit(log_n, **kw)
     n, reps, w = c.n, c.lookup_reps, c.lookup_width
-    lv = np.ascontiguousarray(c.variables[c.num_gp_vars:c.num_gp_vars + reps * w])
-    wA, wB = OP.lookup_polys(lv, c.constants[c.table_id_col], c.tables, c.multiplicities[0], reps, w, log_n, LBETA, LGAMMA, threads=8)
-    d_l, d_t, d_tab, d_m = DevBuf(lv), DevBuf(c.constants[c.table_id_col]), DevBuf(c.tables), DevBuf(c.multiplicities[0])
+    lv = _lookup_vars(c)
+    tid = OP.lookup_table_id(c, c.constants)
+    wA, wB = OP.lookup_polys(lv, tid, c.tables, c.multiplicities[0], reps, w, log_n, LBETA, LGAMMA, threads=8)
+    d_l, d_t, d_tab, d_m = DevBuf(lv), DevBuf(tid if tid is not None else np.zeros(1, dtype=np.uint64)), DevBuf(c.tables), DevBuf(c.multiplicities[0])
     d_A, d_B = DevBuf(nelems=2 * reps * n), DevBuf(nelems=2 * n)
-    ctx().lookup_polys(d_l.ptr, n, d_t.ptr, d_tab.ptr, n, d_m.ptr, reps, w, log_n, LBETA, LGAMMA, d_A.ptr, d_B.ptr)
+    ctx().lookup_polys(d_l.ptr, n, d_t.ptr if tid is not None else None, d_tab.ptr, n, d_m.ptr, reps, w, log_n, LBETA, LGAMMA, d_A.ptr, d_B.ptr)
     A, B = d_A.get((reps, 2, n)), d_B.get((2, n))
     assert np.array_equal(A, wA) and np.array_equal(B, wB)
     # the log-derivative argument itself: sum_rows (sum_i A_i - B) = 0 (lookup_argument_in_ext.rs, the sumcheck the verifier does at 0)
@@ -96,8 +106,8 @@ def _quotient_inputs(c):
     z, partials = OP.copy_perm_stage2(c.variables, c.sigmas, c.non_residues, log_n, q, BETA, GAMMA, threads=8)
     stage2 = [z[0], z[1]] + [partials[j][k] for j in range(partials.shape[0]) for k in range(2)]
     reps, w = c.lookup_reps, c.lookup_width
-    lv = np.ascontiguousarray(c.variables[c.num_gp_vars:c.num_gp_vars + reps * w])
-    A, B = OP.lookup_polys(lv, c.constants[c.table_id_col], c.tables, c.multiplicities[0], reps, w, log_n, LBETA, LGAMMA, threads=8)
+    A, B = OP.lookup_polys(_lookup_vars(c), OP.lookup_table_id(c, c.constants), c.tables, c.multiplicities[0], reps, w, log_n, LBETA, LGAMMA,
+                           threads=8)
     stage2 += [A[i][k] for i in range(reps) for k in range(2)] + [B[0], B[1]]
 
     def lde_q(cols):
@@ -124,7 +134,8 @@ def _oracle_quotient(c, d, alphas):
                        d["log_q"], alphas, BETA, GAMMA, LBETA, LGAMMA, threads=8)
 
 
-@pytest.mark.parametrize("log_n,kw", [(9, {}), (11, dict(num_gp_vars=24, lookup_width=3, lookup_reps=4, num_public_inputs=0))])
+@pytest.mark.parametrize("log_n,kw", [(9, {}), (11, dict(num_gp_vars=24, lookup_width=3, lookup_reps=4, num_public_inputs=0)),
+                                      (10, dict(table_id_as_variable=True))])
 def test_quotient_term_kernels_one_by_one_and_together(log_n, kw):
     c = _circuit(log_n, **kw)
     d = _quotient_inputs(c)
@@ -137,7 +148,7 @@ def test_quotient_term_kernels_one_by_one_and_together(log_n, kw):
     out = DevBuf(nelems=2 * Q)
     o0, o1 = out.ptr, out.ptr + 8 * Q
     lv_ptr = bufs["vars"].ptr + 8 * Q * c.num_gp_vars
-    tid_ptr = bufs["con"].ptr + 8 * Q * c.table_id_col
+    tid_ptr = None if c.table_id_as_variable else bufs["con"].ptr + 8 * Q * c.table_id_col
     A_ptr = bufs["s2"].ptr + 8 * Q * (2 + 2 * n_part)
     B_ptr = A_ptr + 8 * Q * 2 * reps
     C = ctx()

@@ -164,3 +164,61 @@ def test_specialized_gate_with_its_own_constant_columns():
         S.check_satisfied(bad)
     with pytest.raises(AssertionError, match="unsatisfied"):
         OP.prove(bad, OP.Setup(bad, 8, 16, threads=4), 8, 16, security_level=20, threads=4)
+
+
+def test_lookup_with_the_table_id_as_a_variable_column():
+    """UseSpecializedColumnsWithTableIdAsVariable (cs/mod.rs:237-241): the CPU restatement of the second mode of
+    compute_lookup_poly_pairs_specialized / compute_quotient_terms_for_lookup_specialized (lookup_argument_in_ext.rs:354-366,
+    949-1000) proves a circuit whose sub-arguments each carry their own table id in a (width+1)-th variable column; the verifier
+    restatement (verifier.rs:1402-1464) and the quotient-identity code pinned by the reference's own proof accept it, the
+    coset-streaming restatement gives the same caps and openings, and a wrong table id breaks the verifier's lookup sumcheck."""
+    import json
+    from era_boojum_amd import wire_format as W
+    from oracle import golden_quotient as GQ
+    from oracle import prover_streaming as PS
+    c = S.sha_shaped_circuit(9, seed=17, table_bits=2, table_id_as_variable=True, boolean_columns=2)
+    assert S.check_satisfied(c) and c.num_vars == 60 + 8 * 5 + 2 and c.num_constant_cols == c.num_constants_for_gates
+    ids = c.variables[c.num_gp_vars + 4::5][:8]
+    assert not np.array_equal(ids[0], ids[1]) and 1 <= int(ids.min()) and int(ids.max()) <= 5      # a table per sub-argument and row
+    setup = OP.Setup(c, 8, 16, threads=4)
+    proof = OP.prove(c, setup, 8, 16, security_level=30, threads=4)
+    vk = OV.VerificationKey(c, setup.cap, 8, 16)
+    assert OV.verify(vk, proof, verbose=True)
+    assert len(proof["values_at_z"]) == 102 + c.num_constant_cols + 102 + 1 + 25 + (1 + 8 + 1 + 5) + 4
+    assert len(proof["queries_per_fri_repetition"][0]["witness_query"]["leaf_elements"]) == 103
+    # the identity code that holds on the reference's own proof, from the VerificationKey JSON of this circuit
+    vkj = json.loads(W.dumps(W.vk_to_reference_json(c, setup.cap, 8, 16)))
+    assert vkj["fixed_parameters"]["lookup_parameters"] == {"UseSpecializedColumnsWithTableIdAsVariable":
+                                                            {"width": 4, "num_repetitions": 8, "share_table_id": False}}
+    t = O.Transcript()
+    t.absorb_cap(setup.cap)
+    t.absorb(proof["public_inputs"])
+    t.absorb_cap(np.array(proof["witness_oracle_cap"], dtype=np.uint64))
+    beta, gamma, lbeta, lgamma = (t.challenge_ext() for _ in range(4))
+    t.absorb_cap(np.array(proof["stage_2_oracle_cap"], dtype=np.uint64))
+    alpha = t.challenge_ext()
+    t.absorb_cap(np.array(proof["quotient_oracle_cap"], dtype=np.uint64))
+    z = t.challenge_ext()
+    lhs, rhs = GQ.quotient_identity(GQ.geometry_from_vk_json(vkj), [g.name for g in c.gates], [("BooleanConstraintGate", 2)],
+                                    c.non_residues, dict(beta=beta, gamma=gamma, lookup_beta=lbeta, lookup_gamma=lgamma, alpha=alpha, z=z),
+                                    proof["values_at_z"], proof["values_at_z_omega"][0])
+    assert lhs == rhs
+    bad = copy.deepcopy(proof)                              # the opening of a table-id column at z
+    k = c.num_gp_vars + 4
+    bad["values_at_z"][k] = [(bad["values_at_z"][k][0] + 1) % O.P, bad["values_at_z"][k][1]]
+    assert not OV.verify(vk, bad)
+    plain = S.sha_shaped_circuit(8, seed=18, table_bits=2, table_id_as_variable=True)      # the streaming restatement's circuit class
+    psetup = OP.Setup(plain, 8, 16, threads=4)
+    want = OP.prove(plain, psetup, 8, 16, security_level=20, threads=4)
+    got = PS.commitments_and_openings(plain, psetup.cap, 8, 16, threads=4)
+    for key in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z", "values_at_z_omega", "values_at_0"):
+        assert got[key] == want[key], key
+    wrong = S.sha_shaped_circuit(8, seed=3, table_bits=2, table_id_as_variable=True)
+    col = wrong.num_gp_vars + 2 * 5 + 4
+    wrong.variables[col, 9] = np.uint64(77)                 # names a table that does not exist: the tuple is in no table
+    # A_i = 1 / denominator makes every lookup TERM of the quotient vanish by construction; what a wrong tuple breaks is the sum
+    # sum_i A_i(0) = B(0) the verifier checks (verifier.rs:1236-1256), exactly as in the reference (its prover sums only under
+    # DEBUG_SATISFIABLE, lookup_argument_in_ext.rs:672-700)
+    wsetup = OP.Setup(wrong, 8, 16, threads=4)
+    wproof = OP.prove(wrong, wsetup, 8, 16, security_level=20, threads=4)
+    assert not OV.verify(OV.VerificationKey(wrong, wsetup.cap, 8, 16), wproof)

@@ -102,7 +102,7 @@ def parse_fn_pointer(decl, enums, structs):
 
 def parse_header(path=HEADER):
     src = strip_comments(open(path).read())
-    defines = [(m.group(1), m.group(2)) for m in re.finditer(r"^#define\s+(BJ_[A-Z0-9_]+)\s+(\d+)\s*$", src, flags=re.M)]
+    defines = [(m.group(1), m.group(2)) for m in re.finditer(r"^#define\s+(BJ_[A-Z0-9_]+)\s+(\d+|0[xX][0-9a-fA-F]+)[uU]?\s*$", src, flags=re.M)]
     enums, enum_consts = {}, []
     for m in re.finditer(r"(typedef\s+)?enum\s*([A-Za-z_0-9]*)\s*\{(.*?)\}\s*([A-Za-z_0-9]*)\s*;", src, flags=re.S):
         name = m.group(4) or m.group(2)
