@@ -119,8 +119,15 @@ def lde_coset_shifts(log_n, log_lde):
     return out
 
 
-def fft_batch(cols, coset=1, threads=1):
-    """cols: [n_cols, n] natural -> bit-reversed evaluations on coset*<w>; returns a new array."""
+def fft_batch(cols, coset=1, threads=1, out=None):
+    """cols: [n_cols, n] natural -> bit-reversed evaluations on coset*<w>; returns a new array, or `out` (same shape, reused by a
+    caller that transforms the same columns to many cosets: no fresh pages per call)."""
+    if out is not None:
+        src = _arr(cols)
+        assert out.shape == src.shape and out.dtype == np.uint64 and out.flags["C_CONTIGUOUS"] and out is not src
+        n_cols, n = src.shape
+        lib().orc_fft_batch_to(_p(src), _p(out), C.c_uint(n.bit_length() - 1), C.c_size_t(n_cols), C.c_uint64(coset), C.c_int(threads))
+        return out
     a = _arr(cols).copy()
     n_cols, n = a.shape
     lib().orc_fft_batch(_p(a), C.c_uint(n.bit_length() - 1), C.c_size_t(n_cols), C.c_uint64(coset), C.c_int(threads))
@@ -373,6 +380,28 @@ def deep_quotient_accumulate(sources, values, challenges, at, log_n, log_lde, ds
     chs = _arr(challenges).reshape(-1)
     lib().orc_deep_quotient_accumulate(p0, p1, C.c_size_t(k), _p(vals), _p(chs), _p(_arr(at)), C.c_uint(log_n),
                                        C.c_uint(log_lde), _p(dst0), _p(dst1), C.c_int(threads))
+
+
+def deep_quotient_accumulate_range(sources, values, challenges, at, log_n, log_lde, first, dst0, dst1, threads=1):
+    """The same on the flat LDE indices [first, first + len(dst0)): sources and dst hold only those points."""
+    k = len(sources)
+    keep = []
+    p0 = (u64p * k)()
+    p1 = (u64p * k)()
+    count = dst0.size
+    for i, (a, b) in enumerate(sources):
+        a = _arr(a); keep.append(a); p0[i] = _p(a)
+        assert a.size == count
+        if b is None:
+            p1[i] = None
+        else:
+            b = _arr(b); keep.append(b); p1[i] = _p(b)
+    vals = _arr(values).reshape(-1)
+    chs = _arr(challenges).reshape(-1)
+    assert dst0.flags["C_CONTIGUOUS"] and dst1.flags["C_CONTIGUOUS"] and dst1.size == count
+    lib().orc_deep_quotient_accumulate_range(p0, p1, C.c_size_t(k), _p(vals), _p(chs), _p(_arr(at)), C.c_uint(log_n),
+                                             C.c_uint(log_lde), C.c_size_t(first), C.c_size_t(count), _p(dst0), _p(dst1),
+                                             C.c_int(threads))
 
 
 def deep_quotient_point(f, values, challenges, at, x):

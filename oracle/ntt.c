@@ -154,6 +154,19 @@ void orc_fft_batch(uint64_t *cols, unsigned log_n, size_t n_cols, uint64_t coset
     for (size_t c = 0; c < n_cols; c++) orc_fft_natural_to_bitreversed(cols + c * n, log_n, coset, tw);
     free(tw);
 }
+/* out-of-place: dst[c] = NTT(src[c]); the copy runs inside the parallel loop (a caller that reuses dst over many cosets does not
+ * fault fresh pages in for every call — oracle/prover_streaming.py) */
+void orc_fft_batch_to(const uint64_t *src, uint64_t *dst, unsigned log_n, size_t n_cols, uint64_t coset, int threads) {
+    size_t n = (size_t)1 << log_n;
+    gl_t *tw = (gl_t *)malloc((n / 2 + 1) * sizeof(gl_t));
+    orc_twiddles(tw, log_n, 0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (size_t c = 0; c < n_cols; c++) {
+        memcpy(dst + c * n, src + c * n, n * sizeof(uint64_t));
+        orc_fft_natural_to_bitreversed(dst + c * n, log_n, coset, tw);
+    }
+    free(tw);
+}
 void orc_ifft_batch(uint64_t *cols, unsigned log_n, size_t n_cols, uint64_t coset, int threads) {
     size_t n = (size_t)1 << log_n;
     gl_t *tw = (gl_t *)malloc((n / 2 + 1) * sizeof(gl_t));

@@ -26,6 +26,7 @@ void orc_naive_dft(const uint64_t *a, uint64_t *out, unsigned log_n, uint64_t co
 void orc_lde_coset_shifts(uint64_t *out, unsigned log_n, unsigned log_lde);
 void orc_lde_from_monomials(const uint64_t *mono, uint64_t *out, unsigned log_n, unsigned log_lde, const uint64_t *fwd_tw);
 void orc_fft_batch(uint64_t *cols, unsigned log_n, size_t n_cols, uint64_t coset, int threads);
+void orc_fft_batch_to(const uint64_t *src, uint64_t *dst, unsigned log_n, size_t n_cols, uint64_t coset, int threads);
 void orc_ifft_batch(uint64_t *cols, unsigned log_n, size_t n_cols, uint64_t coset, int threads);
 void orc_lde_batch(const uint64_t *mono, uint64_t *out, unsigned log_n, unsigned log_lde, size_t n_cols, int threads);
 
@@ -91,6 +92,9 @@ void orc_deep_quotient_point(const uint64_t *f0, const uint64_t *f1, const unsig
 void orc_deep_quotient_accumulate(const uint64_t *const *src_c0, const uint64_t *const *src_c1, size_t n_src,
                                   const uint64_t *values, const uint64_t *challenges, const uint64_t *at, unsigned log_n,
                                   unsigned log_lde, uint64_t *dst0, uint64_t *dst1, int threads);
+void orc_deep_quotient_accumulate_range(const uint64_t *const *src_c0, const uint64_t *const *src_c1, size_t n_src,
+                                        const uint64_t *values, const uint64_t *challenges, const uint64_t *at, unsigned log_n,
+                                        unsigned log_lde, size_t first, size_t count, uint64_t *dst0, uint64_t *dst1, int threads);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,33 @@ void orc_deep_quotient_point(const uint64_t *f0, const uint64_t *f1, const unsig
     out2[0] = acc.c0; out2[1] = acc.c1;
 }
 
+/* The same over the flat LDE indices [first, first + count) only: every array (sources, dst) holds `count` entries, entry i
+ * belonging to the point I = first + i.  The accumulation is pointwise (prover.rs:2552-2706 iterates (outer, inner) and touches
+ * one LDE point at a time), so a caller short of memory runs it one coset at a time (oracle/prover_streaming.py). */
+void orc_deep_quotient_accumulate_range(const uint64_t *const *src_c0, const uint64_t *const *src_c1, size_t n_src,
+                                        const uint64_t *values /*[n_src][2]*/, const uint64_t *challenges /*[n_src][2]*/,
+                                        const uint64_t *at, unsigned log_n, unsigned log_lde, size_t first, size_t count,
+                                        uint64_t *dst0, uint64_t *dst1, int threads) {
+    unsigned log_full = log_n + log_lde;
+    gl_t w = gl_omega(log_full);
+#pragma omp parallel num_threads(threads)
+    {
+        uint64_t *f0 = (uint64_t *)malloc(n_src * sizeof(uint64_t)), *f1 = (uint64_t *)malloc(n_src * sizeof(uint64_t));
+        unsigned char *ie = (unsigned char *)malloc(n_src);
+        for (size_t k = 0; k < n_src; k++) ie[k] = src_c1[k] != NULL;
+#pragma omp for schedule(static)
+        for (size_t i = 0; i < count; i++) {
+            gl_t x = gl_mul(GL_GEN, gl_pow(w, bitrev64(first + i, log_full)));
+            for (size_t k = 0; k < n_src; k++) { f0[k] = src_c0[k][i]; f1[k] = src_c1[k] ? src_c1[k][i] : 0; }
+            uint64_t o[2];
+            orc_deep_quotient_point(f0, f1, ie, n_src, values, challenges, at, x, o);
+            dst0[i] = gl_add(gl_canon(dst0[i]), o[0]);
+            dst1[i] = gl_add(gl_canon(dst1[i]), o[1]);
+        }
+        free(f0); free(f1); free(ie);
+    }
+}
+
 void orc_deep_quotient_accumulate(const uint64_t *const *src_c0, const uint64_t *const *src_c1, size_t n_src,
                                   const uint64_t *values /*[n_src][2]*/, const uint64_t *challenges /*[n_src][2]*/,
                                   const uint64_t *at, unsigned log_n, unsigned log_lde, uint64_t *dst0, uint64_t *dst1,

@@ -325,9 +325,11 @@ def test_proof_at_2p23_rows_equals_the_streaming_oracle():
     (oracle/prover_streaming.py) recomputes from the witness alone: the cap nodes of cosets {0, 5} of the witness and
     second-stage oracles (a coset of the witness oracle is 10^8 permutations on the host: all eight would not fit the suite),
     the WHOLE quotient cap, and all 241 values at z, z*omega and 0 under the challenges of the HIP proof's transcript; all of
-    them must equal the HIP proof's.  The verifier restatement then accepts the rest (DEEP, FRI, queries; public inputs
-    included — their DEEP opening sets run over all 2^26 points; one of those launches lost a loop's exit test to an undeclared
-    SCC write until round 2, tests/test_gpu_openings.py)."""
+    them must equal the HIP proof's.  Since round 5 the restatement goes on past the openings: DEEP on every one of the 2^26
+    points (a second pass over the cosets), do_fri, queries — FRI base cap, every intermediate cap, final monomials, every FRI
+    query opening, and the base-oracle openings of the queries that land in hashed cosets equal the HIP proof's too.  The
+    verifier restatement accepts the proof as a whole (public inputs included — their DEEP opening sets run over all 2^26 points;
+    one of those launches lost a loop's exit test to an undeclared SCC write until round 2, tests/test_gpu_openings.py)."""
     from oracle import prover_streaming as PS
     c = S.sha_shaped_circuit(23, seed=42, table_bits=4)
     setup = E.ProverSetup(ctx(), c, 8, 16, 100)
@@ -343,9 +345,15 @@ def test_proof_at_2p23_rows_equals_the_streaming_oracle():
     assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg, verbose=True)
     claimed = {k: pg[k] for k in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap")}
     po = PS.commitments_and_openings(c, cap, 8, 16, threads=64, transcript_kind=1, check_setup_cosets=(5,), cap_cosets=(0, 5),
-                                     claimed_caps=claimed)
+                                     claimed_caps=claimed, rest_of_the_proof=True, security_level=100)
     for k in ("public_inputs", "quotient_oracle_cap", "values_at_z", "values_at_z_omega", "values_at_0"):
         assert pg[k] == po[k], k
+    # past the openings (round 5): the DEEP accumulator of all 2^26 points coset by coset, every FRI cap, the final monomials and
+    # all FRI query openings byte for byte; the quotient opening + path of every query, the witness / second-stage ones of the
+    # queries in cosets {0, 5}, the setup ones of coset 5
+    compared = PS.compare_rest_of_the_proof(pg, po)
+    nq = len(pg["queries_per_fri_repetition"])
+    assert compared >= nq and len(po["query_indexes"]) == nq
     for name in ("witness_oracle_cap", "stage_2_oracle_cap"):
         for cs, frag in po["cap_fragments"][name].items():
             assert np.array_equal(frag, np.asarray(pg[name], dtype=np.uint64)[2 * cs:2 * cs + 2]), (name, cs)

@@ -93,6 +93,50 @@ def test_coset_streaming_restatement_equals_the_full_prover(small_case):
     assert got["challenges"]["z"] != aux["z"]      # the other transcript draws other challenges: the comparison above is not vacuous
 
 
+def test_coset_streaming_restatement_of_the_rest_of_the_proof(small_case):
+    """Past the openings (what pins the WHOLE transcript at the bench's 2^22 rows on hosts that cannot hold the full oracle
+    prover): the DEEP accumulator coset by coset, do_fri on it, the queries.  Against oracle/prover.py under both algebraic
+    transcripts: DEEP challenge, every FRI cap and fold challenge, final monomials, query indices, every FRI query opening byte
+    for byte; for the witness / second-stage / quotient oracles every query's path and the hash of the full prover's opened
+    leaf; the setup oracle's on the cosets asked for.  A proof with one changed opened element or one changed FRI leaf is
+    told apart."""
+    from oracle import prover_streaming as PS
+    c, setup, proof, aux, vk = small_case
+    N, n = c.n * 8, c.n
+    for kind in (1, 2):
+        want = proof if kind == 1 else OP.prove(c, setup, 8, 16, security_level=30, threads=4, transcript_kind=2)
+        got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, transcript_kind=kind, check_setup_cosets=(0, 3, 7),
+                                          rest_of_the_proof=True, security_level=30)
+        compared = PS.compare_rest_of_the_proof(want, got)
+        nq = len(want["queries_per_fri_repetition"])
+        in_setup = sum(1 for idx in got["query_indexes"] if (idx >> c.log_n) in (0, 3, 7))
+        assert compared == 3 * nq + in_setup and 0 < in_setup < nq
+        if kind == 1:
+            assert got["deep_challenge"] == aux["deep_challenge"] and got["fri_challenges"] == aux["fri_challenges"]
+            fri_slot = aux["deep"][0][got["query_indexes"][0]]
+            assert want["queries_per_fri_repetition"][0]["fri_queries"][0]["leaf_elements"][got["query_indexes"][0] & 7] == int(fri_slot)
+    bad = copy.deepcopy(proof)
+    bad["queries_per_fri_repetition"][2]["stage_2_query"]["leaf_elements"][11] ^= 1
+    got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, rest_of_the_proof=True, security_level=30)
+    with pytest.raises(AssertionError, match="stage_2_query leaf"):
+        PS.compare_rest_of_the_proof(bad, got)
+    bad = copy.deepcopy(proof)
+    bad["queries_per_fri_repetition"][1]["fri_queries"][1]["leaf_elements"][3] ^= 1
+    with pytest.raises(AssertionError, match="FRI query"):
+        PS.compare_rest_of_the_proof(bad, got)
+    bad = copy.deepcopy(proof)
+    bad["queries_per_fri_repetition"][0]["witness_query"]["proof"][4][0] ^= 1
+    with pytest.raises(AssertionError, match="witness_query path"):
+        PS.compare_rest_of_the_proof(bad, got)
+    # claimed-cap mode (2^23 rows): only two cosets of the two big oracles are hashed; the rest of the proof is still recomputed
+    claimed = {k: proof[k] for k in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap")}
+    got = PS.commitments_and_openings(c, setup.cap, 8, 16, threads=4, cap_cosets=(0, 5), claimed_caps=claimed, check_setup_cosets=(0, 5),
+                                      rest_of_the_proof=True, security_level=30)
+    compared = PS.compare_rest_of_the_proof(proof, got)
+    in_two = sum(1 for idx in got["query_indexes"] if (idx >> c.log_n) in (0, 5))
+    assert compared == len(got["query_indexes"]) + 3 * in_two      # quotient everywhere; witness, stage 2, setup on cosets {0, 5}
+
+
 def test_coset_streaming_restatement_with_claimed_caps(small_case):
     """The cfg5 mode (2^23 rows): only cosets {0, 5} of the witness and second-stage oracles are hashed, the transcript absorbs
     the caps of the proof under check, the recomputed subtree roots are returned for comparison and every opening is still
