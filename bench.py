@@ -29,6 +29,11 @@ Extra objects on the JSON line:
   stages_ms     per-round wall time, named after the reference's log lines.
   kernels       gate evaluation, copy-permutation quotient, barycentric evaluation, DEEP and the first FRI fold: first launch of
                 each inside every timed proof (HIP events on the launch stream), algorithmic bytes by SURVEY §8d vs the HBM peak.
+  scale_replay  (N = 1) one rank's critical path of the SAME proof sharded over W = 2, 4, 8 GPUs, measured on this one GPU: the W ranks
+                run once as threads sharing the device while every all-gathered buffer is recorded, then each rank runs ALONE with
+                the recorded-peer transport (bj_comm_replay_create) serving its collectives as device copies.  ms per proof per
+                rank, max over ranks; link time and waiting for peers EXCLUDED (DESIGN.md §6 adds ~2-3.5 ms for them); every
+                replayed proof equals the single-GPU bytes.  Next to it the model of tools/scale_model.py.
   cpu_baseline  the C/Python oracle prover (restated reference CPU algorithm) on this box's host cores, on a smaller
                 instance of the same circuit (2^20 rows = BASELINE cfg3's size, ~40 s; 2^18 as `micro.proof_2p18`), in rows/s; `micro` times the oracle's C primitives on all
                 cores at the bench's own sizes (NTT 2^20 x 256, Poseidon2 tree 2^23 x 93: benches/benchmarks.rs:479-520, 73-79);
@@ -93,6 +98,11 @@ def main():
     ap.add_argument("--no-host-witness", action="store_true", help="skip the bj_prove (host witness, PCIe inclusive) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-scale-replay", action="store_true", help="skip the one-rank-alone measurement of the sharded proof at W = 2, 4, 8")
+    ap.add_argument("--replay-world", type=str, default="2,4,8",
+                    help="world sizes of the scale_replay leg (era_boojum_amd/scale_replay.py): rank r of a W-rank proof alone on this "
+                         "GPU with its peers' all-gathered buffers replayed from a recording")
+    ap.add_argument("--replay-steps", type=int, default=3)
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -389,6 +399,34 @@ def main():
         if not OV.verify(OV.VerificationKey(circuit, setup.cap(), args.fri_lde, args.cap), pg, transcript_kind=setup.transcript_kind):
             raise SystemExit("parity failure: the verifier restatement rejects the HIP proof")
         out["config"]["verified"] = "oracle/verifier.py accepts the last timed proof"
+    transcript_kind = setup.transcript_kind
+    if rank == 0 and world == 1 and not args.no_scale_replay and log_n >= 12:
+        # one rank of the sharded proof alone on this GPU, peers replayed (the only multi-GPU evidence one GPU can give)
+        from era_boojum_amd import scale_replay
+        t1_ms = elapsed / args.steps * 1e3
+        setup.close()                         # the single-GPU setup and arena make room for the W rank contexts
+        ctx.release_workspace()
+        torch.cuda.empty_cache()
+        sr = {"what": "rank r of a W-rank sharded proof ALONE on this GPU, every all-gather served by a device copy of the buffer "
+                      "recorded in a W-thread run of the same proof (bj_comm_replay_create); ms per proof = kernels + launches + host "
+                      "round trips of one rank; link time and waiting for peers excluded; every replayed proof = the single-GPU bytes",
+              "single_gpu_ms": round(t1_ms, 3), "steps": args.replay_steps,
+              "model_ms_from_tools_scale_model": {"2": 143.5, "4": 84.4, "8": 54.9} if (log_n == 22 and args.fri_lde == 8) else None,
+              "worlds": {}}
+        for w in [int(x) for x in args.replay_world.split(",") if x]:
+            if w < 2 or args.fri_lde % w or args.cap % w:
+                continue
+            try:
+                r = scale_replay.measure(circuit, w, args.fri_lde, args.cap, args.security, args.transcript, steps=args.replay_steps,
+                                         warmup=1, device=local_rank, reference_proof=proof_buf, d_vars=d_vars, d_mult=d_mult)
+                # T(W) = R + S / W and T(1) = R + S give the replicated part R the measurement implies
+                r["implied_replicated_ms"] = round((w * r["max_ms"] - t1_ms) / (w - 1), 2)
+                r["speedup_compute_only"] = round(t1_ms / r["max_ms"], 3)
+                sr["worlds"][str(w)] = r
+            except Exception as e:                # noqa: BLE001 — the headline must not be lost to the secondary leg
+                sr["worlds"][str(w)] = {"error": repr(e)[:300]}
+                torch.cuda.empty_cache()
+        out["scale_replay"] = sr
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as O
         from oracle import prover as OP
@@ -430,7 +468,7 @@ def main():
             cpu0 = sum(os.times()[:2])
             c0 = time.perf_counter()
             OP.prove(csmall, osetup, args.fri_lde, args.cap, security_level=args.security, threads=threads,
-                     transcript_kind=setup.transcript_kind if setup.transcript_kind in (1, 2) else 1)
+                     transcript_kind=transcript_kind if transcript_kind in (1, 2) else 1)
             t = time.perf_counter() - c0
             return t, (sum(os.times()[:2]) - cpu0) / t        # CPU seconds per wall second: the cores the proof actually kept busy
 
@@ -474,6 +512,10 @@ def main():
         perms = (1 << tl_log) * 12 + (1 << tl_log) - args.cap
         del cols
         out["cpu_baseline"] = {"value": round((1 << main_log) / t_cpu, 1), "unit": "rows/s", "cores": threads, "kind": "port",
+                               "log_n": main_log, "downgraded_from": (args.cpu_log_n if main_log != args.cpu_log_n else None),
+                               "downgrade_reason": (None if main_log == args.cpu_log_n else
+                                                    ("estimated %.0f s at 2^%d on this host" % (est_main, args.cpu_log_n) if est_main >= 150.0
+                                                     else "%.0f GB of host memory available, %.0f GB wanted" % (ram_gb, 2.5 * need_gb))),
                                "cpu_model": cpu_model, "affinity_cpus": affinity, "cgroup_quota_cores": quota, "busy_cores_measured": round(busy_cores, 1),
                                "sample": "one proof of the same circuit at 2^%d rows by the oracle prover (C bulk ops + python "
                                          "orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (main_log, t_cpu),

@@ -67,6 +67,10 @@ _SIGNATURES = {
     "bj_comm_rccl_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "bj_comm_rccl_destroy": (None, [C.c_void_p]),
     "bj_comm_rccl_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bj_setup_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_comm_replay_create": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
+    "bj_comm_replay_destroy": (None, [C.c_void_p]),
+    "bj_comm_replay_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bj_gate_program_generated": (C.c_int, [C.c_void_p]),
     "bj_gate_program_canonical_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_gate_program_emit_body": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -629,6 +633,100 @@ class RcclComm:
             pass
 
 
+class ReplayComm:
+    """The recorded-peer transport (bj_comm_replay_create): one rank of a `world`-rank proof alone on its GPU, every all-gather
+    answered by a device copy of what that collective gathered in a real run.  `recorded` = [(device pointer, bytes)] in call
+    order: n_setup buffers for the setup's collectives, then the buffers of one proof (used cyclically)."""
+
+    def __init__(self, ctx, rank, world, recorded, n_setup=0, verify=False):
+        self._ctx, self._lib = ctx, ctx._lib
+        self.rank, self.world = rank, world
+        self._ptrs = (C.c_void_p * max(1, len(recorded)))(*[p for p, _ in recorded])
+        self._sizes = (C.c_size_t * max(1, len(recorded)))(*[b for _, b in recorded])
+        self.struct = _Comm()
+        ctx._check(self._lib.bj_comm_replay_create(ctx._h, rank, world, self._ptrs, self._sizes, n_setup, len(recorded) - n_setup,
+                                                   1 if verify else 0, C.byref(self.struct)))
+
+    def stats(self):
+        a, b, m = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._lib.bj_comm_replay_stats(C.byref(self.struct), C.byref(a), C.byref(b), C.byref(m))
+        return a.value, b.value, m.value
+
+    calls = property(lambda self: self.stats()[0])
+    bytes = property(lambda self: self.stats()[1])
+    mismatches = property(lambda self: self.stats()[2])
+
+    def close(self):
+        if self.struct.user:
+            self._lib.bj_comm_replay_destroy(C.byref(self.struct))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ThreadGroup:
+    """`world` ranks of ONE sharded proof as threads of this process, all on one GPU (each with its own Context = its own stream
+    and arena): the all-gather is a rendezvous of the threads and device-to-device copies.  Functionally the sharded prover as
+    it runs over RCCL (the ranks time-slice the GPU, so its timing means nothing); with record=True rank 0 keeps a copy of
+    every gathered buffer — what ReplayComm then serves to one rank running alone (bench.py --replay-world)."""
+
+    def __init__(self, world, record=False):
+        import threading
+        self.world, self.record = world, record
+        self._barrier = threading.Barrier(world)
+        self._posted = [None] * world
+        self.recorded = []            # [(torch uint8 tensor)] in call order (rank 0's view)
+        self.marks = []               # len(recorded) at the moments mark() was called
+        self.error = None
+
+    def mark(self):
+        self.marks.append(len(self.recorded))
+
+    def comm(self, ctx, rank):
+        return _ThreadComm(self, ctx, rank)
+
+
+class _ThreadComm:
+    def __init__(self, group, ctx, rank):
+        self._g, self._ctx, self.rank, self.world = group, ctx, rank, group.world
+        self.calls, self.bytes = 0, 0
+        self._fn = _ALL_GATHER_FN(self._all_gather)
+        self.struct = _Comm(rank, group.world, self._fn, None, _ALL_GATHER_STREAM_FN())
+
+    def _all_gather(self, _user, d_send, d_recv, nbytes):
+        g = self._g
+        try:
+            g._posted[self.rank] = (d_send, nbytes)
+            g._barrier.wait()                   # every rank's stream is idle here (the library's contract for this entry)
+            ctx, lib = self._ctx, self._ctx._lib
+            for r in range(self.world):
+                src, nb = g._posted[r]
+                if nb != nbytes:
+                    raise BoojumHipError("ranks disagree on the size of a collective (%d vs %d bytes)" % (nb, nbytes))
+                ctx._check(lib.bj_memcpy_d2d(ctx._h, C.c_void_p(d_recv + r * nbytes), C.c_void_p(src), nbytes))
+            if g.record and self.rank == 0:
+                import torch
+                t = torch.empty(nbytes * self.world, dtype=torch.uint8, device=torch.device("cuda", ctx.device))
+                ctx._check(lib.bj_memcpy_d2d(ctx._h, C.c_void_p(t.data_ptr()), C.c_void_p(d_recv), nbytes * self.world))
+                g.recorded.append(t)
+            g._barrier.wait()                   # nobody overwrites its send buffer before every peer has read it
+            self.calls += 1
+            self.bytes += nbytes * self.world
+            return 0
+        except Exception as e:                  # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            g.error = e
+            try:
+                g._barrier.abort()
+            except Exception:
+                pass
+            return 1
+
+
 class TorchComm:
     """bj_comm over torch.distributed: the all-gather the sharded prover asks the host for.
 
@@ -744,6 +842,11 @@ class ProverSetup:
                                                      _np_ptr(tab) if c.lookup_reps else None, C.byref(cfg),
                                                      C.byref(comm.struct) if comm is not None else None, C.byref(h)))
         self._h = h
+
+    def set_comm(self, comm):
+        """bj_setup_set_comm: another transport for the same shard (same rank / world)."""
+        self._ctx._check(self._lib.bj_setup_set_comm(self._h, C.byref(comm.struct)))
+        self._comm = comm
 
     def close(self):
         if getattr(self, "_h", None):

@@ -233,6 +233,14 @@ int gather_cap(bj_ctx *ctx, const Shard &sh, const u64 *d_tree_local, size_t lea
 
 extern "C" {
 
+int bj_setup_set_comm(bj_setup *s, const bj_comm *comm) {
+    if (!s || !comm) return BJ_ERR_INVALID_ARG;
+    if (s->sh.world < 2 || comm->world != s->sh.world || comm->rank != s->sh.rank || (!comm->all_gather && !comm->all_gather_stream))
+        return BJ_ERR_INVALID_ARG;   // only the transport changes: the shard this setup holds is fixed
+    s->sh.comm = *comm;
+    return BJ_OK;
+}
+
 void bj_setup_destroy(bj_setup *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);

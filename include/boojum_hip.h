@@ -519,6 +519,21 @@ void bj_comm_rccl_destroy(bj_comm *comm);
 int bj_comm_rccl_stats(const bj_comm *comm, size_t *calls, size_t *bytes_received); /* collectives issued, bytes received */
 int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_sigmas, const uint64_t *h_constants,
                             const uint64_t *h_tables, const bj_proof_config *config, const bj_comm *comm, bj_setup **out);
+/* Replaces the transport of a sharded setup (a host that re-creates its communicator, or switches between its own callback and
+ * the in-library one): same rank and world as the setup was created with, nothing else changes.  Not while a proof runs. */
+int bj_setup_set_comm(bj_setup *s, const bj_comm *comm);
+/* Recorded-peer transport (measurement): rank `rank` of a `world`-rank proof runs ALONE on its GPU; the k-th
+ * all-gather is served by a device-to-device copy, on the proof's stream, of d_gathered[k] — the world * bytes that collective
+ * produced in a real run of the same proof (every rank of a sharded proof receives the same bytes; proofs of one witness are
+ * deterministic).  The first n_setup buffers are consumed once (the collectives of bj_setup_create_sharded), the next
+ * n_per_proof cyclically by every proof.  The prover cannot tell it from RCCL and the proof is bit for bit the single-GPU one;
+ * what it times is one rank's critical path — kernels, launches, host round trips — with the link time replaced by an HBM
+ * copy (bench.py --replay-world).  verify != 0: every contribution of this rank is compared with the slice the recording holds
+ * for it (synchronising; bj_comm_replay_stats counts the mismatches).  The buffers stay the caller's and must outlive the comm. */
+int bj_comm_replay_create(bj_ctx *ctx, unsigned rank, unsigned world, const void *const *d_gathered, const size_t *gathered_bytes,
+                          size_t n_setup, size_t n_per_proof, int verify, bj_comm *out);
+void bj_comm_replay_destroy(bj_comm *comm);
+int bj_comm_replay_stats(const bj_comm *comm, size_t *calls, size_t *bytes_received, size_t *mismatches);
 /* bj_prove / bj_prove_dev on a sharded setup are collective: every rank calls them with the same witness. */
 void bj_setup_destroy(bj_setup *s);
 int bj_setup_cap(const bj_setup *s, uint64_t *h_cap); /* vk.setup_merkle_tree_cap: cap_size*4 u64 */

@@ -166,3 +166,48 @@ def test_plain_bench_command_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(want), "--log-n", "14",
                         "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "refusing" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 11), (4, 12), (8, 12)])
+def test_one_rank_alone_with_recorded_peers(world, log_n):
+    """bench.py's scale_replay leg in small (era_boojum_amd/scale_replay.py): the `world` ranks of one proof as threads of this
+    process on the one GPU (binding.ThreadGroup) give the single-GPU proof while every gathered buffer is recorded; then every
+    rank runs ALONE behind the recorded-peer transport (bj_comm_replay_create, installed with bj_setup_set_comm): each of its
+    contributions equals the slice the recording holds for it, and its proof is again the single-GPU proof, byte for byte."""
+    from era_boojum_amd import scale_replay
+    c = S.sha_shaped_circuit(log_n, seed=23, table_bits=2)
+    single = E.ProverSetup(ctx(), c, 8, 16, 30)
+    ref, _ = single.prove()
+    single.close()
+    got = scale_replay.measure(c, world, 8, 16, 30, steps=2, warmup=1, reference_proof=ref)
+    assert got["world"] == world and sorted(got["ranks"]) == list(range(world))
+    assert got["collectives_per_proof"] >= 5 and got["mb_gathered_per_proof"] > 0
+    assert all(v["ms_per_step"] > 0 and "fri" in v["stages_ms"] for v in got["ranks"].values())
+    assert got["max_ms"] == got["ranks"][got["slowest_rank"]]["ms_per_step"] >= got["min_ms"]
+
+
+def test_replay_transport_refuses_what_was_not_recorded():
+    """The recorded-peer transport answers only the collectives it holds: another size is an error of the proof, not a wrong
+    answer; a sharded setup takes another transport only for its own rank and world."""
+    import ctypes as C
+    from gpu_util import DevBuf
+    blob = DevBuf(np.arange(64, dtype=np.uint64))
+    rc = E.ReplayComm(ctx(), 1, 2, [(blob.ptr, 512)], verify=True)
+    src, dst = DevBuf(np.arange(32, 64, dtype=np.uint64)), DevBuf(nelems=64)
+    assert rc.struct.all_gather(rc.struct.user, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), 256) == 0
+    assert np.array_equal(dst.get(), np.arange(64, dtype=np.uint64)) and rc.stats() == (1, 512, 0)
+    other = DevBuf(np.zeros(32, dtype=np.uint64))        # not what rank 1 contributed in the recording
+    assert rc.struct.all_gather(rc.struct.user, C.c_void_p(other.ptr), C.c_void_p(dst.ptr), 256) == 0
+    assert rc.stats() == (2, 1024, 1)
+    assert rc.struct.all_gather(rc.struct.user, C.c_void_p(src.ptr), C.c_void_p(dst.ptr), 128) != 0      # a size nobody recorded
+    with pytest.raises(E.BoojumHipError):
+        E.ReplayComm(ctx(), 2, 2, [(blob.ptr, 512)])
+    with pytest.raises(E.BoojumHipError):
+        E.ReplayComm(ctx(), 0, 2, [(blob.ptr, 511)])
+    single = E.ProverSetup(ctx(), S.sha_shaped_circuit(8, seed=1, table_bits=2), 8, 16, 20)
+    with pytest.raises(E.BoojumHipError):
+        single.set_comm(rc)                                # not a sharded setup
+    single.close()
+    rc.close()
+    for d in (blob, src, dst, other):
+        d.free()
