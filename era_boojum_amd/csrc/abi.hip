@@ -135,11 +135,12 @@ int probe_begin(bj_ctx *ctx, const char *name, double algorithmic_bytes) {
     if (!p.ev[1] && hipEventCreate(&p.ev[1]) != hipSuccess) return -1;
     p.name = name;
     p.bytes = algorithmic_bytes;
+    p.closed = false;
     if (hipEventRecord(p.ev[0], ctx->stream) != hipSuccess) return -1;
     return (int)ctx->probe_n++;
 }
 void probe_end(bj_ctx *ctx, int idx) {
-    if (idx >= 0) (void)hipEventRecord(ctx->probes[idx].ev[1], ctx->stream);
+    if (idx >= 0) ctx->probes[idx].closed = hipEventRecord(ctx->probes[idx].ev[1], ctx->stream) == hipSuccess;
 }
 
 namespace {

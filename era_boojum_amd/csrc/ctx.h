@@ -51,6 +51,7 @@ struct bj_ctx {
         const char *name = nullptr;
         double bytes = 0;
         hipEvent_t ev[2] = {nullptr, nullptr};
+        bool closed = false;      // the closing event was recorded in THIS proof (an unclosed probe still holds the previous proof's)
     } probes[BJ_MAX_KERNEL_PROBES];
     unsigned probe_n = 0;
 };

@@ -311,12 +311,11 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: world must divide fri_lde_factor and cap_size, and "
                                                      "quotient_degree must not exceed fri_lde_factor");
         const unsigned cl = cfg->fri_lde_factor / W;
-        if (cl < c->quotient_degree && c->quotient_degree % cl)
-            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: cosets per rank must divide the quotient degree");
         if ((((size_t)1 << c->log_n) * cl) < cfg->cap_size / W)
             return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: shard smaller than its cap fragment");
-        if ((((size_t)c->quotient_degree << c->log_n) / W) < 2)   // every rank evaluates q n / W points of the quotient
-            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: fewer than two quotient points per rank");
+        const size_t Qe_rank = ((size_t)c->quotient_degree << c->log_n) / W;   // every rank evaluates q n / W points of the quotient
+        if (Qe_rank < 2 || !bj::is_pow2(Qe_rank))                              // and inverse-transforms them: a power of two
+            return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_setup_create_sharded: q n / world = %zu quotient points per rank (a power of two >= 2 is needed)", Qe_rank);
     }
     bj_setup *s = new bj_setup();
     s->device = ctx->device;
@@ -1348,6 +1347,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         proof->comm_bytes = ctx->comm_bytes;
         for (unsigned i = 0; i < ctx->probe_n; i++) {
             float e = 0;
+            if (!ctx->probes[i].closed) continue;   // its closing record failed: the event still belongs to an earlier proof
             if (hipEventElapsedTime(&e, ctx->probes[i].ev[0], ctx->probes[i].ev[1]) != hipSuccess) continue;
             proof->kernel_stats[proof->n_kernel_stats++] = {ctx->probes[i].name, e, ctx->probes[i].bytes};
         }

@@ -493,7 +493,9 @@ int bj_setup_create(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_si
  * z from the rank's own first coset) is replicated, so every rank ends with the same transcript state and the SAME proof,
  * bit for bit the one a single GPU produces.  The all-gather is the library's own (bj_comm_rccl_create below: ncclAllGather
  * of RCCL on the proof's stream, librccl dlopen'ed) or one the host hands in through bj_comm (era_boojum_amd/binding.py wraps
- * torch.distributed that way: gloo in the tests).  Requirements: world | fri_lde_factor, world | cap_size, quotient_degree <= fri_lde_factor. */
+ * torch.distributed that way: gloo in the tests).  Requirements: world a power of two <= 8 (one node: the W x W residue
+ * combination of the quotient keeps its inverse Vandermonde matrix, W^2 <= 64 words, in kernel arguments), world | fri_lde_factor,
+ * world | cap_size, quotient_degree <= fri_lde_factor. */
 typedef struct bj_comm {
     unsigned rank, world;
     /* every rank contributes `bytes` at d_send; on return d_recv holds world*bytes, rank-major.  Called with the

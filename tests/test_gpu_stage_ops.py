@@ -78,7 +78,7 @@ def _lookup_vars(c):
 @pytest.mark.parametrize("log_n,kw", [(8, {}), (12, {}), (10, dict(num_gp_vars=24, lookup_width=3, lookup_reps=4, num_public_inputs=0)),
                                       (9, dict(num_gp_vars=20, lookup_width=4, lookup_reps=1, num_public_inputs=0)),
                                       (11, dict(table_id_as_variable=True)),
-                                      (9, dict(num_gp_vars=20, lookup_width=2, lookup_reps=11, num_public_inputs=0, table_id_as_variable=True))])
+                                      (9, dict(num_gp_vars=20, lookup_width=3, lookup_reps=11, num_public_inputs=0, table_id_as_variable=True))])
 def test_lookup_polynomials(log_n, kw):
     c = _circuit(log_n, **kw)
     n, reps, w = c.n, c.lookup_reps, c.lookup_width
