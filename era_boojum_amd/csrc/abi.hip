@@ -163,6 +163,8 @@ void load_env() {
     e.gate_no_jit = set("BJ_GATE_NO_JIT");
     e.gates_windowed = str("BJ_GATES_WINDOWED").rfind("0", 0) != 0;
     e.prove_no_absorb = set("BJ_PROVE_NO_ABSORB");
+    e.prove_uniform_groups = set("BJ_PROVE_UNIFORM_GROUPS");
+    e.copy_perm_wide_k = set("BJ_COPY_PERM_WIDE_K");
     if (set("BJ_PROVE_H2D_GROUP")) {
         const unsigned v = (unsigned)strtoul(getenv("BJ_PROVE_H2D_GROUP"), nullptr, 10);
         e.prove_h2d_group = v ? v : 8u;

@@ -250,6 +250,17 @@ __host__ __device__ __forceinline__ u64 mul7_weak(u64 a) {
     return s < t ? s + EPS : s;                        // wrapped: s < 2^35 now, the second EPS cannot wrap
 }
 
+// any u64 times a 32-bit integer -> weak residue: two 32 x 32 products, the (at most 32) bits above 2^64 folded back with one
+// multiply-add by 2^64 mod p — 3 multiply-adds and a conditional correction instead of the 15 instructions of mul_weak.  For the
+// copy-permutation non-residues k_c (small integers: 1, 7, 11, 13, ... by make_non_residues, utils.rs:636-688).
+__host__ __device__ __forceinline__ u64 mul_u32_weak(u64 a, u32 k) {
+    const u64 lo = (u64)lo32(a) * k;
+    const u64 hi = (u64)hi32(a) * k + hi32(lo);        // k a = lo32(lo) + hi * 2^32,  hi <= (2^32 - 1)^2 + 2^32 - 1 < 2^64
+    const u64 t = (u64)hi32(hi) * EPS;                 // the bits above 2^64, times 2^64 mod p;  t <= (2^32 - 1)^2
+    const u64 s = pack(lo32(lo), lo32(hi)) + t;
+    return s < t ? s + EPS : s;                        // wrapped: s < t <= 2^64 - 2^33 + 1, so s + EPS < 2^64: no second wrap
+}
+
 }  // namespace gl
 #include "gl_asm.inc"   // generated: butterfly2_weak_asm, addsub2_weak_asm (tools/gen_gl_asm.py)
 namespace gl {

@@ -22,6 +22,8 @@ struct EnvConfig {
     bool gate_no_aot = false, gate_no_fuse = false, gate_no_jit = false;
     bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
     bool prove_no_absorb = false;
+    bool copy_perm_wide_k = false;       // BJ_COPY_PERM_WIDE_K: quotient_copy_perm with 64-bit non-residue products even when they fit 32 bits (A/B, tests)
+    bool prove_uniform_groups = false;   // BJ_PROVE_UNIFORM_GROUPS: bj_prove's round-4 plan (equal groups, one absorption per eight columns)
     unsigned prove_h2d_group = 8;
     size_t nodes_lanepar_max = 16384;
     std::string jit_cache_dir, rccl_lib;

@@ -39,6 +39,27 @@ struct R16Args {
 static constexpr u32 TILE = 4096;
 static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
 
+// A/B builds for the question "what is the parked time of these passes waiting for" (tools/ntt_wait_ab.sh; results are WRONG
+// transforms, only their duration means something; never defined in the product build):
+//   -DBJ_R16_AB_NOLOAD     the 16 input words of a lane come from a register expression instead of HBM
+//   -DBJ_R16_AB_NOSTORE    the HBM stores sit behind a wave-uniform condition that is never true
+//   -DBJ_R16_AB_NOBARRIER  no workgroup barrier around the LDS transposes
+#ifdef BJ_R16_AB_NOLOAD
+#define BJ_R16_LD(base, off, salt) ((u64)(off) * 0x9E3779B97F4A7C15ull + (u64)(salt))
+#else
+#define BJ_R16_LD(base, off, salt) ld_off(base, off)
+#endif
+#ifdef BJ_R16_AB_NOSTORE
+#define BJ_R16_ST_GUARD(a) if ((a).n_cols == 0xFFFFFFFFu)
+#else
+#define BJ_R16_ST_GUARD(a)
+#endif
+#ifdef BJ_R16_AB_NOBARRIER
+#define BJ_R16_SYNC()
+#else
+#define BJ_R16_SYNC() __syncthreads()
+#endif
+
 __device__ __forceinline__ u32 pad(u32 l) { return l + (l >> 4); }
 // wave-uniform base pointer + 32-bit per-lane BYTE offset: the shape the compiler turns into `global_load v, v_off, s[base]`
 // (the empty asm pins the base in an SGPR pair: without it the optimiser re-associates base + offset into sixteen hoisted
@@ -148,28 +169,28 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + (size_t)b * TILE;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = ld_off(src + j * 256, t * 8u);
+        for (int j = 0; j < 16; j++) x[j] = BJ_R16_LD(src + j * 256, t * 8u, j + col);
         radix16<false, 12 - ROUNDS>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
-        __syncthreads();
+        BJ_R16_SYNC();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(ta * 256 + j * 16 + tc)];
-        __syncthreads();
+        BJ_R16_SYNC();
         radix16_lds<false>(x, lds_twB + ta * 16);   // step B: bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(ta * 256 + j * 16 + tc)] = x[j];
-        __syncthreads();
+        BJ_R16_SYNC();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(t * 16 + j)];
-        __syncthreads();
+        BJ_R16_SYNC();
         radix16<false>(x, twC);   // step C: bits 3..0
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(t * 16 + j)] = gl::canon(x[j]);   // the transform's output: canonical residues
-        __syncthreads();
+        BJ_R16_SYNC();
 #pragma unroll
-        for (int j = 0; j < 16; j++) st_off(dst + j * 256, t * 8u, lds[pad(j * 256 + t)]);
-        __syncthreads();
+        for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD(a) st_off(dst + j * 256, t * 8u, lds[pad(j * 256 + t)]);
+        BJ_R16_SYNC();
     }
 }
 
@@ -214,17 +235,17 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
         u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + tile_base;
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = ld_off(src + ((size_t)(j * 16) << rem_log), off_ld);
+        for (int j = 0; j < 16; j++) x[j] = BJ_R16_LD(src + ((size_t)(j * 16) << rem_log), off_ld, j + col);
         radix16_lds<UNIT_FIRST>(x, lds_tw);    // mid bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
-        __syncthreads();
+        BJ_R16_SYNC();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(tm * 256 + j * 16 + tl)];
-        __syncthreads();
+        BJ_R16_SYNC();
         radix16_lds<false>(x, lds_tw2 + tm * 16);   // mid bits 3..0
 #pragma unroll
-        for (int j = 0; j < 16; j++) st_off(dst + ((size_t)j << rem_log), off_st, x[j]);
+        for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD(a) st_off(dst + ((size_t)j << rem_log), off_st, x[j]);
     }
 }
 

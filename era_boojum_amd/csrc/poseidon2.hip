@@ -276,11 +276,12 @@ poseidon2_leaves_kernel(const u64 *base, size_t col_stride, const u64 *const *co
     d[1] = make_ulonglong2(gl::canon(s[2]), gl::canon(s[3]));
 }
 
-// ONE absorption of the same sponge, for leaves whose columns arrive in groups of eight (bj_prove: the witness comes over
-// PCIe while the first groups are already being extended and hashed): state[0..8] <- the group's elements (zero-padded in
-// the last group), state[8..12] <- what the previous group left in `capacity` ([4][num_leaves], zeros before the first
-// group), permute; the last group writes the digest, the others their capacity words.  Group by group this is exactly
-// poseidon2_leaves_kernel's loop (sponge.rs:224-346: overwrite mode, no length tag).
+// A RUN of absorptions of the same sponge, for leaves whose columns arrive in groups (bj_prove: the witness comes over PCIe
+// while the first groups are already being extended and hashed): state[8..12] <- what the previous group left in `capacity`
+// ([4][num_leaves], zeros before the first group); then, eight columns at a time, state[0..8] <- the group's next elements
+// (zero-padded in the last block of the last group), permute — every group but the last holds a multiple of eight columns;
+// the last group writes the digest, the others their capacity words.  Group by group this is exactly poseidon2_leaves_kernel's
+// loop (sponge.rs:224-346: overwrite mode, no length tag), with ONE call site of the permutation as there.
 __global__ void __launch_bounds__(256)
 poseidon2_leaves_absorb_kernel(const u64 *base, size_t col_stride, unsigned n_cols, size_t num_leaves, u64 *capacity,
                                u64 *digests, int first, int last) {
@@ -288,10 +289,12 @@ poseidon2_leaves_absorb_kernel(const u64 *base, size_t col_stride, unsigned n_co
     if (I >= num_leaves) return;
     u64 s[12];
 #pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = (unsigned)k < n_cols ? base[(size_t)k * col_stride + I] : 0;
-#pragma unroll
     for (int k = 0; k < 4; k++) s[8 + k] = first ? 0 : capacity[(size_t)k * num_leaves + I];
-    poseidon2_permutation(s);
+    for (unsigned c = 0; c < n_cols; c += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = c + k < n_cols ? base[(size_t)(c + k) * col_stride + I] : 0;
+        poseidon2_permutation(s);
+    }
     if (last) {
         ulonglong2 *d = reinterpret_cast<ulonglong2 *>(digests + 4 * I);
         d[0] = make_ulonglong2(gl::canon(s[0]), gl::canon(s[1]));

@@ -40,7 +40,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
                                unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
                                const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, const u64 *d_inv_xm1, u64 *d_out0,
-                               u64 *d_out1, hipStream_t s);
+                               u64 *d_out1, hipStream_t s, bool small_non_residues);
 void launch_inv_x_minus_one(const u64 *d_tw_fwd, size_t Q, size_t I0, u64 *d_out, hipStream_t s);
 bool launch_combine_residues(const u64 *d_residues, unsigned W, size_t E, unsigned n_cols, const u64 *h_a, u64 *d_out, hipStream_t s);
 void launch_gather_rows(const u64 *d_base, size_t col_stride, unsigned n_cols, const u64 *d_idx, unsigned n_idx,
@@ -86,6 +86,7 @@ struct bj_setup {
     std::vector<SpecGate> spec;
     unsigned n_spec_terms = 0;
     std::vector<u64> non_residues;
+    bool small_non_residues = false;   // every k_c < 2^32 (canonical): quotient_copy_perm multiplies by them as 32-bit integers
     std::vector<unsigned> pub_cols, pub_rows;
     // proof config
     unsigned fri_lde = 0, cap_size = 0, security = 0, pow_bits = 0, transcript = BJ_TRANSCRIPT_POSEIDON2, hasher = BJ_HASHER_POSEIDON2;
@@ -458,6 +459,8 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
         }
     }
     s->non_residues.assign(c->non_residues, c->non_residues + c->num_vars);
+    s->small_non_residues = true;
+    for (u64 k : s->non_residues) s->small_non_residues = s->small_non_residues && gl::canon(k) < ((u64)1 << 32);
     for (unsigned i = 0; i < c->num_public_inputs; i++) {
         s->pub_cols.push_back(c->public_input_cols[i]);
         s->pub_rows.push_back(c->public_input_rows[i]);
@@ -709,7 +712,40 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         if ((nW + G - 1) / G > 64) G = (nW + 63) / 64;
         const bool absorb = ctx->hasher == BJ_HASHER_POSEIDON2 && !bj::env().prove_no_absorb;
         if (absorb) G = (G + 7) / 8 * 8;
-        const unsigned n_groups = (nW + G - 1) / G;
+        // The plan: transfer / transform groups [c0, c1) with one event each, and after some of them one absorption run over the
+        // columns extended since the last one.  Nothing can be hashed before the first G columns have crossed PCIe, so those go in
+        // quarters (the transforms of a quarter run under the transfer of the next) and are absorbed together; from then on the
+        // transfer (PCIe, ~5 ms per 8 columns of 2^22 rows) runs ahead of the hashing (~10 ms), so the groups widen to 2 G and
+        // 3 G: fewer round trips of the 32-byte capacity per leaf and fewer launch tails.
+        struct Grp {
+            unsigned c0, c1, absorb_from;   // absorb_from == ~0u: no absorption after this group
+        };
+        std::vector<Grp> plan;
+        const unsigned NONE = ~0u;
+        for (;;) {
+            plan.clear();
+            if (!absorb || bj::env().prove_uniform_groups) {
+                for (unsigned c0 = 0; c0 < nW; c0 += G) plan.push_back({c0, c0 + G < nW ? c0 + G : nW, absorb ? c0 : NONE});
+            } else {
+                const unsigned q = G / 4;   // G is a multiple of 8
+                unsigned pos = 0;
+                for (unsigned k = 0; k < 4 && pos < nW; k++) {
+                    const unsigned c1 = pos + q < nW ? pos + q : nW;
+                    plan.push_back({pos, c1, (k == 3 || c1 == nW) ? 0u : NONE});
+                    pos = c1;
+                }
+                const unsigned widths[6] = {1, 2, 2, 3, 3, 3};
+                for (unsigned k = 0; pos < nW; k++) {
+                    const unsigned w = G * widths[k < 6 ? k : 5];
+                    const unsigned c1 = pos + w < nW ? pos + w : nW;
+                    plan.push_back({pos, c1, pos});
+                    pos = c1;
+                }
+            }
+            if (plan.size() <= 64) break;
+            G = absorb ? G + 8 : G + 1;
+        }
+        const unsigned n_groups = (unsigned)plan.size();
         ArenaBuf capacity;
         if (absorb) {
             if ((rc = wit_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
@@ -718,7 +754,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         }
         for (unsigned g = 0; g < n_groups; g++) {
             if (!ctx->copy_ev[g]) BJ_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[g], hipEventDisableTiming));
-            const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
+            const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
             const unsigned v1 = c1 < VW ? c1 : VW;         // variable / witness columns of this group: [c0, v1)
             if (c0 < v1)
                 BJ_HIP(ctx, hipMemcpyAsync(const_cast<uint64_t *>(d_variables) + (size_t)c0 * n, hw->h_variables + (size_t)c0 * n,
@@ -730,7 +766,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         }
         if (absorb) BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
         for (unsigned g = 0; g < n_groups && !rc; g++) {
-            const unsigned c0 = g * G, c1 = c0 + G < nW ? c0 + G : nW;
+            const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
             const unsigned v1 = c1 < VW ? c1 : VW;
             BJ_HIP(ctx, hipStreamWaitEvent(st, ctx->copy_ev[g], 0));
             if (c0 < v1) rc = bj_intt_batch(ctx, d_variables + (size_t)c0 * n, mono.p + (size_t)c0 * n, log_n, v1 - c0, n, 1);
@@ -738,9 +774,10 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             if (!rc)
                 rc = bj::lde_cosets_strided(ctx, mono.p + (size_t)c0 * n, n, wit_lde.p + (size_t)c0 * Ln, Ln, log_n, c1 - c0, S->log_L,
                                             S->c0, S->cl);
-            for (unsigned c = c0; absorb && !rc && c < c1; c += 8)
-                bj::launch_poseidon2_leaves_absorb(wit_lde.p + (size_t)c * Ln, Ln, c1 - c < 8 ? c1 - c : 8, N, capacity.p, wit_tree.p,
-                                                   c == 0, c + 8 >= nW, st);
+            if (absorb && !rc && plan[g].absorb_from != NONE) {
+                const unsigned a0 = plan[g].absorb_from;
+                bj::launch_poseidon2_leaves_absorb(wit_lde.p + (size_t)a0 * Ln, Ln, c1 - a0, N, capacity.p, wit_tree.p, a0 == 0, c1 == nW, st);
+            }
         }
         if (absorb) BJ_HIP(ctx, hipEventRecord(ctx->ev1, st));
     }
@@ -870,7 +907,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         // variables + sigmas + z and the partial products + 1/(x - 1), accumulators read and written
         const int pc = bj::probe_begin(ctx, "quotient_copy_perm", 8.0 * (2.0 * V + 2 + 2 * n_part + 1) * (double)Qe + 32.0 * (double)Qe);
         bj::launch_quotient_copy_perm(wit_lde.p, Ln, d_sig_lde, Ln, s2_lde.p, Ln, S->d_non_res, V, q, log_n, S->log_L, ctx->tw_fwd,
-                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_spec_terms + n_gate_terms), a_l1 + 2, Qe, I0, S->d_inv_xm1, t0, t1, st);
+                                      beta, gamma, alphas.data() + 2 * (n_lookup_terms + n_spec_terms + n_gate_terms), a_l1 + 2, Qe, I0, S->d_inv_xm1, t0, t1, st,
+                                      S->small_non_residues);
         bj::probe_end(ctx, pc);
     }
     BJ_CHECK_LAUNCH(ctx);

@@ -309,6 +309,10 @@ struct CopyPermQArgs {
     u64 xn_minus_one[64];        // per coset: x^n - 1
     u64 vanishing_inv[64];       // per coset: 1 / (x^n - 1)
 };
+// SMALLK: every non-residue fits 32 bits (always the case for make_non_residues' output; the launcher checks) — the numerator's
+// k_c * (x * beta) is then a 32 x 64-bit product per component on top of ONE x * beta per point, instead of two 64 x 64 products
+// per column against k_c * beta staged in LDS
+template <bool SMALLK>
 __global__ void __launch_bounds__(256)
 quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas, size_t sig_stride, const u64 *stage2,
                           size_t s2_stride, const u64 *non_res, unsigned V, unsigned chunk, unsigned n_chunks,
@@ -316,9 +320,13 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
                           size_t Q, size_t I0 /* global index of local point 0 (multi-GPU coset shards) */,
                           const u64 *inv_xm1 /* 1 / (x_I - 1) per local point, or NULL: computed here */, u64 *out0, u64 *out1) {
     // k_c * beta for every column, once per workgroup (a lane would otherwise spend a product per column on k_c * x first)
-    extern __shared__ u64 kbeta[];   // [V][2], sized by the launcher
-    for (unsigned t = threadIdx.x; t < 2 * V; t += blockDim.x)
-        kbeta[t] = gl::mul(non_res[t >> 1], (t & 1) ? ca.beta.c1 : ca.beta.c0);
+    extern __shared__ u64 kbeta[];   // [V][2], sized by the launcher (SMALLK: [V] words holding k_c)
+    if (SMALLK) {
+        for (unsigned t = threadIdx.x; t < V; t += blockDim.x) kbeta[t] = gl::canon(non_res[t]);
+    } else {
+        for (unsigned t = threadIdx.x; t < 2 * V; t += blockDim.x)
+            kbeta[t] = gl::mul(non_res[t >> 1], (t & 1) ? ca.beta.c1 : ca.beta.c0);
+    }
     __syncthreads();
     const size_t I = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= Q) return;
@@ -326,6 +334,7 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
     const unsigned coset = (unsigned)((I0 + I) >> log_n);   // global coset: selects x^n and the vanishing inverse
     const u32 i_br = (u32)(I & (n - 1));
     const u64 x = lde_point(tw, I0 + I);
+    const gl::e2 xb = SMALLK ? gl::e2{gl::mul_weak(x, ca.beta.c0), gl::mul_weak(x, ca.beta.c1)} : gl::e2{0, 0};   // x * beta, once per point
     Acc160q s0, s1;
     s0.clear();
     s1.clear();
@@ -353,7 +362,13 @@ quotient_copy_perm_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
             const u64 sg = sigmas[(size_t)c * sig_stride + I];
             const gl::e2 d{gl::add_weak(gl::mul_weak(sg, ca.beta.c0), wg), gl::add_weak(gl::mul_weak(sg, ca.beta.c1), ca.gamma.c1)};
             lhs = gl::e2_mul_weak(lhs, d);
-            const gl::e2 nm{gl::add_weak(gl::mul_weak(x, kbeta[2 * c]), wg), gl::add_weak(gl::mul_weak(x, kbeta[2 * c + 1]), ca.gamma.c1)};
+            gl::e2 nm;
+            if (SMALLK) {
+                const u32 k = (u32)kbeta[c];
+                nm = {gl::add_weak(gl::mul_u32_weak(xb.c0, k), wg), gl::add_weak(gl::mul_u32_weak(xb.c1, k), ca.gamma.c1)};
+            } else {
+                nm = {gl::add_weak(gl::mul_weak(x, kbeta[2 * c]), wg), gl::add_weak(gl::mul_weak(x, kbeta[2 * c + 1]), ca.gamma.c1)};
+            }
             rhs = gl::e2_mul_weak(rhs, nm);
         }
         const gl::e2 t{gl::sub_weak(lhs.c0, rhs.c0), gl::sub_weak(lhs.c1, rhs.c1)};
@@ -505,7 +520,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
                                unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
                                const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, const u64 *d_inv_xm1, u64 *d_out0,
-                               u64 *d_out1, hipStream_t s) {
+                               u64 *d_out1, hipStream_t s, bool small_non_residues) {
     const size_t n = (size_t)1 << log_n, Q = Q_local;
     const unsigned L = 1u << log_L;   // cosets of the whole LDE domain; a GPU may hold any contiguous range of them
     CopyPermQArgs ca;
@@ -526,9 +541,14 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
         }
     }
     const unsigned n_chunks = (V + chunk - 1) / chunk;
-    hipLaunchKernelGGL(quotient_copy_perm_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 16, s, d_vars, var_stride,
-                       d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
-                       d_alphas_cp, Q, I0, d_inv_xm1, d_out0, d_out1);
+    if (small_non_residues && !env().copy_perm_wide_k)
+        hipLaunchKernelGGL(quotient_copy_perm_kernel<true>, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 8, s, d_vars, var_stride,
+                           d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
+                           d_alphas_cp, Q, I0, d_inv_xm1, d_out0, d_out1);
+    else
+        hipLaunchKernelGGL(quotient_copy_perm_kernel<false>, dim3((unsigned)((Q + 255) / 256)), dim3(256), (size_t)V * 16, s, d_vars, var_stride,
+                           d_sigmas, sig_stride, d_stage2, s2_stride, d_non_res, V, chunk, n_chunks, log_n, d_tw_fwd, ca,
+                           d_alphas_cp, Q, I0, d_inv_xm1, d_out0, d_out1);
 }
 
 // ----------------------------------------------------------------------------------------------- query gathers

@@ -26,7 +26,7 @@ void launch_quotient_copy_perm(const u64 *d_vars, size_t var_stride, const u64 *
                                const u64 *d_stage2, size_t s2_stride, const u64 *d_non_res, unsigned V, unsigned chunk,
                                unsigned log_n, unsigned log_L, const u64 *d_tw_fwd, const u64 *beta, const u64 *gamma,
                                const u64 *alpha_l1, const u64 *d_alphas_cp, size_t Q_local, size_t I0, const u64 *d_inv_xm1, u64 *d_out0,
-                               u64 *d_out1, hipStream_t s);
+                               u64 *d_out1, hipStream_t s, bool small_non_residues);
 }  // namespace bj
 
 namespace {
@@ -179,9 +179,11 @@ int bj_quotient_copy_perm(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride
     if (int rc = al.alloc(16 * ((size_t)n_chunks + 1))) return rc;
     if (int rc = bj::h2d_async(ctx, nr.p, h_non_residues, 8 * (size_t)num_vars)) return rc;
     if (int rc = bj::h2d_async(ctx, al.p, h_alphas + 2, 16 * (size_t)n_chunks)) return rc;
+    bool small_k = true;
+    for (unsigned c = 0; c < num_vars; c++) small_k = small_k && gl::canon(h_non_residues[c]) < ((u64)1 << 32);
     bj::launch_quotient_copy_perm(d_vars, var_stride, d_sigmas, sig_stride, d_stage2, stage2_stride, (const u64 *)nr.p, num_vars,
                                   chunk, log_n, log_lde, ctx->tw_fwd, h_beta, h_gamma, h_alphas, (const u64 *)al.p, num_points,
-                                  first_point, nullptr, d_out0, d_out1, ctx->stream);
+                                  first_point, nullptr, d_out0, d_out1, ctx->stream, small_k);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

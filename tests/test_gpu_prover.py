@@ -398,3 +398,34 @@ def test_two_contexts_on_two_host_threads_prove_concurrently():
     for c in ctxs:
         c.release_workspace()
         c.close()
+
+
+def test_host_witness_group_plans_and_non_residue_paths_give_the_same_proof():
+    """bj_prove takes the witness over PCIe in groups and hashes it group by group (prover.hip: quarters of the first eight
+    columns, then 8, 16, 16, 24, ... columns per absorption run); bj_prove_dev hashes the resident witness in one kernel.  Every
+    plan — the default one, the round-4 uniform one, other group widths, no group-wise absorption — and both forms of the
+    copy-permutation numerator (32-bit non-residue multipliers, the default for make_non_residues' output, and 64-bit products)
+    must give the bytes of the resident path, for the bench geometry (93 leaf columns) and for a 156-column witness oracle."""
+    import os
+    lib = E.load_library()
+    for c in (S.sha_shaped_circuit(11, seed=77, table_bits=2), S.recursion_like_circuit(10, seed=7)):
+        setup = E.ProverSetup(ctx(), c, 8, 16, 30)
+        d_vars, d_mult = ctx().upload(c.variables), ctx().upload(c.multiplicities)
+        ref, _ = setup.prove_dev(d_vars, d_mult)
+        for env in ({}, {"BJ_PROVE_UNIFORM_GROUPS": "1"}, {"BJ_PROVE_H2D_GROUP": "16"}, {"BJ_PROVE_H2D_GROUP": "3"}, {"BJ_PROVE_NO_ABSORB": "1"},
+                    {"BJ_COPY_PERM_WIDE_K": "1"}):
+            os.environ.update(env)
+            try:
+                lib.bj_env_reload()
+                got, _ = setup.prove()
+                if "BJ_COPY_PERM_WIDE_K" in env:
+                    dev, _ = setup.prove_dev(d_vars, d_mult)
+                    assert np.array_equal(dev, ref), env
+            finally:
+                for k in env:
+                    del os.environ[k]
+                lib.bj_env_reload()
+            assert np.array_equal(got, ref), env
+        setup.close()
+        ctx().free(d_vars)
+        ctx().free(d_mult)
