@@ -54,16 +54,75 @@ static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
 #else
 #define BJ_R16_ST_GUARD(a)
 #endif
+// Software pipeline over the columns of a workgroup (round 5, build switches): the loads of column c + 1 are issued before the stores
+// of column c and the barriers stop draining vmcnt (the ISA then waits with vmcnt(22..16) at the top of a column: the sixteen stores
+// stay in flight).  Measured on MI355X (profiles/r05_ntt_wait_ab.txt): parked wave-cycles of ntt_local12 24.4 % -> 20.7 %, issue-stall
+// cycles up by the same amount, duration 1.410 -> 1.415 ms at equal clocks (1.362 ms in the one run where the part held 1.89 GHz);
+// ntt_strided8 0.924 -> 0.959 ms (sixteen more register pairs: 125 -> 157 VGPRs, four resident waves per SIMD become three).  The
+// passes are not short of latency cover: they run at the power limit (1.77-1.80 GHz against 2.3 GHz for the hash kernels; without
+// their loads or their stores the SAME instruction stream runs at 1.93 / 2.18 GHz and 7-8 % fewer cycles).  Both default to off.
+#ifndef BJ_R16_PREFETCH_LOCAL
+#define BJ_R16_PREFETCH_LOCAL 0
+#endif
+#ifndef BJ_R16_PREFETCH_STRIDED
+#define BJ_R16_PREFETCH_STRIDED 0
+#endif
+#ifndef BJ_R16_WIDE_ST
+#define BJ_R16_WIDE_ST 0   // 1: ntt_local12 stores 16 bytes per lane (two adjacent words out of LDS) — half the store instructions
+#endif
+// Workgroup barrier that orders LDS traffic only (for the pipelined pass).  __syncthreads() is a workgroup-scope fence: it drains
+// vmcnt too, i.e. waits for every global store of the wave to be acknowledged and for the loads that were issued ahead for the NEXT
+// column — the two things the pipeline keeps in flight across the transposes.  All data exchanged between the lanes of a workgroup
+// here goes through LDS, so this wave's LDS operations being complete (lgkmcnt) before the barrier is all the ordering they need.
 #ifdef BJ_R16_AB_NOBARRIER
-#define BJ_R16_SYNC()
+#define BJ_R16_SYNC_FULL()
+#define BJ_R16_SYNC_LDS()
 #else
-#define BJ_R16_SYNC() __syncthreads()
+#define BJ_R16_SYNC_FULL() __syncthreads()
+#define BJ_R16_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+#if BJ_R16_PREFETCH_LOCAL
+#define BJ_R16_SYNC_L() BJ_R16_SYNC_LDS()
+#else
+#define BJ_R16_SYNC_L() BJ_R16_SYNC_FULL()
+#endif
+#if BJ_R16_PREFETCH_STRIDED
+#define BJ_R16_SYNC_S() BJ_R16_SYNC_LDS()
+#else
+#define BJ_R16_SYNC_S() BJ_R16_SYNC_FULL()
 #endif
 
 __device__ __forceinline__ u32 pad(u32 l) { return l + (l >> 4); }
 // wave-uniform base pointer + 32-bit per-lane BYTE offset: the shape the compiler turns into `global_load v, v_off, s[base]`
 // (the empty asm pins the base in an SGPR pair: without it the optimiser re-associates base + offset into sixteen hoisted
 // 64-bit per-lane addresses)
+// A wave-uniform GLOBAL pointer the optimiser has lost track of (computed under a branch it treats as divergent): back into an
+// SGPR pair, as an address-space-1 pointer — rebuilt from integers a generic pointer would turn the accesses into flat_load /
+// flat_store, which count on lgkmcnt as well and would make every LDS wait a wait for HBM.
+typedef const u64 __attribute__((address_space(1))) *gcptr;
+typedef u64 __attribute__((address_space(1))) *gptr;
+__device__ __forceinline__ gcptr uniform_gptr(const u64 *p) {
+    const u64 v = reinterpret_cast<u64>(p);
+    return (gcptr)gl::pack(__builtin_amdgcn_readfirstlane(gl::lo32(v)), __builtin_amdgcn_readfirstlane(gl::hi32(v)));
+}
+__device__ __forceinline__ u64 ld_off(gcptr base, u32 byte_off) {
+    asm volatile("" : "+s"(base));
+    return *(gcptr)((const char __attribute__((address_space(1))) *)base + byte_off);
+}
+__device__ __forceinline__ void st_off(gptr base, u32 byte_off, u64 v) {
+    asm volatile("" : "+s"(base));
+    *(gptr)((char __attribute__((address_space(1))) *)base + byte_off) = v;
+}
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef u64x2 __attribute__((address_space(1))) *gptr2;
+__device__ __forceinline__ void st_off2(gptr base, u32 byte_off, u64 v0, u64 v1) {   // byte_off a multiple of 16
+    asm volatile("" : "+s"(base));
+    u64x2 v;
+    v.x = v0;
+    v.y = v1;
+    *(gptr2)((char __attribute__((address_space(1))) *)base + byte_off) = v;
+}
 __device__ __forceinline__ u64 ld_off(const u64 *base, u32 byte_off) {
     asm volatile("" : "+s"(base));
     return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(base) + byte_off);
@@ -164,34 +223,61 @@ __global__ void __launch_bounds__(256, BJ_R16_WAVES) ntt_local12_kernel(R16Args 
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
     const u32 ta = t >> 4, tc = t & 15;
-    for (unsigned col = col0; col < col1; col++) {
-        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + (size_t)b * TILE;
-        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + (size_t)b * TILE;
-        u64 x[16];
+    // Software pipeline over the columns of this workgroup: VMEM returns in issue order and ONE counter (vmcnt) covers loads and
+    // stores, so a column's loads queued BEHIND the previous column's stores cannot be consumed before those stores have been
+    // acknowledged by the memory system (A/B builds: without the stores the pass is 23 % faster, without the loads 17 %,
+    // tools/ntt_wait_ab.sh).  Here the next column's 16 words are requested right after the data registers of the current one have
+    // gone to LDS for the last transpose, AHEAD of its stores: the wait at the top of the next iteration is vmcnt(16) — the stores
+    // stay in flight under the butterflies — and the load latency hides under the store phase.
+    auto request = [&](u64 (&v)[16], unsigned col) {
+        const gcptr src = uniform_gptr(a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + (size_t)b * TILE);
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = BJ_R16_LD(src + j * 256, t * 8u, j + col);
+        for (int j = 0; j < 16; j++) v[j] = BJ_R16_LD(src + j * 256, t * 8u, j + col);
+    };
+    // The first column is peeled off the loop: the register scoreboard of the compiler is merged at a loop header, and with the
+    // prologue's loads (nothing behind them) on one edge and the latch's loads (sixteen stores behind them) on the other it would
+    // wait for vmcnt(0) at the top of every iteration — stores included.  With the peeled copy both edges look alike.
+    u64 x[16];
+    auto column = [&](unsigned col) {
+        const gptr dst = (gptr)uniform_gptr(a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + (size_t)b * TILE);
+        if (!BJ_R16_PREFETCH_LOCAL) request(x, col);
         radix16<false, 12 - ROUNDS>(x, lds_tw);   // step A: bits 11..8 in registers, twiddles uniform (LDS broadcasts at the point of use)
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_L();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(ta * 256 + j * 16 + tc)];
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_L();
         radix16_lds<false>(x, lds_twB + ta * 16);   // step B: bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(ta * 256 + j * 16 + tc)] = x[j];
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_L();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(t * 16 + j)];
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_L();
         radix16<false>(x, twC);   // step C: bits 3..0
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(t * 16 + j)] = gl::canon(x[j]);   // the transform's output: canonical residues
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_L();
+        if (BJ_R16_PREFETCH_LOCAL && col + 1 < col1) request(x, col + 1);            // x is free: its values sit in LDS
+        if (BJ_R16_WIDE_ST) {   // lane t: words 2u, 2u + 1 (u = t & 127) of row 2k + (t >> 7): one 16-byte store, 1 KB per wave instruction
+            const u32 u2 = (t & 127u) * 2u, rh = t >> 7;
 #pragma unroll
-        for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD(a) st_off(dst + j * 256, t * 8u, lds[pad(j * 256 + t)]);
-        BJ_R16_SYNC();
-    }
+            for (int k = 0; k < 8; k++) {
+                const u32 l = (2u * k + rh) * 256u + u2;
+                BJ_R16_ST_GUARD(a) st_off2(dst, l * 8u, lds[pad(l)], lds[pad(l + 1)]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD(a) st_off(dst + j * 256, t * 8u, lds[pad(j * 256 + t)]);
+        }
+        BJ_R16_SYNC_L();
+    };
+    if (col0 >= col1) return;
+    if (BJ_R16_PREFETCH_LOCAL) request(x, col0);
+    column(col0);
+#pragma nounroll
+    for (unsigned col = col0 + 1; col < col1; col++) column(col);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -230,23 +316,43 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
     const u32 off_ld = ((tm << rem_log) + tl) * 8u, off_st = (((tm * 16) << rem_log) + tl) * 8u;   // bytes; a column is < 2^32 bytes
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
-    for (unsigned col = col0; col < col1; col++) {
-        const u64 *src = a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + tile_base;
-        u64 *dst = a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + tile_base;
-        u64 x[16];
+    // the same software pipeline as in ntt_local12_kernel: the next column's loads go out before this column's stores (here the
+    // stores leave from the data registers themselves, so the prefetched words take sixteen more register pairs: 121 -> ~153 VGPRs,
+    // still three waves per SIMD)
+    auto request = [&](u64 (&v)[16], unsigned col) {
+        const gcptr src = uniform_gptr(a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + tile_base);
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = BJ_R16_LD(src + ((size_t)(j * 16) << rem_log), off_ld, j + col);
+        for (int j = 0; j < 16; j++) v[j] = BJ_R16_LD(src + ((size_t)(j * 16) << rem_log), off_ld, j + col);
+    };
+    u64 x[16];
+    auto column = [&](unsigned col) {
+        const gptr dst = (gptr)uniform_gptr(a.out + (size_t)col * a.out_col_stride + (size_t)coset * n + tile_base);
+        if (!BJ_R16_PREFETCH_STRIDED) request(x, col);
         radix16_lds<UNIT_FIRST>(x, lds_tw);    // mid bits 7..4
 #pragma unroll
         for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_S();
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = lds[pad(tm * 256 + j * 16 + tl)];
-        BJ_R16_SYNC();
+        BJ_R16_SYNC_S();
+        // the next column's words are requested BEFORE the second step: they travel under its butterflies and are in the queue
+        // ahead of this column's stores (the copy nx -> x at the bottom then finds them there: vmcnt(16), the stores stay in flight)
+        u64 nx[16];
+        const bool more = BJ_R16_PREFETCH_STRIDED && col + 1 < col1;   // wave-uniform
+        if (more) request(nx, col + 1);
         radix16_lds<false>(x, lds_tw2 + tm * 16);   // mid bits 3..0
 #pragma unroll
         for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD(a) st_off(dst + ((size_t)j << rem_log), off_st, x[j]);
-    }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = nx[j];
+        }
+    };
+    if (col0 >= col1) return;
+    if (BJ_R16_PREFETCH_STRIDED) request(x, col0);
+    column(col0);          // peeled (see ntt_local12_kernel): both edges into the loop carry loads with sixteen stores behind them
+#pragma nounroll
+    for (unsigned col = col0 + 1; col < col1; col++) column(col);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -13,3 +13,15 @@ for v in PRODUCT NOLOAD NOSTORE NOBARRIER; do
   for i in 1 2; do echo "$v $(BOOJUM_HIP_LIB=$lib python tools/cfg2_ntt.py 2>/dev/null | tail -1)" >> $out; done
 done
 cat $out
+# the same builds under rocprofv3: kernel durations (kernel trace) and SQ_BUSY_CYCLES / 32 = shader cycles of a launch give the
+# clock the part sustains under each variant — whether the A/B gain is fewer cycles (a stall that went away) or a higher clock
+for v in NOLOAD NOSTORE; do
+  lib=$(pwd)/exp/libbj_$v.so; [ -f $lib ] || continue
+  BOOJUM_HIP_LIB=$lib tools/prof_cfg2.sh ${tag}_$v quick > /dev/null 2>&1
+  echo "== $v" >> $out; python3 -c "
+import json
+d=json.load(open('gpurun_out/cfg2_${tag}_${v}_summary.json'))
+for k,e in d['kernels'].items(): print(k[:40], {f: e.get(f) for f in ('avg_ms','kernel_cycles','implied_clock_GHz','cycles_per_valu_instruction_per_simd','SQ_INSTS_VALU')})
+" >> $out 2>&1
+done
+cat $out
