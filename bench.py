@@ -122,6 +122,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and "BJ_BENCH_TEST_DIE_RANK" in os.environ:
+        # tests/test_bench_launcher.py (runs without a GPU): one rank dies right after the rendezvous, the others are left in a
+        # collective — the launcher must notice and end the whole command with an error instead of hanging
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("gloo", rank=rank, world_size=world)
+        if os.environ["BJ_BENCH_TEST_DIE_RANK"] == str(rank):
+            os._exit(3)
+        tdist.barrier()
+        raise SystemExit("the rank that was told to die is still alive")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     backend = os.environ.get("BJ_BENCH_BACKEND", "nccl")     # "gloo": several ranks sharing one GPU (functional check only)
@@ -150,14 +160,40 @@ def main():
     sharded = world > 1 and args.mode != "replicas"
     seed = 42 if sharded else 42 + rank
     t_gen = time.perf_counter()
-    if args.circuit == "sha256" and log_n >= 14:
-        msg_len = SHA.message_len_for_log_n(log_n)
-        circuit = SHA.sha256_circuit(SHA.bench_message(msg_len, seed=seed))
-        assert circuit.log_n == log_n
-        circuit_name = "SHA-256 of %d random bytes (seed %d), synthesised like the reference bench (sha256/mod.rs:296-470)" % (msg_len, seed)
-    else:
-        circuit = S.sha_shaped_circuit(log_n, seed=seed, table_bits=table_bits)
-        circuit_name = "SHA-shaped satisfiable synthetic (seed %d)" % seed
+
+    def synthesise():
+        if args.circuit == "sha256" and log_n >= 14:
+            msg_len = SHA.message_len_for_log_n(log_n)
+            c = SHA.sha256_circuit(SHA.bench_message(msg_len, seed=seed))
+            assert c.log_n == log_n
+            return c, "SHA-256 of %d random bytes (seed %d), synthesised like the reference bench (sha256/mod.rs:296-470)" % (msg_len, seed)
+        return S.sha_shaped_circuit(log_n, seed=seed, table_bits=table_bits), "SHA-shaped satisfiable synthetic (seed %d)" % seed
+
+    circuit, circuit_name, circuit_from = None, None, "synthesised by this rank"
+    if sharded:
+        # every rank of a sharded proof needs the SAME circuit: rank 0 synthesises it once and leaves the big arrays in a directory
+        # of plain .npy files (tmpfs when there is one); the other ranks map them read-only — one copy of the ~7 GB in host memory
+        # and one synthesis instead of N of each.  Anything that goes wrong falls back to local synthesis.
+        cache = os.environ.get("BJ_BENCH_CIRCUIT_CACHE") or os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                                                                          "bj_bench_circuit_%s_%d_%d_%d" % (args.circuit, log_n, seed, os.getuid()))
+        ok = [False]
+        if rank == 0:
+            try:
+                circuit, circuit_name = synthesise()
+                S.save_circuit(circuit, cache, note=circuit_name)
+                ok[0] = True
+            except Exception as e:                # noqa: BLE001
+                print("rank 0: circuit cache not written (%r); every rank synthesises its own" % (e,), file=sys.stderr)
+        dist.broadcast_object_list(ok, src=0)
+        if rank != 0 and ok[0]:
+            try:
+                circuit, circuit_name = S.load_circuit(cache)
+                circuit_from = "mapped from rank 0's copy in %s" % cache
+            except Exception as e:                # noqa: BLE001
+                print("rank %d: circuit cache unreadable (%r); synthesising" % (rank, e), file=sys.stderr)
+                circuit = None
+    if circuit is None:
+        circuit, circuit_name = synthesise()
     t_gen = time.perf_counter() - t_gen
     ctx = E.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -186,19 +222,39 @@ def main():
             else:
                 err = "librccl could not be loaded on every rank"
             if box[0] is not None:
-                try:
-                    comm = E.RcclComm(ctx, box[0], rank, world)
-                    mine = torch.full((128,), 0x0101010101010101 * (rank + 1), dtype=torch.int64, device=dev)
-                    got = torch.zeros((world, 128), dtype=torch.int64, device=dev)
-                    torch.cuda.synchronize()
-                    comm.all_gather(mine.data_ptr(), got.data_ptr(), 1024, stream=torch.cuda.current_stream().cuda_stream)
-                    torch.cuda.synchronize()
-                    want_blk = (torch.arange(1, world + 1, dtype=torch.int64, device=dev) * 0x0101010101010101).view(world, 1)
-                    ok_local = 1 if bool((got == want_blk).all()) else 0
-                    if not ok_local:
-                        err = "self-test of the in-library all-gather returned wrong data"
-                except Exception as e:
-                    err = e
+                # ncclCommInitRank and the first collective are where a fabric / driver problem shows as a HANG, on hardware this
+                # path has never met: they run in a helper thread under a watchdog.  A rank whose helper has not come back in time
+                # votes "failed" in the all-reduce below (torch's own process group) and the run goes on over the callback
+                # transport; the stuck helper is a daemon thread and dies with the process.
+                import threading
+                res = {}
+
+                def bring_up():
+                    try:
+                        torch.cuda.set_device(local_rank)
+                        c = E.RcclComm(ctx, box[0], rank, world)
+                        mine = torch.full((128,), 0x0101010101010101 * (rank + 1), dtype=torch.int64, device=dev)
+                        got = torch.zeros((world, 128), dtype=torch.int64, device=dev)
+                        torch.cuda.synchronize()
+                        c.all_gather(mine.data_ptr(), got.data_ptr(), 1024, stream=torch.cuda.current_stream().cuda_stream)
+                        torch.cuda.synchronize()
+                        want_blk = (torch.arange(1, world + 1, dtype=torch.int64, device=dev) * 0x0101010101010101).view(world, 1)
+                        res["ok"] = bool((got == want_blk).all())
+                        res["comm"] = c
+                    except Exception as e:            # noqa: BLE001
+                        res["err"] = e
+
+                th = threading.Thread(target=bring_up, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("BJ_BENCH_RCCL_TIMEOUT_S", "120")))
+                if th.is_alive():
+                    err = "in-library RCCL bring-up did not return within the watchdog"
+                elif "err" in res:
+                    err = res["err"]
+                elif not res.get("ok"):
+                    err = "self-test of the in-library all-gather returned wrong data"
+                else:
+                    comm, ok_local = res["comm"], 1
             flag = torch.tensor([ok_local], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
@@ -235,7 +291,13 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
+        mine = {"rank": rank, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "stages_ms": {k: round(v / args.steps, 3) for k, v in stage_acc.items()},
+                "leaf_kernel_ms": round(float(np.mean(leaf_ms)), 3), "circuit": circuit_from}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
@@ -308,6 +370,18 @@ def main():
     out["kernels"] = {k: {"ms": round(v[0] / args.steps, 4), "algorithmic_bytes": v[1], "achieved": round(v[1] / (v[0] / args.steps) / 1e6, 1),
                           "unit": "GB/s", "frac": round(v[1] / (v[0] / args.steps) / 1e6 / HBM_PEAK_GBPS, 4), "what": KNOTE.get(k, k)}
                       for k, v in kern_acc.items() if v[0] > 0}
+    if per_rank is not None:      # which rank set the time, and how far apart the ranks are, stage by stage
+        slow = max(per_rank, key=lambda r: r["ms_per_step"])
+        stages = sorted(per_rank[0]["stages_ms"])
+        out["ranks"] = {"slowest_rank": slow["rank"], "ms_per_step_min": min(r["ms_per_step"] for r in per_rank),
+                        "ms_per_step_max": slow["ms_per_step"],
+                        "stages_ms_min": {k: min(r["stages_ms"].get(k, 0.0) for r in per_rank) for k in stages},
+                        "stages_ms_max": {k: max(r["stages_ms"].get(k, 0.0) for r in per_rank) for k in stages},
+                        "leaf_kernel_ms_min_max": [min(r["leaf_kernel_ms"] for r in per_rank), max(r["leaf_kernel_ms"] for r in per_rank)],
+                        "circuit_source": sorted({r["circuit"].split(" in ")[0] for r in per_rank}),
+                        "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or "all",
+                        "note": "LOCAL_RANK indexes the devices this process SEES (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES are applied by "
+                                "the runtime before torch and libboojum_hip enumerate them)"}
     if sharded:      # what a scaling record needs to explain itself: per proof on rank 0, and the slowest rank's time in collectives
         cm = torch.tensor([comm_ms_acc / args.steps], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         cmax = cm.clone()

@@ -629,3 +629,41 @@ def check_satisfied(c: Circuit):
             count[lut[k]] += 1
     assert np.array_equal(count, c.multiplicities[0]), "multiplicities mismatch"
     return True
+
+
+_BIG = ("variables", "multiplicities", "sigmas", "constants", "tables", "witness")
+
+
+def save_circuit(c: Circuit, directory, note=""):
+    """The circuit as a directory of plain .npy files (one per big array) + a pickle of everything else: what `bench.py --gpus N`
+    uses to synthesise once and let the other ranks MAP the arrays read-only (load_circuit).  Written under a temporary name and
+    renamed, so a reader never sees a partial directory."""
+    import os
+    import pickle
+    import shutil
+    import copy
+    tmp = directory + ".tmp%d" % os.getpid()
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    small = copy.copy(c)
+    for k in _BIG:
+        a = getattr(c, k)
+        if a is not None:
+            np.save(os.path.join(tmp, k + ".npy"), np.ascontiguousarray(a))
+        setattr(small, k, None)
+    with open(os.path.join(tmp, "circuit.pkl"), "wb") as f:
+        pickle.dump({"circuit": small, "note": note, "present": [k for k in _BIG if getattr(c, k) is not None]}, f)
+    shutil.rmtree(directory, ignore_errors=True)
+    os.rename(tmp, directory)
+
+
+def load_circuit(directory):
+    """(Circuit, note) from save_circuit's directory; the big arrays are memory-mapped read-only."""
+    import os
+    import pickle
+    with open(os.path.join(directory, "circuit.pkl"), "rb") as f:
+        d = pickle.load(f)
+    c = d["circuit"]
+    for k in d["present"]:
+        setattr(c, k, np.load(os.path.join(directory, k + ".npy"), mmap_mode="r"))
+    return c, d["note"]

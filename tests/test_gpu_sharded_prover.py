@@ -153,6 +153,11 @@ def test_plain_bench_command_with_gpus_2_starts_two_ranks():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
     assert out["comm"]["world"] == 2 and out["comm"]["calls_per_proof"] > 0 and out["comm"]["mb_received_per_rank_per_proof"] > 0
     assert "accepts" in out["config"]["verified"]
+    # first-contact diagnostics of a multi-rank run: which rank set the time, the spread per stage, where the circuit came from
+    rk = out["ranks"]
+    assert rk["slowest_rank"] in (0, 1) and rk["ms_per_step_min"] <= rk["ms_per_step_max"] <= out["ms_per_step"] * 1.001
+    assert set(rk["stages_ms_min"]) == set(rk["stages_ms_max"]) == set(out["stages_ms"])
+    assert any("mapped from rank 0" in c for c in rk["circuit_source"]) and any("synthesised" in c for c in rk["circuit_source"])
 
 
 def test_plain_bench_command_refuses_more_gpus_than_visible():
