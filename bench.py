@@ -314,7 +314,7 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be collected from inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh) is used when it matches the launch shape
     traffic, traffic_src, valu = None, None, None
-    for prof in ("r04_pmc_bench_2p22_leaf_traffic.json", "r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
+    for prof in ("r05_pmc_bench_2p22_leaf_traffic.json", "r04_pmc_bench_2p22_leaf_traffic.json", "r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
             if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
@@ -428,7 +428,7 @@ def main():
                       "achieved": round(nb / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": round(nb / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nb,
                       "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
-        for prof in ("r04_cfg2_ntt_summary.json", "r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
+        for prof in ("r05_cfg2_ntt_summary.json", "r04_cfg2_ntt_summary.json", "r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
             try:   # counters of the same two kernels from the committed rocprofv3 passes over tools/cfg2_ntt.py --cfg2-only
                 cs = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 out["ntt"]["pmc_from_committed_profile"] = {

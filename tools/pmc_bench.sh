@@ -10,7 +10,7 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVES SQ_INSTS_VALU SQ_
   name=${pass%%:*}; ctrs=${pass#*:}
   out=$repo/gpurun_out/pmcb_${tag}_$name
   rm -rf $out; mkdir -p $out
-  rocprofv3 --pmc $ctrs -f csv -d $out -o pmc -- python $repo/bench.py --no-ntt --no-cpu-baseline "$@" > $out/stdout.txt 2>&1
+  rocprofv3 --pmc $ctrs -f csv -d $out -o pmc -- python $repo/bench.py --no-ntt --no-cpu-baseline --no-scale-replay --no-two-in-flight "$@" > $out/stdout.txt 2>&1
   f=$(find $out -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then cp $f $repo/gpurun_out/pmcb_${tag}_$name.raw.csv; python3 $repo/tools/pmc_summarize.py $f > $repo/gpurun_out/pmcb_${tag}_$name.csv; else echo "no counter file for $name"; tail -5 $out/stdout.txt; fi
   rm -rf $out

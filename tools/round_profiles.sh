@@ -13,7 +13,7 @@ mkdir -p $dst
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_kt -o p -- python $repo/bench.py --no-cpu-baseline --no-host-witness --no-ntt --steps 6 --warmup 1 > /tmp/prof_kt_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_kt -o p -- python $repo/bench.py --no-cpu-baseline --no-host-witness --no-ntt --no-scale-replay --no-two-in-flight --steps 6 --warmup 1 > /tmp/prof_kt_stdout.txt 2>&1
 f=$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $dst/r${tag}_prover_2p22_kernel_stats.csv
 t=$(find /tmp/prof_kt -name '*kernel_trace.csv' | head -1)
 [ -n "$t" ] && python3 - "$t" > $dst/r${tag}_prover_2p22_leaf_launches.csv <<'PY'
@@ -31,4 +31,12 @@ for k in fetch write sq; do [ -f gpurun_out/pmcb_r${tag}_$k.csv ] && cp gpurun_o
 [ -f gpurun_out/pmc_bench_r$tag.json ] && cp gpurun_out/pmc_bench_r$tag.json $dst/r${tag}_pmc_bench_2p22_leaf_traffic.json
 bash tools/prof_cfg2.sh r$tag > $dst/prof_cfg2_stdout.txt 2>&1
 for f in gpurun_out/cfg2_r${tag}_*; do b=$(basename $f); cp $f $dst/r${tag}_cfg2_ntt_${b#cfg2_r${tag}_}; done
+# one rank of the 8-GPU proof ALONE on this GPU, its peers replayed (era_boojum_amd/scale_replay.py): the kernel table of what a
+# rank executes per proof at W = 8 (the recording pass — eight ranks sharing the GPU for one proof — is in the trace too: 20 replayed
+# proofs against 1 recorded one per rank)
+cd /tmp
+rm -rf /tmp/prof_rp
+rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_rp -o p -- python $repo/tools/replay_rank.py 8 0 20 > $dst/replay_w8_rank0_stdout.txt 2>&1
+f=$(find /tmp/prof_rp -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $dst/r${tag}_replay_w8_rank0_kernel_stats.csv
+cd $repo
 ls -la $dst
