@@ -19,3 +19,16 @@ def test_scale_model_runs_on_the_committed_profile():
     t = [d["T"][w]["ms"] for w in ("1", "2", "4", "8")]
     assert t[0] > t[1] > t[2] > t[3] > d["replicated_ms"]
     assert d["T"]["8"]["efficiency"] < d["T"]["2"]["efficiency"] <= 1.0
+
+
+def test_scale_model_against_the_replayed_ranks_of_round_5():
+    """The model's per-proof constant was re-fitted to what one rank alone measures (profiles/r05_bench_scale_replay.json, the
+    bench line of round 5): with it the prediction is within 3 % of replayed compute + modelled link time at W = 2, 4, 8."""
+    prof = os.path.join(ROOT, "profiles", "r04_prover_2p22_kernel_stats.csv")
+    line = os.path.join(ROOT, "profiles", "r05_bench_scale_replay.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_model.py"), prof, "--wall-ms", "261.7", "--replay", line],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    for w in ("2", "4", "8"):
+        assert 0.97 < d["T"][w]["model_over_measured"] < 1.03, (w, d["T"][w])
