@@ -37,6 +37,7 @@ for f in gpurun_out/cfg2_r${tag}_*; do b=$(basename $f); cp $f $dst/r${tag}_cfg2
 cd /tmp
 rm -rf /tmp/prof_rp
 rocprofv3 --kernel-trace --stats -f csv -d /tmp/prof_rp -o p -- python $repo/tools/replay_rank.py 8 0 20 > $dst/replay_w8_rank0_stdout.txt 2>&1
-f=$(find /tmp/prof_rp -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $dst/r${tag}_replay_w8_rank0_kernel_stats.csv
+t=$(find /tmp/prof_rp -name '*kernel_trace.csv' | head -1)
+[ -n "$t" ] && python3 $repo/tools/replay_table.py $t 20 > $dst/r${tag}_replay_w8_rank0_per_proof.csv
 cd $repo
 ls -la $dst
