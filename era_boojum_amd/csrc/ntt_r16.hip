@@ -54,6 +54,15 @@ static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
 #else
 #define BJ_R16_ST_GUARD(a)
 #endif
+// -DBJ_R16_AB_S8_NOMEM: only the strided pass loses its loads and its stores — its butterflies stay: what an LDE would cost if the
+// middle pass's 16 n words per column of HBM traffic went away with the arithmetic unchanged (the bound on fusing it into a neighbour)
+#ifdef BJ_R16_AB_S8_NOMEM
+#define BJ_R16_LD_S8(base, off, salt) ((u64)(off) * 0x9E3779B97F4A7C15ull + (u64)(salt))
+#define BJ_R16_ST_GUARD_S8(a) if ((a).n_cols == 0xFFFFFFFFu)
+#else
+#define BJ_R16_LD_S8(base, off, salt) BJ_R16_LD(base, off, salt)
+#define BJ_R16_ST_GUARD_S8(a) BJ_R16_ST_GUARD(a)
+#endif
 // Software pipeline over the columns of a workgroup (round 5, build switches): the loads of column c + 1 are issued before the stores
 // of column c and the barriers stop draining vmcnt (the ISA then waits with vmcnt(22..16) at the top of a column: the sixteen stores
 // stay in flight).  Measured on MI355X (profiles/r05_ntt_wait_ab.txt): parked wave-cycles of ntt_local12 24.4 % -> 20.7 %, issue-stall
@@ -322,7 +331,7 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
     auto request = [&](u64 (&v)[16], unsigned col) {
         const gcptr src = uniform_gptr(a.in + (size_t)col * a.in_col_stride + (size_t)coset * a.in_coset_stride + tile_base);
 #pragma unroll
-        for (int j = 0; j < 16; j++) v[j] = BJ_R16_LD(src + ((size_t)(j * 16) << rem_log), off_ld, j + col);
+        for (int j = 0; j < 16; j++) v[j] = BJ_R16_LD_S8(src + ((size_t)(j * 16) << rem_log), off_ld, j + col);
     };
     u64 x[16];
     auto column = [&](unsigned col) {
@@ -342,7 +351,7 @@ __global__ void __launch_bounds__(256, BJ_S8_WAVES) ntt_strided8_kernel(R16Args 
         if (more) request(nx, col + 1);
         radix16_lds<false>(x, lds_tw2 + tm * 16);   // mid bits 3..0
 #pragma unroll
-        for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD(a) st_off(dst + ((size_t)j << rem_log), off_st, x[j]);
+        for (int j = 0; j < 16; j++) BJ_R16_ST_GUARD_S8(a) st_off(dst + ((size_t)j << rem_log), off_st, x[j]);
         if (more) {
 #pragma unroll
             for (int j = 0; j < 16; j++) x[j] = nx[j];
