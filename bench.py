@@ -169,23 +169,29 @@ def main():
             return c, "SHA-256 of %d random bytes (seed %d), synthesised like the reference bench (sha256/mod.rs:296-470)" % (msg_len, seed)
         return S.sha_shaped_circuit(log_n, seed=seed, table_bits=table_bits), "SHA-shaped satisfiable synthetic (seed %d)" % seed
 
-    circuit, circuit_name, circuit_from = None, None, "synthesised by this rank"
+    circuit, circuit_name, circuit_from, cache = None, None, "synthesised by this rank", None
     if sharded:
         # every rank of a sharded proof needs the SAME circuit: rank 0 synthesises it once and leaves the big arrays in a directory
         # of plain .npy files (tmpfs when there is one); the other ranks map them read-only — one copy of the ~7 GB in host memory
         # and one synthesis instead of N of each.  Anything that goes wrong falls back to local synthesis.
-        cache = os.environ.get("BJ_BENCH_CIRCUIT_CACHE") or os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
-                                                                          "bj_bench_circuit_%s_%d_%d_%d" % (args.circuit, log_n, seed, os.getuid()))
-        ok = [False]
+        ok = [None]
         if rank == 0:
             try:
+                import shutil
                 circuit, circuit_name = synthesise()
+                need = int(S.circuit_bytes(circuit) * 1.1) + (64 << 20)
+                roots = [os.environ["BJ_BENCH_CIRCUIT_CACHE"]] if os.environ.get("BJ_BENCH_CIRCUIT_CACHE") else ["/dev/shm", "/tmp"]
+                root = next((r for r in roots if os.path.isdir(r) and shutil.disk_usage(r).free > need), None)   # a container's /dev/shm is often 64 MB
+                if root is None:
+                    raise OSError("no directory with %.1f GB free among %s" % (need / 1e9, roots))
+                cache = os.path.join(root, "bj_bench_circuit_%s_%d_%d_%d" % (args.circuit, log_n, seed, os.getuid()))
                 S.save_circuit(circuit, cache, note=circuit_name)
-                ok[0] = True
+                ok[0] = cache
             except Exception as e:                # noqa: BLE001
                 print("rank 0: circuit cache not written (%r); every rank synthesises its own" % (e,), file=sys.stderr)
         dist.broadcast_object_list(ok, src=0)
-        if rank != 0 and ok[0]:
+        cache = ok[0]
+        if rank != 0 and cache:
             try:
                 circuit, circuit_name = S.load_circuit(cache)
                 circuit_from = "mapped from rank 0's copy in %s" % cache
@@ -652,6 +658,9 @@ def main():
         print(json.dumps(out))
     barrier()           # rank 0 may still have been verifying / timing the CPU baseline: leave the group together
     setup.close()
+    if sharded and rank == 0 and cache:      # the mapped copy of the circuit (the other ranks' mappings outlive the unlink)
+        import shutil
+        shutil.rmtree(cache, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -645,16 +645,24 @@ def save_circuit(c: Circuit, directory, note=""):
     tmp = directory + ".tmp%d" % os.getpid()
     shutil.rmtree(tmp, ignore_errors=True)
     os.makedirs(tmp)
-    small = copy.copy(c)
-    for k in _BIG:
-        a = getattr(c, k)
-        if a is not None:
-            np.save(os.path.join(tmp, k + ".npy"), np.ascontiguousarray(a))
-        setattr(small, k, None)
-    with open(os.path.join(tmp, "circuit.pkl"), "wb") as f:
-        pickle.dump({"circuit": small, "note": note, "present": [k for k in _BIG if getattr(c, k) is not None]}, f)
-    shutil.rmtree(directory, ignore_errors=True)
-    os.rename(tmp, directory)
+    try:
+        small = copy.copy(c)
+        for k in _BIG:
+            a = getattr(c, k)
+            if a is not None:
+                np.save(os.path.join(tmp, k + ".npy"), np.ascontiguousarray(a))
+            setattr(small, k, None)
+        with open(os.path.join(tmp, "circuit.pkl"), "wb") as f:
+            pickle.dump({"circuit": small, "note": note, "present": [k for k in _BIG if getattr(c, k) is not None]}, f)
+        shutil.rmtree(directory, ignore_errors=True)
+        os.rename(tmp, directory)
+    except BaseException:
+        shutil.rmtree(tmp, ignore_errors=True)      # a full tmpfs must not keep the half-written copy
+        raise
+
+
+def circuit_bytes(c: Circuit):
+    return sum(int(getattr(c, k).nbytes) for k in _BIG if getattr(c, k) is not None)
 
 
 def load_circuit(directory):
