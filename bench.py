@@ -395,7 +395,7 @@ def main():
         out["comm"] = {"world": int(comm.world), "calls_per_proof": int(comm_calls), "mb_received_per_rank_per_proof": round(comm_mb, 2),
                         "ms_in_collectives_rank0": round(float(cm[0]), 3), "ms_in_collectives_max_rank": round(float(cmax[0]), 3),
                         "note": "time between the start and the end of each all-gather on the proof's stream (transfer + waiting for "
-                                "the slowest peer), summed over a proof; replicated main-domain work is ~21 ms per rank (DESIGN.md §6)",
+                                "the slowest peer), summed over a proof; replicated work is ~25 ms per rank, measured by the replayed ranks of scale_replay (DESIGN.md §6)",
                         "transport": transport}
 
     # ---- the drop-in call with a host witness (bj_prove): PCIe transfer of the 93 columns inside the timed region
