@@ -31,6 +31,21 @@ def ctx():
     return _ctx
 
 
+def oracle_threads(default=64):
+    """OpenMP threads for the oracle's bulk operations: the container's CPU quota when there is one (the GPU boxes show 256 CPUs in the
+    affinity mask and deliver 16 cores: 64 threads on them cost the coset-streaming restatement 8 %, tools/oracle_threads_probe.py)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, math.ceil(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, default))
+
+
 def rand_gl(rng, shape, noncanonical=False):
     a = rng.integers(0, P, size=shape, dtype=np.uint64)
     if noncanonical:

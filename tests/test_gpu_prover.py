@@ -6,7 +6,7 @@ import pytest
 
 import era_boojum_amd as E
 from era_boojum_amd import proof_format, synthetic as S
-from gpu_util import ctx
+from gpu_util import ctx, oracle_threads
 from oracle import prover as OP
 from oracle import verifier as OV
 
@@ -344,7 +344,7 @@ def test_proof_at_2p23_rows_equals_the_streaming_oracle():
     pg = proof_format.parse(buf, security_level=100)
     assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg, verbose=True)
     claimed = {k: pg[k] for k in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap")}
-    po = PS.commitments_and_openings(c, cap, 8, 16, threads=64, transcript_kind=1, check_setup_cosets=(5,), cap_cosets=(0, 5),
+    po = PS.commitments_and_openings(c, cap, 8, 16, threads=oracle_threads(), transcript_kind=1, check_setup_cosets=(5,), cap_cosets=(0, 5),
                                      claimed_caps=claimed, rest_of_the_proof=True, security_level=100)
     for k in ("public_inputs", "quotient_oracle_cap", "values_at_z", "values_at_z_omega", "values_at_0"):
         assert pg[k] == po[k], k

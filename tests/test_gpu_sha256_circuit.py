@@ -9,7 +9,7 @@ import pytest
 import era_boojum_amd as E
 from era_boojum_amd import proof_format
 from era_boojum_amd import sha256_circuit as S
-from gpu_util import ctx
+from gpu_util import ctx, oracle_threads
 from oracle import prover as OP
 from oracle import verifier as OV
 from test_gpu_prover import _compare
@@ -75,8 +75,8 @@ def test_hip_proof_at_2p18_rows_equals_oracle_proof():
     multi-workgroup scans of stage 2 and the large-tree kernels are all on this path.  ~1 minute of oracle time."""
     c = S.sha256_circuit(S.bench_message(34000, seed=11))
     assert c.log_n == 18
-    osetup = OP.Setup(c, 8, 16, threads=64)
-    po = OP.prove(c, osetup, 8, 16, security_level=100, threads=64, transcript_kind=1)
+    osetup = OP.Setup(c, 8, 16, threads=oracle_threads())
+    po = OP.prove(c, osetup, 8, 16, security_level=100, threads=oracle_threads(), transcript_kind=1)
     gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript="poseidon2")
     assert np.array_equal(gsetup.cap(), osetup.cap)
     buf, _ = gsetup.prove()
@@ -93,9 +93,9 @@ def test_hip_proof_at_2p20_rows_equals_oracle_proof_under_both_bench_transcripts
     under the bench script's Poseidon one (prover.rs:153-168 is the function replaced).  ~1.5 minutes of oracle time."""
     c = S.sha256_circuit(S.bench_message(S.message_len_for_log_n(20), seed=13))
     assert c.log_n == 20
-    osetup = OP.Setup(c, 8, 16, threads=64)
+    osetup = OP.Setup(c, 8, 16, threads=oracle_threads())
     for transcript, kind in (("poseidon2", 1), ("poseidon", 2)):
-        po = OP.prove(c, osetup, 8, 16, security_level=100, threads=64, transcript_kind=kind)
+        po = OP.prove(c, osetup, 8, 16, security_level=100, threads=oracle_threads(), transcript_kind=kind)
         gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript=transcript)
         assert np.array_equal(gsetup.cap(), osetup.cap)
         buf, _ = gsetup.prove()
@@ -147,13 +147,13 @@ def test_hip_proof_at_2p22_rows_equals_the_oracle():
     ctx().release_workspace()
     pg = proof_format.parse(buf, security_level=100)
     if _host_ram_gb() >= 500:
-        osetup = OP.Setup(c, 8, 16, threads=64)
+        osetup = OP.Setup(c, 8, 16, threads=oracle_threads())
         assert np.array_equal(cap, osetup.cap)
-        po = OP.prove(c, osetup, 8, 16, security_level=100, threads=64, transcript_kind=1)
+        po = OP.prove(c, osetup, 8, 16, security_level=100, threads=oracle_threads(), transcript_kind=1)
         _compare(pg, po)
         return
     from oracle import prover_streaming as PS
-    po = PS.commitments_and_openings(c, cap, 8, 16, threads=64, transcript_kind=1, check_setup_cosets=(0, 5), rest_of_the_proof=True,
+    po = PS.commitments_and_openings(c, cap, 8, 16, threads=oracle_threads(), transcript_kind=1, check_setup_cosets=(0, 5), rest_of_the_proof=True,
                                      security_level=100)
     for k in ("public_inputs", "witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z", "values_at_z_omega",
               "values_at_0"):
