@@ -24,7 +24,7 @@ namespace bj {
 // stage2.hip
 void launch_copy_perm_stage2(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                              const u64 *d_non_res, unsigned V, unsigned chunk, unsigned log_n, const u64 *d_tw_fwd,
-                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s);
+                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s, bool small_non_residues);
 void launch_lookup_polys(const u64 *d_lvars, size_t var_stride, const u64 *d_table_id, const u64 *d_tables,
                          size_t tab_stride, const u64 *d_mult, unsigned reps, unsigned w, unsigned log_n,
                          const u64 *beta, const u64 *gamma, u64 *d_A, u64 *d_B, hipStream_t s);
@@ -808,7 +808,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     if ((rc = tmp.alloc(ctx, (size_t)2 * n_chunks * n + 2 * ((n + 1023) / 1024) + 16))) return rc;
     const u64 *d_sig_nat = S->d_nat, *d_con_nat = S->d_nat + (size_t)V * n, *d_tab_nat = S->d_nat + (size_t)(V + nC) * n;
     bj::launch_copy_perm_stage2(d_variables, n, d_sig_nat, n, S->d_non_res, V, q, log_n, ctx->tw_fwd, beta, gamma, tmp.p,
-                                s2_nat.p, s2_nat.p + 2 * n, st);
+                                s2_nat.p, s2_nat.p + 2 * n, st, S->small_non_residues);
     if (has_lookup) {
         challenge2(lbeta);
         challenge2(lgamma);

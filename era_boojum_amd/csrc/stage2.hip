@@ -41,6 +41,9 @@ __device__ __forceinline__ u64 omega_pow_nat(const u64 *tw, unsigned log_n, u32 
 // together (Montgomery's trick: one F_p^2 inversion = one x^(p-2) chain per RAT_PTS rows instead of per row — the inversion
 // was 60 % of this kernel's multiplications).
 static constexpr int RAT_PTS = 4;
+// SMALLK: every non-residue fits 32 bits (make_non_residues' output always does; the launcher is told): k_c * (x * beta) as a
+// 32 x 64-bit product (gl::mul_u32_weak) instead of a 64 x 64 one
+template <bool SMALLK>
 __global__ void __launch_bounds__(256)
 copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas, size_t sig_stride, const u64 *non_res,
                           unsigned V, unsigned chunk, unsigned log_n, const u64 *tw, gl::e2 beta, gl::e2 gamma, u64 *out) {
@@ -59,7 +62,7 @@ copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
         den[k] = {1, 0};
     }
     for (unsigned i = j * chunk; i < (j + 1) * chunk && i < V; i++) {
-        const u64 kr = non_res[i];
+        const u64 kr = SMALLK ? gl::canon(non_res[i]) : non_res[i];
 #pragma unroll
         for (int k = 0; k < RAT_PTS; k++) {
             const size_t r = base + (size_t)k * 256;
@@ -68,7 +71,8 @@ copy_perm_rational_kernel(const u64 *vars, size_t var_stride, const u64 *sigmas,
             // once, after the last column, instead of after every operation
             const u64 w = vars[(size_t)i * var_stride + r];
             const u64 wg = gl::add_weak(w, gamma.c0);
-            const gl::e2 a{gl::add_weak(gl::mul_weak(kr, xb0[k]), wg), gl::add_weak(gl::mul_weak(kr, xb1[k]), gamma.c1)};
+            const gl::e2 a = SMALLK ? gl::e2{gl::add_weak(gl::mul_u32_weak(xb0[k], (u32)kr), wg), gl::add_weak(gl::mul_u32_weak(xb1[k], (u32)kr), gamma.c1)}
+                                    : gl::e2{gl::add_weak(gl::mul_weak(kr, xb0[k]), wg), gl::add_weak(gl::mul_weak(kr, xb1[k]), gamma.c1)};
             const u64 s = sigmas[(size_t)i * sig_stride + r];
             const gl::e2 b{gl::add_weak(gl::mul_weak(s, beta.c0), wg), gl::add_weak(gl::mul_weak(s, beta.c1), gamma.c1)};
             num[k] = gl::e2_mul_weak(num[k], a);
@@ -203,15 +207,20 @@ scan_apply_partials_kernel(u64 *z0, u64 *z1, const u64 *block_pre, const u64 *Q,
 // Driver.  d_tmp must hold 2*n_chunks*n + 2*ceil(n/1024) elements.  Outputs: d_z [2][n], d_partials [(n_chunks-1)][2][n].
 void launch_copy_perm_stage2(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                              const u64 *d_non_res, unsigned V, unsigned chunk, unsigned log_n, const u64 *d_tw_fwd,
-                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s) {
+                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s,
+                             bool small_non_residues) {
     const size_t n = (size_t)1 << log_n;
     const unsigned n_chunks = (V + chunk - 1) / chunk;
     gl::e2 b{gl::canon(beta[0]), gl::canon(beta[1])}, g{gl::canon(gamma[0]), gl::canon(gamma[1])};
     u64 *P = d_tmp;
     u64 *block_tot = d_tmp + (size_t)2 * n_chunks * n;
     const unsigned rb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(copy_perm_rational_kernel, dim3((unsigned)((n + 256 * RAT_PTS - 1) / (256 * RAT_PTS)), n_chunks), dim3(256), 0, s, d_vars, var_stride, d_sigmas,
-                       sig_stride, d_non_res, V, chunk, log_n, d_tw_fwd, b, g, P);
+    if (small_non_residues && !env().copy_perm_wide_k)
+        hipLaunchKernelGGL(copy_perm_rational_kernel<true>, dim3((unsigned)((n + 256 * RAT_PTS - 1) / (256 * RAT_PTS)), n_chunks), dim3(256), 0, s, d_vars, var_stride,
+                           d_sigmas, sig_stride, d_non_res, V, chunk, log_n, d_tw_fwd, b, g, P);
+    else
+        hipLaunchKernelGGL(copy_perm_rational_kernel<false>, dim3((unsigned)((n + 256 * RAT_PTS - 1) / (256 * RAT_PTS)), n_chunks), dim3(256), 0, s, d_vars, var_stride,
+                           d_sigmas, sig_stride, d_non_res, V, chunk, log_n, d_tw_fwd, b, g, P);
     hipLaunchKernelGGL(chunk_prefix_kernel, dim3(rb), dim3(256), 0, s, P, n_chunks, n);
     const u64 *a0 = P + ((size_t)2 * (n_chunks - 1)) * n, *a1 = a0 + n;
     const size_t n_blocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;

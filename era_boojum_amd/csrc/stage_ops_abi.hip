@@ -10,7 +10,7 @@ using gl::u64;
 namespace bj {
 void launch_copy_perm_stage2(const u64 *d_vars, size_t var_stride, const u64 *d_sigmas, size_t sig_stride,
                              const u64 *d_non_res, unsigned V, unsigned chunk, unsigned log_n, const u64 *d_tw_fwd,
-                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s);
+                             const u64 *beta, const u64 *gamma, u64 *d_tmp, u64 *d_z, u64 *d_partials, hipStream_t s, bool small_non_residues);
 void launch_lookup_polys(const u64 *d_lvars, size_t var_stride, const u64 *d_table_id, const u64 *d_tables,
                          size_t tab_stride, const u64 *d_mult, unsigned reps, unsigned w, unsigned log_n,
                          const u64 *beta, const u64 *gamma, u64 *d_A, u64 *d_B, hipStream_t s);
@@ -71,8 +71,10 @@ int bj_copy_perm_stage2(bj_ctx *ctx, const uint64_t *d_vars, size_t var_stride, 
         partials = (u64 *)dummy.p;
     }
     if (int rc = bj::h2d_async(ctx, nr.p, h_non_residues, 8 * (size_t)num_vars)) return rc;
+    bool small_k = true;
+    for (unsigned c = 0; c < num_vars; c++) small_k = small_k && gl::canon(h_non_residues[c]) < ((u64)1 << 32);
     bj::launch_copy_perm_stage2(d_vars, var_stride, d_sigmas, sig_stride, (const u64 *)nr.p, num_vars, chunk, log_n, ctx->tw_fwd,
-                                h_beta, h_gamma, (u64 *)tmp.p, d_z, partials, ctx->stream);
+                                h_beta, h_gamma, (u64 *)tmp.p, d_z, partials, ctx->stream, small_k);
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

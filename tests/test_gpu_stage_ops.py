@@ -42,6 +42,15 @@ def test_copy_permutation_grand_product_and_partial_products(log_n, kw):
     assert np.array_equal(z, wz)
     if n_chunks > 1:
         assert np.array_equal(d_p.get((n_chunks - 1, 2, n)), wp)
+    # multipliers k_c that do not fit 32 bits take the 64 x 64-bit product path (make_non_residues' own output always fits: the
+    # default path multiplies by it as a 32-bit integer); the operator is the same function of whatever k_c it is given
+    big = [(int(k) * 0x9E3779B97F4A7C15 + 12345) % P for k in c.non_residues]
+    assert max(big) >= 1 << 32
+    wz2, wp2 = OP.copy_perm_stage2(c.variables, c.sigmas, big, log_n, q, BETA, GAMMA, threads=8)
+    ctx().copy_perm_stage2(d_v.ptr, n, d_s.ptr, n, big, V, q, log_n, BETA, GAMMA, d_z.ptr, d_p.ptr if n_chunks > 1 else None)
+    assert np.array_equal(d_z.get((2, n)), wz2) and not np.array_equal(wz2, wz)
+    if n_chunks > 1:
+        assert np.array_equal(d_p.get((n_chunks - 1, 2, n)), wp2)
     # a satisfied copy permutation closes the cycle: z(omega^(n-1)) * last row's full ratio = 1 is implied by the quotient test
     for d in (d_v, d_s, d_z, d_p):
         d.free()
@@ -160,9 +169,10 @@ def test_quotient_term_kernels_one_by_one_and_together(log_n, kw):
         C.quotient_lookup(lv_ptr, Q, tid_ptr, bufs["tab"].ptr, Q, bufs["mult"].ptr, A_ptr, B_ptr, Q, reps, w, LBETA, LGAMMA, alphas,
                           Q, o0, o1)
 
-    def copy_perm(alphas, points=Q, first=0):
+    def copy_perm(alphas, points=Q, first=0, non_residues=None):
         off = 8 * first
-        C.quotient_copy_perm(bufs["vars"].ptr + off, Q, bufs["sig"].ptr + off, Q, bufs["s2"].ptr + off, Q, c.non_residues, V, q,
+        C.quotient_copy_perm(bufs["vars"].ptr + off, Q, bufs["sig"].ptr + off, Q, bufs["s2"].ptr + off, Q,
+                             c.non_residues if non_residues is None else non_residues, V, q,
                              log_n, d["log_q"], BETA, GAMMA, alphas, points, first, o0 + off, o1 + off)
 
     def clear():
@@ -200,6 +210,13 @@ def test_quotient_term_kernels_one_by_one_and_together(log_n, kw):
     # the L1 term alone
     clear(); copy_perm(a_cp[:1] + zero * nch)
     assert np.array_equal(out.get((2, Q)), _oracle_quotient(c, d, zero * (nl + ng) + a_cp[:1] + zero * nch))
+    # the copy-permutation chain with multipliers that do not fit 32 bits (the 64 x 64-bit product path; not a satisfied argument any
+    # more, the operator is the same function of whatever k_c it gets)
+    import copy
+    cb = copy.copy(c)
+    cb.non_residues = [(int(k) * 0x9E3779B97F4A7C15 + 12345) % P for k in c.non_residues]
+    clear(); copy_perm(a_cp, non_residues=cb.non_residues)
+    assert np.array_equal(out.get((2, Q)), _oracle_quotient(cb, d, zero * (nl + ng) + a_cp))
     for b in list(bufs.values()) + [out]:
         b.free()
 
