@@ -561,10 +561,20 @@ def main():
         affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         # the affinity mask can promise more cores than the container's CPU quota delivers (OpenMP then oversubscribes and spins):
         # calibrate on a small Poseidon2 tree and keep the thread count that hashes fastest
+        quota = None                                  # cgroup CPU quota of this container, in cores (None = unlimited / unknown)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else round(float(q) / float(per), 2)
+        except (OSError, ValueError):
+            pass
         rng = np.random.default_rng(1)
         cal = rng.integers(0, E.P, size=(93, 1 << 13), dtype=np.uint64)
         best = (None, 0.0)
-        for t_try in sorted({min(affinity, t) for t in (4, 8, 16, 32, 64, 128, 256)}):
+        # a burst as short as this calibration is not throttled by the quota, a 40 s proof is: over minutes, a team larger than twice
+        # the quota only adds waiting (tools/oracle_threads_probe.py on the GPU box: 16 and 32 threads 54 s, 64 threads 59 s), so the
+        # candidates stop there
+        cap_threads = affinity if quota is None else max(4, min(affinity, int(2 * quota + 0.5)))
+        for t_try in sorted({min(cap_threads, t) for t in (4, 8, 16, 32, 64, 128, 256)}):
             c0 = time.perf_counter()
             O.merkle_construct(cal, args.cap, threads=t_try)
             rate = (1 << 13) * 13 / (time.perf_counter() - c0)
@@ -578,12 +588,6 @@ def main():
                     cpu_model = line.split(":", 1)[1].strip()
                     break
         except OSError:
-            pass
-        quota = None                                  # cgroup CPU quota of this container, in cores (None = unlimited / unknown)
-        try:
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            quota = None if q == "max" else round(float(q) / float(per), 2)
-        except (OSError, ValueError):
             pass
 
         def oracle_proof(lg):
