@@ -481,6 +481,7 @@ def main():
             raise SystemExit("parity failure: the verifier restatement rejects the HIP proof")
         out["config"]["verified"] = "oracle/verifier.py accepts the last timed proof"
     transcript_kind = setup.transcript_kind
+    stuck_legs = []          # secondary legs whose helper threads did not return: the process then leaves through os._exit
     if rank == 0 and world == 1 and not args.no_two_in_flight:
         # secondary throughput figure: TWO proofs of the same circuit in flight on this one GPU — two contexts, two HIP streams, two
         # host threads (the shape of tests/test_gpu_prover.py::test_two_contexts_on_two_host_threads_prove_concurrently).  The
@@ -500,12 +501,15 @@ def main():
 
             run(1, setup2)                      # warm-up of the second context (arena, twiddles)
             torch.cuda.synchronize()
-            th = [threading.Thread(target=run, args=(0, setup)), threading.Thread(target=run, args=(1, setup2))]
+            th = [threading.Thread(target=run, args=(0, setup), daemon=True), threading.Thread(target=run, args=(1, setup2), daemon=True)]
             c0 = time.perf_counter()
             for t in th:
                 t.start()
             for t in th:
-                t.join()
+                t.join(120.0)
+            if any(t.is_alive() for t in th):
+                stuck_legs.append("throughput_2_in_flight")
+                raise TimeoutError("two concurrent provers did not finish within the watchdog")
             torch.cuda.synchronize()
             dt = time.perf_counter() - c0
             assert np.array_equal(bufs[0], proof_buf) and np.array_equal(bufs[1], proof_buf), "concurrent proofs differ from the timed one"
@@ -520,7 +524,7 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                    # noqa: BLE001 — secondary leg
             out["throughput_2_in_flight"] = {"error": repr(e)[:300]}
-    if rank == 0 and world == 1 and not args.no_scale_replay and log_n >= 12:
+    if rank == 0 and world == 1 and not args.no_scale_replay and log_n >= 12 and not stuck_legs:
         # one rank of the sharded proof alone on this GPU, peers replayed (the only multi-GPU evidence one GPU can give)
         from era_boojum_amd import scale_replay
         t1_ms = elapsed / args.steps * 1e3
@@ -535,12 +539,36 @@ def main():
                                                   "(1.7 / 2.3 / 2.7 ms, ring-bound all-gather at one 150 GB/s xGMI link per rank); per-proof constant "
                                                   "re-fitted in round 5 to the replayed ranks"} if (log_n == 22 and args.fri_lde == 8) else None,
               "worlds": {}}
+        import threading
         for w in [int(x) for x in args.replay_world.split(",") if x]:
             if w < 2 or args.fri_lde % w or args.cap % w:
                 continue
+            if stuck_legs:                        # a leg that did not come back may still hold the device: do not stack another on it
+                sr["worlds"][str(w)] = {"error": "skipped: an earlier leg timed out"}
+                continue
             try:
-                r = scale_replay.measure(circuit, w, args.fri_lde, args.cap, args.security, args.transcript, steps=args.replay_steps,
-                                         warmup=1, device=local_rank, reference_proof=proof_buf, d_vars=d_vars, d_mult=d_mult)
+                # the leg runs W host threads that meet in barriers: it gets its own watchdog so that nothing it could do wrong
+                # can cost the run its headline line (printed below in any case)
+                box = {}
+
+                def leg(w=w, box=box):
+                    try:
+                        torch.cuda.set_device(local_rank)
+                        box["r"] = scale_replay.measure(circuit, w, args.fri_lde, args.cap, args.security, args.transcript,
+                                                        steps=args.replay_steps, warmup=1, device=local_rank, reference_proof=proof_buf,
+                                                        d_vars=d_vars, d_mult=d_mult)
+                    except BaseException as e:    # noqa: BLE001
+                        box["e"] = e
+
+                th = threading.Thread(target=leg, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("BJ_BENCH_REPLAY_TIMEOUT_S", "240")))
+                if th.is_alive():
+                    stuck_legs.append("scale_replay W=%d" % w)
+                    raise TimeoutError("did not finish within the watchdog")
+                if "e" in box:
+                    raise box["e"]
+                r = box["r"]
                 # T(W) = R + S / W and T(1) = R + S give the replicated part R the measurement implies
                 r["implied_replicated_ms"] = round((w * r["max_ms"] - t1_ms) / (w - 1), 2)
                 r["speedup_compute_only"] = round(t1_ms / r["max_ms"], 3)
@@ -659,7 +687,10 @@ def main():
                                          "poseidon2_tree_2p%d_x93" % tl_log: {"ms": round(t_tree * 1e3, 1), "Mperm_per_s": round(perms / t_tree / 1e6, 2),
                                                                              "what": "oracle MerkleTreeWithCap::construct, leaves then node layers"}}}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if stuck_legs:           # a helper thread is still inside the library: no orderly teardown behind it
+        print("bench.py: leaving through os._exit, stuck: %s" % ", ".join(stuck_legs), file=sys.stderr, flush=True)
+        os._exit(0)
     barrier()           # rank 0 may still have been verifying / timing the CPU baseline: leave the group together
     setup.close()
     if sharded and rank == 0 and cache:      # the mapped copy of the circuit (the other ranks' mappings outlive the unlink)
