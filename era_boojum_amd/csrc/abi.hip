@@ -157,7 +157,7 @@ void load_env() {
     if (set("BJ_NTT_FRONT")) e.ntt_front = atoi(getenv("BJ_NTT_FRONT"));
     e.ntt_first4_v = str("BJ_NTT_FIRST4_V").rfind("1", 0) == 0 ? 1 : 2;
     if (set("BJ_NTT_FIRST4_MODE")) e.ntt_first4_mode = atoi(getenv("BJ_NTT_FIRST4_MODE"));
-    e.ntt_inv_fused = str("BJ_NTT_INV_FUSED").rfind("0", 0) != 0;
+    e.ntt_two_pass = str("BJ_NTT_TWO_PASS").rfind("0", 0) != 0;
     e.gate_no_aot = set("BJ_GATE_NO_AOT");
     e.gate_no_fuse = set("BJ_GATE_NO_FUSE");
     e.gate_no_jit = set("BJ_GATE_NO_JIT");
@@ -226,7 +226,7 @@ int bj_ctx_create(int device, bj_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return BJ_ERR_NO_DEVICE;
     bj_ctx *ctx = new bj_ctx();
     ctx->device = device;
-    if (hipMalloc((void **)&ctx->d_small, (64 + 64 * 32 + 4096) * sizeof(u64)) != hipSuccess ||
+    if (hipMalloc((void **)&ctx->d_small, (64 + 64 * 32 + 4096 + bj::BJ_FRONT_TABLE_WORDS) * sizeof(u64)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         delete ctx;
         return BJ_ERR_HIP;
@@ -394,7 +394,7 @@ int bj_ntt_forward_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uns
         bj::launch_round_scales(ctx->d_small + 64, &coset, 1, log_n, ctx->stream);
         scales = ctx->d_small + 64;
     }
-    bj::launch_ntt_passes(d_in, d_out, ctx->tw_fwd, scales, log_n, n_cols, 1, col_stride, col_stride, ctx->stream);
+    bj::launch_ntt_passes(d_in, d_out, ctx->tw_fwd, scales, log_n, n_cols, 1, col_stride, col_stride, ctx->stream, bj::front_table(ctx));
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }
@@ -410,7 +410,7 @@ int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned l
     const size_t n = (size_t)1 << log_n;
     // butterflies with inverse twiddles into scratch (bit-reversed), then un-reverse + scale into d_out
     if (int rc = ensure_scratch(ctx, (size_t)n_cols * n)) return rc;
-    bj::launch_ntt_passes(d_in, ctx->d_scratch, ctx->tw_inv, nullptr, log_n, n_cols, 1, col_stride, n, ctx->stream);
+    bj::launch_ntt_passes(d_in, ctx->d_scratch, ctx->tw_inv, nullptr, log_n, n_cols, 1, col_stride, n, ctx->stream, bj::front_table(ctx));
     u64 n_inv = log_n ? gl::inv(gl::canon((u64)n % gl::P)) : 1;
     u64 step = coset == 1 ? 1 : gl::inv(coset);
     bj::launch_bitrev_scale(ctx->d_scratch, d_out, log_n, n_cols, n, col_stride, n_inv, step, ctx->stream);
@@ -431,7 +431,7 @@ int lde_cosets_strided(bj_ctx *ctx, const u64 *d_mono, size_t in_col_stride, u64
         shifts[i] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(coset_begin + i, log_lde)));  // utils.rs:345-346, 370-373
     bj::launch_round_scales(ctx->d_small + 64, shifts, coset_count, log_n ? log_n : 1, ctx->stream);
     bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, coset_count,
-                          in_col_stride, out_col_stride, ctx->stream);
+                          in_col_stride, out_col_stride, ctx->stream, bj::front_table(ctx));
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

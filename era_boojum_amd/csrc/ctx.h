@@ -17,7 +17,7 @@ struct bj_ctx {
     // twiddle caches (bit-reversed tables; a table for 2^k serves every smaller size as a prefix)
     gl::u64 *tw_fwd = nullptr, *tw_inv = nullptr;
     unsigned tw_fwd_log = 0, tw_inv_log = 0;
-    gl::u64 *d_small = nullptr;  // 64 shifts + 64*32 per-round scales + 4096 for gathered Merkle caps
+    gl::u64 *d_small = nullptr;  // 64 shifts + 64*32 per-round scales + 4096 for gathered Merkle caps + the front-pass twiddle table
     const gl::u64 **d_ptrs = nullptr;
     size_t d_ptrs_cap = 0;
     gl::u64 *d_scratch = nullptr;  // big scratch for out-of-place steps
@@ -67,6 +67,7 @@ int bind(bj_ctx *ctx);
 int h2d_async(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
+inline gl::u64 *front_table(bj_ctx *ctx) { return ctx->d_small + 64 + 64 * 32 + 4096; }   // BJ_FRONT_TABLE_WORDS (kernels.h)
 int arena_reset(bj_ctx *ctx, size_t need_elems);
 gl::u64 *arena_alloc(bj_ctx *ctx, size_t elems);   // nullptr if the reservation was too small
 // short-lived device memory: from the arena inside a proof (no hipMalloc/hipFree, no implicit syncs), hipMalloc otherwise

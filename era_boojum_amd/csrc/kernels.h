@@ -18,7 +18,7 @@ struct EnvConfig {
     int ntt_front = 4;                  // BJ_NTT_FRONT: 0 remainder passes only, 5 first5 wherever it applies, default 4
     int ntt_first4_v = 2;               // BJ_NTT_FIRST4_V: indices per lane of the four-round front pass
     int ntt_first4_mode = 0;            // BJ_NTT_FIRST4_MODE: 0 inputs of the front pass kept in registers across the cosets (round 3: two waves per SIMD); 3 / 4: re-read per coset (L2), that many waves
-    bool ntt_inv_fused = true;          // BJ_NTT_INV_FUSED=0: inverse transforms end in the separate bit-reversal sweep
+    bool ntt_two_pass = true;           // BJ_NTT_TWO_PASS=0: 2^22-point transforms as 4 + 8 + 10 rounds (rounds 3-5) instead of 10 + 12
     bool gate_no_aot = false, gate_no_fuse = false, gate_no_jit = false;
     bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
     bool prove_no_absorb = false;
@@ -35,8 +35,11 @@ void env_reload();
 // ntt.hip
 void launch_twiddles(u64 *d_out, unsigned log_n, bool inverse, hipStream_t s);
 void launch_round_scales(u64 *d_out, const u64 *h_shifts, unsigned n_cosets, unsigned log_n, hipStream_t s);
+// d_front_table: BJ_FRONT_TABLE_WORDS words of device scratch for the twiddle table of the two-pass plan (nullptr: never that plan)
+constexpr size_t BJ_FRONT_TABLE_WORDS = 64 * 1024;
 void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
-                       unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s);
+                       unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s,
+                       u64 *d_front_table = nullptr);
 void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n_cols, size_t in_col_stride,
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s);
 void launch_canonicalize(u64 *d, size_t n, hipStream_t s);
@@ -46,6 +49,8 @@ void launch_field_op(int op, const u64 *a, const u64 *b, u64 *out, size_t n, hip
 void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n,
                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
                         size_t out_col_stride, unsigned rounds /* 12, or 10 / 9 behind launch_ntt_first4 / first5 */, hipStream_t s);
+void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
+                        unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s);
 void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
                        unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s);
 void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,

@@ -261,7 +261,7 @@ static bool force_generic() { return bj::env().ntt_generic; }
 // rounds (log_n not of the form 12 + 4k) in one generic strided pass at the very front.
 void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
                        unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride,
-                       hipStream_t s) {
+                       hipStream_t s, u64 *d_front_table) {
     const size_t n = (size_t)1 << log_n;
     if (log_n == 0) {  // size-1 transform: canonicalising copy
         launch_generic_pass(d_in, d_out, d_tw, nullptr, 0, 0, 0, 0, n_cols, n_cosets, in_col_stride, 0,
@@ -296,6 +296,16 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
         return;
     }
     unsigned front = log_n - 12;
+    // 22 rounds in two passes: ten in ntt_front10 (every coset from one tile of the caller's column), twelve in ntt_local12
+    // (the front pass moves 16 bytes per lane on both sides: columns on 16-byte boundaries)
+    const bool io16 = ((uintptr_t)d_out % 16) == 0 && out_col_stride % 2 == 0 && ((uintptr_t)d_in % 16) == 0 && in_col_stride % 2 == 0;
+    if (log_n == 22 && d_front_table && n_cosets <= 64 && io16 && bj::env().ntt_two_pass) {
+        launch_ntt_front10(src, d_out, d_tw, d_round_scale, d_front_table, log_n, n_cols, n_cosets, src_col_stride, out_col_stride, s);
+        advance(10);
+        launch_ntt_local12(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
+                           out_col_stride, 12, s);
+        return;
+    }
     // 14 + 4k and 15 + 4k rounds: the coset-expanding front pass is bound by its traffic whatever it computes, so it takes four
     // or five rounds (ntt_first4 / ntt_first5) and the local pass runs ten or nine instead of twelve — the same number of passes,
     // butterflies moved into idle VALU slots.  13 + 4k rounds keep the remainder pass of one round.

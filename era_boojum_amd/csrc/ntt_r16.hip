@@ -529,6 +529,163 @@ __global__ void __launch_bounds__(256) ntt_first5_kernel(R16Args a, unsigned n_c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The first TEN rounds (strides n/2 .. n/1024) of a 2^22-point transform in ONE pass over every coset: with ntt_local12 behind it
+// an LDE'd column makes two HBM passes (25 n words) instead of the three of first4 + strided8 + local10 (41 n), an inverse
+// transform two instead of three.  Tile = 1024 "mid" indices (the ten high bits of the element index) x 8 consecutive "lo"
+// indices: 8192 elements = 64 KB of LDS, 512 threads with 16 elements each, two workgroups per CU (<= 128 VGPRs: four waves per
+// SIMD), every HBM access a 64-byte run (the two tiles that share a 128-byte line are given to the same XCD back to back —
+// blocks b and b + 8 — so that the halves meet in that XCD's L2).  Three register steps per coset: radix-16 on mid bits 9..6,
+// radix-16 on bits 5..2, radix-4 on bits 1..0 (four lo values per lane, so that a lane stores 32 contiguous bytes), with two
+// transposes through LDS in between.  LDS indices are XOR-swizzled instead of padded (tools/lds_conflicts.py: every ds_read_b64 /
+// ds_write_b64 below is conflict-free), which keeps the tile at exactly 64 KB.
+// Twiddles: round r < 10 of group k < 2^r needs T[k] * sc_c[r]; all of them are uniform over the tiles, so they come from a
+// table tw[coset][2^r - 1 + k] (1023 entries per coset, front10_table_kernel) instead of being rebuilt by every workgroup:
+// step A's fifteen per coset sit in LDS for the whole kernel, step B's 16 x 15 are re-staged per coset, step C's three per lane
+// are loaded into registers.  The inputs of a tile are read again for every coset (no room for them in 128 VGPRs): seven of the
+// eight reads are L2 / Infinity-Cache hits.
+struct F10Args {
+    const u64 *in;
+    u64 *out;
+    const u64 *tw;            // [n_cosets][1024]
+    unsigned log_n, n_cols, cols_per_block, n_cosets;
+    size_t in_col_stride, out_col_stride;
+};
+__global__ void front10_table_kernel(u64 *out, const u64 *__restrict__ T, const u64 *__restrict__ round_scale, unsigned n_cosets) {
+    const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_cosets * 1024u) return;
+    const u32 c = idx >> 10, e = idx & 1023u;
+    if (e == 1023u) {
+        out[idx] = 0;
+        return;
+    }
+    const int r = 31 - __clz(e + 1);
+    const u32 k = e + 1 - (1u << r);
+    u64 v = T[k];
+    if (round_scale) v = gl::mul(v, round_scale[(size_t)c * 32 + r]);
+    out[idx] = gl::canon(v);
+}
+// The B -> C index map is LINEAR over GF(2) in the bits of (lane, register): index(lane, i) = index(lane, 0) ^ index(0, i), so a lane
+// keeps ONE value for it and reaches register i's slot with one v_xor by a literal (padding would need sixteen live addresses).
+__host__ __device__ constexpr u32 f10_bc(u32 m, u32 l) {   // transpose B -> C
+    const u32 x = l * 1024u + m;
+    return x ^ (((x >> 5) ^ (x >> 8) ^ (x >> 11)) & 31u);
+}
+__device__ __forceinline__ u64 &f10_at(u64 *lds, u32 byte_index) { return *reinterpret_cast<u64 *>(reinterpret_cast<char *>(lds) + byte_index); }
+// four rounds on 16 registers, stage s reading its 2^s twiddles at tw[off_s + g] (one table for all ten rounds of a coset)
+template <bool UNIT_FIRST>
+__device__ __forceinline__ void radix16_tab(u64 (&x)[16], const u64 *tw, u32 o0, u32 o1, u32 o2, u32 o3) {
+    const u32 off[4] = {o0, o1, o2, o3};
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int half = 8 >> s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+            const u64 w = (UNIT_FIRST && s == 0) ? 1 : tw[off[s] + g];
+#pragma unroll
+            for (int j = 0; j < half; j += 2) {
+                const int iu = g * 2 * half + j, iv = iu + half;
+                if (UNIT_FIRST && s == 0)
+                    gl::addsub2_weak(x[iu], x[iv], x[iu + 1], x[iv + 1]);
+                else
+                    gl::butterfly2_weak(x[iu], x[iv], w, x[iu + 1], x[iv + 1], w);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g += 2)
+        gl::butterfly2_weak(x[2 * g], x[2 * g + 1], tw[off[3] + g], x[2 * g + 2], x[2 * g + 3], tw[off[3] + g + 1]);
+}
+typedef const void __attribute__((address_space(1))) *f10_gsrc;
+typedef void __attribute__((address_space(3))) *f10_ldst;
+// The inputs of the NEXT (column, coset) iteration travel by LDS-DMA (global_load_lds_dwordx4: no destination registers) while
+// this iteration's last step computes and stores: eight 1-KB pieces of the tile and one of the coset's twiddle table per wave.
+// They are issued BEFORE this iteration's eight stores, so the counted wait at the top of the next iteration (vmcnt(8): VMEM
+// operations retire in order) leaves the stores in flight; the barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).
+template <bool UNIT_FIRST>
+__global__ void __launch_bounds__(512, 4) ntt_front10_kernel(F10Args a) {
+    __shared__ u64 lds[8192 + 1024];      // ONE object: the tile (64 KB) and the twiddle table of the coset being processed (8 KB)
+    u64 *lds_tw = lds + 8192;
+    const u32 t = threadIdx.x;
+    const u32 wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63u;
+    const unsigned s_log = a.log_n - 10;
+    const size_t n = (size_t)1 << a.log_n;
+    const u32 b = blockIdx.x;
+    const u32 tile = (b & ~15u) | ((b & 7u) << 1) | ((b >> 3) & 1u);   // tiles 2u, 2u + 1 -> blocks on one XCD
+    const size_t lo0 = (size_t)tile << 3;
+    // step A: lane = (ml : mid bits 5..0, l); registers = mid bits 9..6: LDS index i * 512 + t (as the DMA leaves the tile)
+    // step B: lane = (mh : mid bits 9..6, mll : bits 1..0, l); registers = bits 5..2
+    const u32 lB = t & 7u, mllB = (t >> 3) & 3u, mhB = t >> 5;
+    // step C: lane = (m92 : mid bits 9..2, l2 : lo bit 2); registers = (mid bits 1..0, lo bits 1..0)
+    const u32 l2C = t & 1u, m92 = t >> 1;
+    const u32 offC = (((m92 * 4u) << s_log) + l2C * 4u) * 8u;
+    const u32 ixB1 = ((mhB * 64u + mllB) * 8u + lB) * 8u, ixB2 = f10_bc(mhB * 64u + mllB, lB) * 8u, ixC = f10_bc(m92 * 4u, l2C * 4u) * 8u;
+    // DMA source of this lane inside a piece: piece p (of 64) = mid indices [16 p, 16 p + 16), lane = (mid & 15, lo pair)
+    const u32 dma_off = (((lane >> 2) << s_log) + (lane & 3u) * 2u) * 8u;
+    const unsigned col0 = blockIdx.y * a.cols_per_block;
+    const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
+    if (col0 >= col1) return;
+    const unsigned n_it = (col1 - col0) * a.n_cosets;
+    auto request = [&](unsigned col, unsigned c) {
+        const char __attribute__((address_space(1))) *src =
+            (const char __attribute__((address_space(1))) *)uniform_gptr(a.in + (size_t)col * a.in_col_stride + lo0) + dma_off;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 piece = wave * 8u + k;
+            __builtin_amdgcn_global_load_lds((f10_gsrc)(src + (((size_t)piece * 16u) << s_log) * 8u), (f10_ldst)(lds + piece * 128u), 16, 0, 0);
+        }
+        const char __attribute__((address_space(1))) *tsrc =
+            (const char __attribute__((address_space(1))) *)uniform_gptr(a.tw + (size_t)c * 1024u + wave * 128u) + lane * 16u;
+        __builtin_amdgcn_global_load_lds((f10_gsrc)tsrc, (f10_ldst)(lds_tw + wave * 128u), 16, 0, 0);
+    };
+    request(col0, 0);
+    unsigned col = col0, c = 0;
+    for (unsigned it = 0; it < n_it; it++) {
+        // opaque copies: the sixteen xor-ed indices of an arrangement are formed where they are used, not hoisted out of the loop
+        u32 jB1 = ixB1, jB2 = ixB2, jC = ixC;
+        asm volatile("" : "+v"(jB1), "+v"(jB2), "+v"(jC));
+        if (it == 0)
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // this iteration's nine pieces have landed; the last eight stores may still fly
+        u64 x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = lds[i * 512 + t];
+        radix16_tab<UNIT_FIRST>(x, lds_tw, 0, 1, 3, 7);
+#pragma unroll
+        for (int i = 0; i < 16; i++) lds[i * 512 + t] = x[i];          // in place: no barrier between the read and this write
+        BJ_R16_SYNC_LDS();
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = f10_at(lds, jB1 + i * 256u);
+        BJ_R16_SYNC_LDS();   // everybody has read the linear arrangement before anybody writes the swizzled one
+        radix16_tab<false>(x, lds_tw, 15u + mhB, 31u + 2u * mhB, 63u + 4u * mhB, 127u + 8u * mhB);
+#pragma unroll
+        for (int i = 0; i < 16; i++) f10_at(lds, jB2 ^ (f10_bc(i * 4u, 0) * 8u)) = x[i];
+        const u64 w8 = lds_tw[255u + m92], w9a = lds_tw[511u + 2u * m92], w9b = lds_tw[512u + 2u * m92];
+        BJ_R16_SYNC_LDS();
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = f10_at(lds, jC ^ (f10_bc(i >> 2, i & 3) * 8u));
+        BJ_R16_SYNC_LDS();   // tile and table are dead: the next iteration's pieces may land
+        const unsigned c_now = c, col_now = col;
+        if (++c == a.n_cosets) c = 0, col++;
+        if (it + 1 < n_it) request(col, c);
+        // round 8: mid bit 1 (registers 8 apart), group m92; round 9: mid bit 0 (registers 4 apart), groups 2 m92, 2 m92 + 1
+#pragma unroll
+        for (int ll = 0; ll < 4; ll += 2) {
+            gl::butterfly2_weak(x[ll], x[8 + ll], w8, x[4 + ll], x[12 + ll], w8);
+            gl::butterfly2_weak(x[ll + 1], x[9 + ll], w8, x[5 + ll], x[13 + ll], w8);
+        }
+#pragma unroll
+        for (int ll = 0; ll < 4; ll++) gl::butterfly2_weak(x[ll], x[4 + ll], w9a, x[8 + ll], x[12 + ll], w9b);
+        const gptr dst = (gptr)uniform_gptr(a.out + (size_t)col_now * a.out_col_stride + (size_t)c_now * n + lo0);
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+            st_off2(dst + ((size_t)mm << s_log), offC, x[4 * mm], x[4 * mm + 1]);
+            st_off2(dst + ((size_t)mm << s_log), offC + 16u, x[4 * mm + 2], x[4 * mm + 3]);
+        }
+    }
+}
+
 static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_cosets) {
     // amortise the per-workgroup twiddle preparation over several columns, but keep >= ~4096 workgroups in flight
 #ifndef BJ_R16_CPB
@@ -624,6 +781,25 @@ void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
         hipLaunchKernelGGL(ntt_first5_kernel<true>, grid, dim3(256), 0, s, a, n_cosets);
     else
         hipLaunchKernelGGL(ntt_first5_kernel<false>, grid, dim3(256), 0, s, a, n_cosets);
+}
+
+// first ten rounds of all cosets (log_n == 22); d_table: n_cosets * 1024 words of device scratch for the twiddle table
+void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
+                        unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s) {
+    hipLaunchKernelGGL(front10_table_kernel, dim3(n_cosets * 4), dim3(256), 0, s, d_table, tw, round_scale, n_cosets);
+    const unsigned tiles = 1u << (log_n - 13);
+    const size_t n = (size_t)1 << log_n;
+    for (unsigned c0 = 0; c0 < n_cosets; c0 += 8) {   // eight cosets per launch (their step-A twiddles share one LDS block)
+        const unsigned nc = n_cosets - c0 < 8 ? n_cosets - c0 : 8;
+        unsigned cpb = 4;
+        while (cpb > 1 && (size_t)tiles * ((n_cols + cpb - 1) / cpb) < 2048) cpb >>= 1;
+        F10Args a{in, out + (size_t)c0 * n, d_table + (size_t)c0 * 1024, log_n, n_cols, cpb, nc, in_col_stride, out_col_stride};
+        dim3 grid(tiles, (n_cols + cpb - 1) / cpb, 1);
+        if (round_scale)
+            hipLaunchKernelGGL(ntt_front10_kernel<false>, grid, dim3(512), 0, s, a);
+        else
+            hipLaunchKernelGGL(ntt_front10_kernel<true>, grid, dim3(512), 0, s, a);
+    }
 }
 
 }  // namespace bj
