@@ -103,6 +103,12 @@ static constexpr u32 LDS_ELEMS = TILE + TILE / 16;
 #endif
 
 __device__ __forceinline__ u32 pad(u32 l) { return l + (l >> 4); }
+__device__ __forceinline__ void set_prio(int p) {   // s_setprio takes an immediate: p is a constant after unrolling
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 // wave-uniform base pointer + 32-bit per-lane BYTE offset: the shape the compiler turns into `global_load v, v_off, s[base]`
 // (the empty asm pins the base in an SGPR pair: without it the optimiser re-associates base + offset into sixteen hoisted
 // 64-bit per-lane addresses)
@@ -162,10 +168,14 @@ __device__ __forceinline__ void load_step_twiddles(u64 (&tw)[15], const u64 *__r
 // gl::butterfly2_weak, nothing is canonicalised in between (the last pass does it once per element when it stores).
 // tw: the step's 15 twiddles, in registers (array) or in LDS (pointer) — indexed by constants after unrolling either way.
 // FIRST_S = 2 runs only the last two of the four rounds (the local pass after a front pass that has already done the other two).
-template <bool UNIT_FIRST, int FIRST_S = 0>
+// PRIO: the wave lowers its issue priority round by round (3, 2, 1, 0): the SIMD's arbiter serves the oldest wave first, so the waves
+// of a workgroup would reach the barrier behind the step one after the other and the last one would compute alone; with the
+// priority falling as a wave advances, the wave that is behind is served first and they arrive together (ntt_front10)
+template <bool UNIT_FIRST, int FIRST_S = 0, bool PRIO = false>
 __device__ __forceinline__ void radix16(u64 (&x)[16], const u64 *tw) {
 #pragma unroll
     for (int s = FIRST_S; s < 3; s++) {
+        if (PRIO) set_prio(3 - s);
         const int half = 8 >> s;
 #pragma unroll
         for (int g = 0; g < (1 << s); g++) {
@@ -180,6 +190,7 @@ __device__ __forceinline__ void radix16(u64 (&x)[16], const u64 *tw) {
             }
         }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int g = 0; g < 8; g += 2)   // last round: neighbours, one twiddle per pair
         gl::butterfly2_weak(x[2 * g], x[2 * g + 1], tw[7 + g], x[2 * g + 2], x[2 * g + 3], tw[8 + g]);
@@ -567,17 +578,20 @@ __global__ void front10_table_kernel(u64 *out, const u64 *__restrict__ T, const 
 }
 // The B -> C index map is LINEAR over GF(2) in the bits of (lane, register): index(lane, i) = index(lane, 0) ^ index(0, i), so a lane
 // keeps ONE value for it and reaches register i's slot with one v_xor by a literal (padding would need sixteen live addresses).
-__host__ __device__ constexpr u32 f10_bc(u32 m, u32 l) {   // transpose B -> C
-    const u32 x = l * 1024u + m;
-    return x ^ (((x >> 5) ^ (x >> 8) ^ (x >> 11)) & 31u);
+// It permutes the low five index bits only: the 1024 elements of a wave's region stay inside it.  LB = log2(lo values per tile).
+template <int LB>
+__host__ __device__ constexpr u32 f10_bc(u32 m, u32 l) {
+    const u32 x = (m << LB) + l;
+    return LB == 3 ? x ^ (((x >> 3) ^ (x >> 5)) & 31u) : x ^ (((x >> 2) ^ (x >> 4)) & 31u);
 }
 __device__ __forceinline__ u64 &f10_at(u64 *lds, u32 byte_index) { return *reinterpret_cast<u64 *>(reinterpret_cast<char *>(lds) + byte_index); }
 // four rounds on 16 registers, stage s reading its 2^s twiddles at tw[off_s + g] (one table for all ten rounds of a coset)
-template <bool UNIT_FIRST>
+template <bool UNIT_FIRST, bool PRIO>
 __device__ __forceinline__ void radix16_tab(u64 (&x)[16], const u64 *tw, u32 o0, u32 o1, u32 o2, u32 o3) {
     const u32 off[4] = {o0, o1, o2, o3};
 #pragma unroll
     for (int s = 0; s < 3; s++) {
+        if (PRIO) set_prio(3 - s);
         const int half = 8 >> s;
 #pragma unroll
         for (int g = 0; g < (1 << s); g++) {
@@ -592,92 +606,121 @@ __device__ __forceinline__ void radix16_tab(u64 (&x)[16], const u64 *tw, u32 o0,
             }
         }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int g = 0; g < 8; g += 2)
         gl::butterfly2_weak(x[2 * g], x[2 * g + 1], tw[off[3] + g], x[2 * g + 2], x[2 * g + 3], tw[off[3] + g + 1]);
 }
 typedef const void __attribute__((address_space(1))) *f10_gsrc;
 typedef void __attribute__((address_space(3))) *f10_ldst;
-// The inputs of the NEXT (column, coset) iteration travel by LDS-DMA (global_load_lds_dwordx4: no destination registers) while
-// this iteration's last step computes and stores: eight 1-KB pieces of the tile and one of the coset's twiddle table per wave.
-// They are issued BEFORE this iteration's eight stores, so the counted wait at the top of the next iteration (vmcnt(8): VMEM
-// operations retire in order) leaves the stores in flight; the barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).
-template <bool UNIT_FIRST>
-__global__ void __launch_bounds__(512, 4) ntt_front10_kernel(F10Args a) {
-    __shared__ u64 lds[8192 + 1024];      // ONE object: the tile (64 KB) and the twiddle table of the coset being processed (8 KB)
-    u64 *lds_tw = lds + 8192;
+// A workgroup (8 waves) owns ONE (tile, coset) and loops over columns.  The eight cosets of a tile are eight workgroups that the
+// dispatcher places on ONE XCD at the same time (block b runs on XCD b % 8: b = ((window * n_cosets + coset) * 2 + half) * 8 + xcd), so the
+// tile crosses the fabric once and the other seven reads hit that XCD's L2 (measured with the cosets looped INSIDE a workgroup
+// instead: FETCH_SIZE = 8 x the input, the pass ran at 4 TB/s of L2-miss traffic).  Data flow of one column:
+//   the tile arrives by LDS-DMA (global_load_lds_dwordx4: no destination registers), wave w fetching the eight 1-KB pieces of
+//   region w = mid bits 9..7; it is requested BEFORE the previous column's eight stores, so the counted wait at the top
+//   (vmcnt(8): VMEM operations retire in order) leaves those stores in flight;                                    [barrier 1]
+//   step A (mid bits 9..6 in registers) reads and writes the tile in place, in the linear order the DMA left;   [barrier 2]
+//   steps B (bits 5..2) and C (bits 1..0 x four lo values) of wave w touch region w only — the B -> C transpose is an exchange
+//   among the lanes of ONE wave, ordered by the wave's own LDS queue, no barrier — and when wave w has read its step-C
+//   registers, region w is dead: it requests the next column's pieces at once, then computes step C and stores.
+// The coset's twiddle table (8 KB) is fetched once per workgroup, by LDS-DMA as well.
+#ifndef BJ_F10_PRIO
+#define BJ_F10_PRIO 1
+#endif
+template <bool UNIT_FIRST, int LB>
+__global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
+    constexpr u32 NT = 64u << LB, TILE_E = 1024u << LB, ROWS = 128u >> LB;   // threads, elements per tile, mid rows per 1-KB DMA piece
+    __shared__ u64 lds[TILE_E + 1024];      // ONE object: tile (64 / 128 KB), twiddle table of this workgroup's coset (8 KB)
+    u64 *lds_tw = lds + TILE_E;
     const u32 t = threadIdx.x;
     const u32 wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63u;
     const unsigned s_log = a.log_n - 10;
     const size_t n = (size_t)1 << a.log_n;
     const u32 b = blockIdx.x;
-    const u32 tile = (b & ~15u) | ((b & 7u) << 1) | ((b >> 3) & 1u);   // tiles 2u, 2u + 1 -> blocks on one XCD
-    const size_t lo0 = (size_t)tile << 3;
-    // step A: lane = (ml : mid bits 5..0, l); registers = mid bits 9..6: LDS index i * 512 + t (as the DMA leaves the tile)
+    u32 c, tile;
+    if (LB == 3) {   // tiles 2u, 2u + 1 (the halves of 128-byte lines): blocks b, b + 8 — one XCD, back to back
+        const u32 xcd = b & 7u, half = (b >> 3) & 1u, window = (b >> 4) / a.n_cosets;
+        c = (b >> 4) % a.n_cosets;
+        tile = window * 16u + xcd * 2u + half;
+    } else {
+        const u32 xcd = b & 7u, window = (b >> 3) / a.n_cosets;
+        c = (b >> 3) % a.n_cosets;
+        tile = window * 8u + xcd;
+    }
+    const size_t lo0 = (size_t)tile << LB;
+    // step A: lane = (ml : mid bits 5..0, l); registers = mid bits 9..6: LDS index i * NT + t (as the DMA leaves the tile)
     // step B: lane = (mh : mid bits 9..6, mll : bits 1..0, l); registers = bits 5..2
-    const u32 lB = t & 7u, mllB = (t >> 3) & 3u, mhB = t >> 5;
-    // step C: lane = (m92 : mid bits 9..2, l2 : lo bit 2); registers = (mid bits 1..0, lo bits 1..0)
-    const u32 l2C = t & 1u, m92 = t >> 1;
-    const u32 offC = (((m92 * 4u) << s_log) + l2C * 4u) * 8u;
-    const u32 ixB1 = ((mhB * 64u + mllB) * 8u + lB) * 8u, ixB2 = f10_bc(mhB * 64u + mllB, lB) * 8u, ixC = f10_bc(m92 * 4u, l2C * 4u) * 8u;
-    // DMA source of this lane inside a piece: piece p (of 64) = mid indices [16 p, 16 p + 16), lane = (mid & 15, lo pair)
-    const u32 dma_off = (((lane >> 2) << s_log) + (lane & 3u) * 2u) * 8u;
+    const u32 lB = t & ((1u << LB) - 1u), mllB = (t >> LB) & 3u, mhB = t >> (LB + 2);
+    // step C: lane = (m92 : mid bits 9..2, lhi : lo bits above 1..0); registers = (mid bits 1..0, lo bits 1..0)
+    const u32 lhiC = t & ((1u << (LB - 2)) - 1u), m92 = t >> (LB - 2);
+    const u32 offC = (((m92 * 4u) << s_log) + lhiC * 4u) * 8u;
+    const u32 ixB1 = (((mhB * 64u + mllB) << LB) + lB) * 8u, ixB2 = f10_bc<LB>(mhB * 64u + mllB, lB) * 8u, ixC = f10_bc<LB>(m92 * 4u, lhiC * 4u) * 8u;
+    // DMA source of this lane inside a piece: piece p = mid rows [ROWS p, ROWS (p + 1)), lane = (row, lo pair)
+    const u32 dma_off = (((lane >> (LB - 1)) << s_log) + (lane & ((1u << (LB - 1)) - 1u)) * 2u) * 8u;
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
     if (col0 >= col1) return;
-    const unsigned n_it = (col1 - col0) * a.n_cosets;
-    auto request = [&](unsigned col, unsigned c) {
+    auto request_tile = [&](unsigned col) {
         const char __attribute__((address_space(1))) *src =
             (const char __attribute__((address_space(1))) *)uniform_gptr(a.in + (size_t)col * a.in_col_stride + lo0) + dma_off;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const u32 piece = wave * 8u + k;
-            __builtin_amdgcn_global_load_lds((f10_gsrc)(src + (((size_t)piece * 16u) << s_log) * 8u), (f10_ldst)(lds + piece * 128u), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((f10_gsrc)(src + (((size_t)piece * ROWS) << s_log) * 8u), (f10_ldst)(lds + piece * 128u), 16, 0, 0);
         }
+    };
+    if (wave < 8u) {
         const char __attribute__((address_space(1))) *tsrc =
             (const char __attribute__((address_space(1))) *)uniform_gptr(a.tw + (size_t)c * 1024u + wave * 128u) + lane * 16u;
         __builtin_amdgcn_global_load_lds((f10_gsrc)tsrc, (f10_ldst)(lds_tw + wave * 128u), 16, 0, 0);
-    };
-    request(col0, 0);
-    unsigned col = col0, c = 0;
-    for (unsigned it = 0; it < n_it; it++) {
+    }
+    request_tile(col0);
+    const gptr dst0 = (gptr)uniform_gptr(a.out + (size_t)c * n + lo0);
+    for (unsigned col = col0; col < col1; col++) {
         // opaque copies: the sixteen xor-ed indices of an arrangement are formed where they are used, not hoisted out of the loop
         u32 jB1 = ixB1, jB2 = ixB2, jC = ixC;
         asm volatile("" : "+v"(jB1), "+v"(jB2), "+v"(jC));
-        if (it == 0)
+        if (col == col0)
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // this iteration's nine pieces have landed; the last eight stores may still fly
+#ifdef BJ_F10_AB_NOWAIT   // timing experiment (wrong results): what the pass would cost if the tile were always there
+            asm volatile("s_barrier" ::: "memory");
+#else
+            asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");   // this column's pieces have landed; the last eight stores may still fly
+#endif
         u64 x[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) x[i] = lds[i * 512 + t];
-        radix16_tab<UNIT_FIRST>(x, lds_tw, 0, 1, 3, 7);
+        for (int i = 0; i < 16; i++) x[i] = lds[i * NT + t];
+        radix16<UNIT_FIRST, 0, BJ_F10_PRIO>(x, lds_tw);
 #pragma unroll
-        for (int i = 0; i < 16; i++) lds[i * 512 + t] = x[i];          // in place: no barrier between the read and this write
+        for (int i = 0; i < 16; i++) lds[i * NT + t] = x[i];          // in place: no barrier between the read and this write
+#ifdef BJ_F10_AB_NOBAR2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         BJ_R16_SYNC_LDS();
+#endif
 #pragma unroll
-        for (int i = 0; i < 16; i++) x[i] = f10_at(lds, jB1 + i * 256u);
-        BJ_R16_SYNC_LDS();   // everybody has read the linear arrangement before anybody writes the swizzled one
-        radix16_tab<false>(x, lds_tw, 15u + mhB, 31u + 2u * mhB, 63u + 4u * mhB, 127u + 8u * mhB);
+        for (int i = 0; i < 16; i++) x[i] = f10_at(lds, jB1 + i * (32u << LB));
+        radix16_tab<false, BJ_F10_PRIO>(x, lds_tw, 15u + mhB, 31u + 2u * mhB, 63u + 4u * mhB, 127u + 8u * mhB);
 #pragma unroll
-        for (int i = 0; i < 16; i++) f10_at(lds, jB2 ^ (f10_bc(i * 4u, 0) * 8u)) = x[i];
+        for (int i = 0; i < 16; i++) f10_at(lds, jB2 ^ (f10_bc<LB>(i * 4u, 0) * 8u)) = x[i];      // inside this wave's region
         const u64 w8 = lds_tw[255u + m92], w9a = lds_tw[511u + 2u * m92], w9b = lds_tw[512u + 2u * m92];
-        BJ_R16_SYNC_LDS();
 #pragma unroll
-        for (int i = 0; i < 16; i++) x[i] = f10_at(lds, jC ^ (f10_bc(i >> 2, i & 3) * 8u));
-        BJ_R16_SYNC_LDS();   // tile and table are dead: the next iteration's pieces may land
-        const unsigned c_now = c, col_now = col;
-        if (++c == a.n_cosets) c = 0, col++;
-        if (it + 1 < n_it) request(col, c);
+        for (int i = 0; i < 16; i++) x[i] = f10_at(lds, jC ^ (f10_bc<LB>(i >> 2, i & 3) * 8u));     // written by lanes of this wave
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of its region are complete: the region is dead
+        if (col + 1 < col1) request_tile(col + 1);
         // round 8: mid bit 1 (registers 8 apart), group m92; round 9: mid bit 0 (registers 4 apart), groups 2 m92, 2 m92 + 1
+        if (BJ_F10_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ll = 0; ll < 4; ll += 2) {
             gl::butterfly2_weak(x[ll], x[8 + ll], w8, x[4 + ll], x[12 + ll], w8);
             gl::butterfly2_weak(x[ll + 1], x[9 + ll], w8, x[5 + ll], x[13 + ll], w8);
         }
+        if (BJ_F10_PRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int ll = 0; ll < 4; ll++) gl::butterfly2_weak(x[ll], x[4 + ll], w9a, x[8 + ll], x[12 + ll], w9b);
-        const gptr dst = (gptr)uniform_gptr(a.out + (size_t)col_now * a.out_col_stride + (size_t)c_now * n + lo0);
+        const gptr dst = dst0 + (size_t)col * a.out_col_stride;
 #pragma unroll
         for (int mm = 0; mm < 4; mm++) {
             st_off2(dst + ((size_t)mm << s_log), offC, x[4 * mm], x[4 * mm + 1]);
@@ -784,21 +827,25 @@ void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
 }
 
 // first ten rounds of all cosets (log_n == 22); d_table: n_cosets * 1024 words of device scratch for the twiddle table
+#ifndef BJ_F10_LB
+#define BJ_F10_LB 4   // lo values per tile = 2^LB: 3 -> 64-byte runs, 512 threads, two workgroups per CU; 4 -> full lines, 1024 threads, one
+#endif
 void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
                         unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s) {
     hipLaunchKernelGGL(front10_table_kernel, dim3(n_cosets * 4), dim3(256), 0, s, d_table, tw, round_scale, n_cosets);
-    const unsigned tiles = 1u << (log_n - 13);
+    constexpr int LB = BJ_F10_LB;
+    const unsigned tiles = 1u << (log_n - 10 - LB);
     const size_t n = (size_t)1 << log_n;
-    for (unsigned c0 = 0; c0 < n_cosets; c0 += 8) {   // eight cosets per launch (their step-A twiddles share one LDS block)
+    for (unsigned c0 = 0; c0 < n_cosets; c0 += 8) {   // at most eight cosets per launch: a tile's workgroups are one dispatch window on one XCD
         const unsigned nc = n_cosets - c0 < 8 ? n_cosets - c0 : 8;
-        unsigned cpb = 4;
-        while (cpb > 1 && (size_t)tiles * ((n_cols + cpb - 1) / cpb) < 2048) cpb >>= 1;
+        unsigned cpb = 8;
+        while (cpb > 1 && (size_t)tiles * nc * ((n_cols + cpb - 1) / cpb) < 4096) cpb >>= 1;
         F10Args a{in, out + (size_t)c0 * n, d_table + (size_t)c0 * 1024, log_n, n_cols, cpb, nc, in_col_stride, out_col_stride};
-        dim3 grid(tiles, (n_cols + cpb - 1) / cpb, 1);
+        dim3 grid(tiles * nc, (n_cols + cpb - 1) / cpb, 1);
         if (round_scale)
-            hipLaunchKernelGGL(ntt_front10_kernel<false>, grid, dim3(512), 0, s, a);
+            hipLaunchKernelGGL((ntt_front10_kernel<false, LB>), grid, dim3(64u << LB), 0, s, a);
         else
-            hipLaunchKernelGGL(ntt_front10_kernel<true>, grid, dim3(512), 0, s, a);
+            hipLaunchKernelGGL((ntt_front10_kernel<true, LB>), grid, dim3(64u << LB), 0, s, a);
     }
 }
 
