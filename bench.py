@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the secondary throughput leg with two proofs in flight on one GPU")
     ap.add_argument("--no-scale-replay", action="store_true", help="skip the one-rank-alone measurement of the sharded proof at W = 2, 4, 8")
-    ap.add_argument("--replay-world", type=str, default="2,4,8",
+    ap.add_argument("--replay-world", "--scale-replay", dest="replay_world", type=str, default="2,4,8",
                     help="world sizes of the scale_replay leg (era_boojum_amd/scale_replay.py): rank r of a W-rank proof alone on this "
                          "GPU with its peers' all-gathered buffers replayed from a recording")
     ap.add_argument("--replay-steps", type=int, default=3)
@@ -343,6 +343,13 @@ def main():
         "scaling": "weak" if (args.mode == "replicas") else "strong",   # --gpus N shards the SAME 2^22-row proof: total work fixed
         "vs_baseline": None,
         "dtype": "u64",
+        "hbm_gb": {"what": "HBM this rank holds for the proof: its setup (bj_setup_device_bytes: natural columns, monomials, LDE shard, tree), the "
+                           "proof workspace (bj_proof_workspace_bytes: reserved, high-water mark; overflow slabs must be 0) and the resident witness",
+                   "setup": round(setup.device_bytes() / 1e9, 2),
+                   "workspace_reserved": round(setup.last_workspace["reserved_bytes"] / 1e9, 2),
+                   "workspace_high_water": round(setup.last_workspace["high_water_bytes"] / 1e9, 2),
+                   "workspace_overflow_slabs": setup.last_workspace["overflow_slabs"],
+                   "witness": round((d_vars.numel() + d_mult.numel()) * 8 / 1e9, 2)},
         "data": "synthetic input (seeded random message bytes) through the real SHA-256 circuit" if circuit_name.startswith("SHA-256")
                 else "synthetic (random satisfiable circuit of the bench geometry)",
         "config": {"workload": "%s: full prove of the SHA-256 circuit, 2^%d rows (92 variable + 1 multiplicity "
@@ -528,16 +535,20 @@ def main():
         # one rank of the sharded proof alone on this GPU, peers replayed (the only multi-GPU evidence one GPU can give)
         from era_boojum_amd import scale_replay
         t1_ms = elapsed / args.steps * 1e3
-        setup.close()                         # the single-GPU setup and arena make room for the W rank contexts
+        setup_cap = setup.cap()
+        single_mem = {"setup_bytes": setup.device_bytes(), "workspace": dict(setup.last_workspace)}
+        setup.close()                         # the single-GPU setup and arena make room for the W rank setups
         ctx.release_workspace()
         torch.cuda.empty_cache()
         sr = {"what": "rank r of a W-rank sharded proof ALONE on this GPU, every all-gather served by a device copy of the buffer "
-                      "recorded in a W-thread run of the same proof (bj_comm_replay_create); ms per proof = kernels + launches + host "
-                      "round trips of one rank; link time and waiting for peers excluded; every replayed proof = the single-GPU bytes",
+                      "that collective gathers (recorded one collective at a time with one rank on the device: bj_comm_replay_capture); "
+                      "ms per proof = kernels + launches + host round trips of one rank; link time and waiting for peers excluded; "
+                      "every replayed proof = the single-GPU bytes; hbm_per_rank_gb = the rank's setup (bj_setup_device_bytes) + the "
+                      "high-water mark of its proof workspace (bj_proof_workspace_bytes)",
               "single_gpu_ms": round(t1_ms, 3), "steps": args.replay_steps,
-              "model_ms_from_tools_scale_model": {"2": 145.4, "4": 87.1, "8": 57.9, "note": "kernel-table model incl. its link term "
-                                                  "(1.7 / 2.3 / 2.7 ms, ring-bound all-gather at one 150 GB/s xGMI link per rank); per-proof constant "
-                                                  "re-fitted in round 5 to the replayed ranks"} if (log_n == 22 and args.fri_lde == 8) else None,
+              "single_gpu_hbm_gb": {"setup": round(single_mem["setup_bytes"] / 1e9, 2),
+                                    "workspace_high_water": round(single_mem["workspace"]["high_water_bytes"] / 1e9, 2),
+                                    "workspace_reserved": round(single_mem["workspace"]["reserved_bytes"] / 1e9, 2)},
               "worlds": {}}
         import threading
         for w in [int(x) for x in args.replay_world.split(",") if x]:
@@ -556,19 +567,25 @@ def main():
                         torch.cuda.set_device(local_rank)
                         box["r"] = scale_replay.measure(circuit, w, args.fri_lde, args.cap, args.security, args.transcript,
                                                         steps=args.replay_steps, warmup=1, device=local_rank, reference_proof=proof_buf,
-                                                        d_vars=d_vars, d_mult=d_mult)
+                                                        d_vars=d_vars, d_mult=d_mult, setup_cap=setup_cap)
                     except BaseException as e:    # noqa: BLE001
                         box["e"] = e
 
                 th = threading.Thread(target=leg, daemon=True)
                 th.start()
-                th.join(float(os.environ.get("BJ_BENCH_REPLAY_TIMEOUT_S", "240")))
+                th.join(float(os.environ.get("BJ_BENCH_REPLAY_TIMEOUT_S", str(240 << max(0, log_n - 22)))))
                 if th.is_alive():
                     stuck_legs.append("scale_replay W=%d" % w)
                     raise TimeoutError("did not finish within the watchdog")
                 if "e" in box:
                     raise box["e"]
                 r = box["r"]
+                r["hbm_per_rank_gb"] = {"setup": round(max(v["setup_bytes"] for v in r["ranks"].values()) / 1e9, 2),
+                                        "workspace_high_water": round(max(v["workspace"]["high_water_bytes"] for v in r["ranks"].values()) / 1e9, 2),
+                                        "workspace_reserved": round(max(v["workspace"]["reserved_bytes"] for v in r["ranks"].values()) / 1e9, 2)}
+                for v in r["ranks"].values():
+                    v.pop("setup_bytes", None)
+                    v.pop("workspace", None)
                 # T(W) = R + S / W and T(1) = R + S give the replicated part R the measurement implies
                 r["implied_replicated_ms"] = round((w * r["max_ms"] - t1_ms) / (w - 1), 2)
                 r["speedup_compute_only"] = round(t1_ms / r["max_ms"], 3)

@@ -71,6 +71,8 @@ _SIGNATURES = {
     "bj_comm_replay_create": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     "bj_comm_replay_destroy": (None, [C.c_void_p]),
     "bj_comm_replay_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "bj_comm_replay_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bj_comm_replay_captured": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "bj_gate_program_generated": (C.c_int, [C.c_void_p]),
     "bj_gate_program_canonical_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_gate_program_emit_body": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -84,6 +86,7 @@ _SIGNATURES = {
                                           C.POINTER(C.c_void_p)]),
     "bj_setup_destroy": (None, [C.c_void_p]),
     "bj_setup_cap": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_setup_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "bj_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_proof_destroy": (None, [C.c_void_p]),
@@ -95,6 +98,7 @@ _SIGNATURES = {
     "bj_prove_from_dumps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                       C.POINTER(C.c_void_p)]),
     "bj_proof_stage_ms": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bj_proof_workspace_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bj_proof_kernel_stats": (C.c_int, [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_proof_comm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bj_fri_fold_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint64, C.c_uint64, C.c_uint64]),
@@ -136,7 +140,7 @@ def exported_symbols():
 _lib = None
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def load_library():
@@ -638,14 +642,27 @@ class ReplayComm:
     answered by a device copy of what that collective gathered in a real run.  `recorded` = [(device pointer, bytes)] in call
     order: n_setup buffers for the setup's collectives, then the buffers of one proof (used cyclically)."""
 
-    def __init__(self, ctx, rank, world, recorded, n_setup=0, verify=False):
+    def __init__(self, ctx, rank, world, recorded, n_setup=0, verify=False, keepalive=None, capture=None):
+        """keepalive: whatever owns the recorded device buffers (e.g. the list of torch tensors) — held for the life of the comm.
+        capture = (device pointer, capacity in bytes): the first collective past the recorded ones is not served; this rank's
+        contribution is copied there and the call fails, ending the proof (bj_comm_replay_capture); `captured` then says how many
+        bytes were taken."""
         self._ctx, self._lib = ctx, ctx._lib
         self.rank, self.world = rank, world
+        self._keep = keepalive
         self._ptrs = (C.c_void_p * max(1, len(recorded)))(*[p for p, _ in recorded])
         self._sizes = (C.c_size_t * max(1, len(recorded)))(*[b for _, b in recorded])
         self.struct = _Comm()
         ctx._check(self._lib.bj_comm_replay_create(ctx._h, rank, world, self._ptrs, self._sizes, n_setup, len(recorded) - n_setup,
                                                    1 if verify else 0, C.byref(self.struct)))
+        if capture is not None:
+            ctx._check(self._lib.bj_comm_replay_capture(C.byref(self.struct), C.c_void_p(capture[0]), capture[1]))
+
+    @property
+    def captured(self):
+        b = C.c_size_t()
+        self._lib.bj_comm_replay_captured(C.byref(self.struct), C.byref(b))
+        return int(b.value)
 
     def stats(self):
         a, b, m = C.c_size_t(), C.c_size_t(), C.c_size_t()
@@ -843,6 +860,12 @@ class ProverSetup:
                                                      C.byref(comm.struct) if comm is not None else None, C.byref(h)))
         self._h = h
 
+    def device_bytes(self):
+        """HBM held by this setup (its shard when sharded): bj_setup_device_bytes."""
+        b = C.c_size_t()
+        self._ctx._check(self._lib.bj_setup_device_bytes(self._h, C.byref(b)))
+        return int(b.value)
+
     def set_comm(self, comm):
         """bj_setup_set_comm: another transport for the same shard (same rank / world)."""
         self._ctx._check(self._lib.bj_setup_set_comm(self._h, C.byref(comm.struct)))
@@ -878,7 +901,15 @@ class ProverSetup:
         while self._lib.bj_proof_kernel_stats(h, k, C.byref(name), C.byref(kms), C.byref(kb)) == 0:
             self.last_kernels[name.value.decode()] = (float(kms.value), float(kb.value))
             k += 1
+        res, hw, slabs = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._lib.bj_proof_workspace_bytes(h, C.byref(res), C.byref(hw), C.byref(slabs))
+        self.last_workspace = {"reserved_bytes": int(res.value), "high_water_bytes": int(hw.value), "overflow_slabs": int(slabs.value)}
         self._lib.bj_proof_destroy(h)
+        if slabs.value and not os.environ.get("BJ_ALLOW_WORKSPACE_OVERFLOW"):
+            # the proof is right, but the reservation of prove_impl was not an upper bound for this geometry: every proof the test
+            # suite makes passes through here, so the list of buffers in csrc/prover.hip cannot drift away from the allocations
+            raise BoojumHipError("the proof needed %d overflow slab(s): reserved %d bytes, high-water mark %d bytes"
+                                 % (slabs.value, res.value, hw.value))
         stages = dict(zip(STAGE_NAMES, [float(x) for x in ms][:7]))
         stages["witness_tree_leaf_kernel"] = float(ms[7])
         return buf, stages

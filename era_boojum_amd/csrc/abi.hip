@@ -64,8 +64,18 @@ int ensure_scratch(bj_ctx *ctx, size_t elems) {
     return BJ_OK;
 }
 
+int arena_drop_slabs(bj_ctx *ctx) {
+    if (ctx->arena_slabs.empty()) return BJ_OK;
+    BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sl : ctx->arena_slabs) (void)hipFree(sl.first);
+    ctx->arena_slabs.clear();
+    ctx->slab_off = 0;
+    return BJ_OK;
+}
 int arena_reset(bj_ctx *ctx, size_t need_elems) {
     ctx->arena_off = 0;
+    ctx->arena_high_water = 0;
+    if (int rc = arena_drop_slabs(ctx)) return rc;
     if (need_elems <= ctx->arena_elems) return BJ_OK;
     if (ctx->arena) {
         BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -119,10 +129,31 @@ int h2d_async(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
 }
 
 u64 *arena_alloc(bj_ctx *ctx, size_t elems) {
-    size_t start = (ctx->arena_off + 63) & ~(size_t)63;   // 512-byte alignment
-    if (start + elems > ctx->arena_elems) return nullptr;
-    ctx->arena_off = start + elems;
-    return ctx->arena + start;
+    const size_t start = (ctx->arena_off + 63) & ~(size_t)63;   // 512-byte alignment
+    if (ctx->arena_slabs.empty() && start + elems <= ctx->arena_elems) {
+        ctx->arena_off = start + elems;
+        if (ctx->arena_off > ctx->arena_high_water) ctx->arena_high_water = ctx->arena_off;
+        return ctx->arena + start;
+    }
+    // the reservation was too small: overflow slabs (only inside a proof: the arena belongs to the proof in flight)
+    if (!ctx->in_proof) return nullptr;
+    if (!ctx->arena_slabs.empty()) {
+        auto &last = ctx->arena_slabs.back();
+        const size_t st = (ctx->slab_off + 63) & ~(size_t)63;
+        if (st + elems <= last.second) {
+            ctx->slab_off = st + elems;
+            ctx->arena_high_water += elems + 64;
+            return last.first + st;
+        }
+    }
+    const size_t slab = elems > ((size_t)1 << 25) ? elems : ((size_t)1 << 25);   // at least 256 MiB
+    u64 *p = nullptr;
+    if (hipMalloc((void **)&p, slab * sizeof(u64)) != hipSuccess) return nullptr;
+    ctx->arena_slabs.emplace_back(p, slab);
+    ctx->slab_off = elems;
+    if (ctx->arena_high_water < ctx->arena_off) ctx->arena_high_water = ctx->arena_off;
+    ctx->arena_high_water += elems + 64;
+    return p;
 }
 
 
@@ -255,6 +286,7 @@ void bj_ctx_destroy(bj_ctx *ctx) {
         for (hipEvent_t e : p.ev)
             if (e) (void)hipEventDestroy(e);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    for (auto &sl : ctx->arena_slabs) (void)hipFree(sl.first);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -266,9 +298,11 @@ int bj_ctx_release_workspace(bj_ctx *ctx) {
     if (ctx->in_proof) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ctx_release_workspace: a proof is running");
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->copy_stream) BJ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (int rc = bj::arena_drop_slabs(ctx)) return rc;
     if (ctx->arena) BJ_HIP(ctx, hipFree(ctx->arena));
     ctx->arena = nullptr;
     ctx->arena_elems = ctx->arena_off = 0;
+    ctx->arena_learned = 0;
     if (ctx->d_scratch) BJ_HIP(ctx, hipFree(ctx->d_scratch));
     ctx->d_scratch = nullptr;
     ctx->scratch_elems = 0;
@@ -408,12 +442,21 @@ int bj_intt_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned l
     coset = gl::canon(coset);
     if (coset == 0) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_intt_batch: coset shift must be non-zero");
     const size_t n = (size_t)1 << log_n;
-    // butterflies with inverse twiddles into scratch (bit-reversed), then un-reverse + scale into d_out
-    if (int rc = ensure_scratch(ctx, (size_t)n_cols * n)) return rc;
-    bj::launch_ntt_passes(d_in, ctx->d_scratch, ctx->tw_inv, nullptr, log_n, n_cols, 1, col_stride, n, ctx->stream, bj::front_table(ctx));
-    u64 n_inv = log_n ? gl::inv(gl::canon((u64)n % gl::P)) : 1;
-    u64 step = coset == 1 ? 1 : gl::inv(coset);
-    bj::launch_bitrev_scale(ctx->d_scratch, d_out, log_n, n_cols, n, col_stride, n_inv, step, ctx->stream);
+    // butterflies with inverse twiddles into scratch (bit-reversed), then un-reverse + scale into d_out — in groups of columns whose
+    // scratch stays below 1 GiB (the groups of a wide batch run back to back on the stream; a 2^23-row witness would otherwise
+    // keep 6 GB of scratch per context: eight sharded ranks on one device could not afford it)
+    const size_t cap_elems = (size_t)1 << 27;
+    unsigned group = n >= cap_elems ? 1u : (unsigned)(cap_elems / n);
+    if (group > n_cols) group = n_cols;
+    if (int rc = ensure_scratch(ctx, (size_t)group * n)) return rc;
+    const u64 n_inv = log_n ? gl::inv(gl::canon((u64)n % gl::P)) : 1;
+    const u64 step = coset == 1 ? 1 : gl::inv(coset);
+    for (unsigned c0 = 0; c0 < n_cols; c0 += group) {
+        const unsigned nc = n_cols - c0 < group ? n_cols - c0 : group;
+        bj::launch_ntt_passes(d_in + (size_t)c0 * col_stride, ctx->d_scratch, ctx->tw_inv, nullptr, log_n, nc, 1, col_stride, n, ctx->stream,
+                              bj::front_table(ctx));
+        bj::launch_bitrev_scale(ctx->d_scratch, d_out + (size_t)c0 * col_stride, log_n, nc, n, col_stride, n_inv, step, ctx->stream);
+    }
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }

@@ -19,20 +19,37 @@ struct ReplayComm {
     size_t calls = 0, bytes = 0, mismatches = 0;
     int verify = 0;
     std::vector<unsigned char> h_a, h_b;
+    // capture (bj_comm_replay_capture): the FIRST collective past the recorded ones is not served — this rank's contribution
+    // to it is copied out and the call fails with BJ_REPLAY_CAPTURED, which ends the proof.  That is how a recording is made
+    // one collective at a time with ONE rank on the device at a time (era_boojum_amd/scale_replay.py): collective k of rank r is
+    // what r contributes after k replayed ones, and every rank receives the same gathered bytes.
+    void *d_capture = nullptr;
+    size_t capture_capacity = 0, captured = 0;
 };
+constexpr int BJ_REPLAY_CAPTURED = 77;
 
 int replay_on_stream(void *user, const void *d_send, void *d_recv, size_t bytes, void *stream) {
     ReplayComm *c = (ReplayComm *)user;
     size_t k = c->calls;
-    if (k >= c->n_setup) {
+    hipStream_t st = (hipStream_t)stream;
+    if (c->d_capture && k == c->blobs.size()) {   // the first collective nobody has recorded yet
+        if (bytes > c->capture_capacity) return -5;
+        if (hipMemcpyAsync(c->d_capture, d_send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return -4;
+        if (hipStreamSynchronize(st) != hipSuccess) return -4;
+        c->captured = bytes;
+        return BJ_REPLAY_CAPTURED;
+    }
+    if (k >= c->n_setup && !c->d_capture) {
         if (!c->n_cycle) return -2;
         k = c->n_setup + (k - c->n_setup) % c->n_cycle;
     }
     if (k >= c->blobs.size() || c->sizes[k] != bytes * c->world) return -3;   // not the collective that was recorded here
     c->calls++;
     c->bytes += bytes * c->world;
-    hipStream_t st = (hipStream_t)stream;
-    if (c->verify) {   // this rank's own contribution must be the slice the recording has for it
+    // without `verify` the first collective of every proof is compared all the same (a cap fragment: a few hundred bytes): a
+    // recording of another witness or configuration of the same shape does not go unnoticed
+    const bool first_of_proof = c->n_cycle && k == c->n_setup;
+    if (c->verify || first_of_proof) {   // this rank's own contribution must be the slice the recording has for it
         c->h_a.resize(bytes);
         c->h_b.resize(bytes);
         if (hipMemcpyAsync(c->h_a.data(), d_send, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -4;
@@ -85,6 +102,19 @@ void bj_comm_replay_destroy(bj_comm *comm) {
     std::memset(comm, 0, sizeof(*comm));
 }
 
+int bj_comm_replay_capture(bj_comm *comm, void *d_capture, size_t capacity_bytes) {
+    if (!comm || comm->all_gather_stream != replay_on_stream || !comm->user || !d_capture) return BJ_ERR_INVALID_ARG;
+    ReplayComm *c = (ReplayComm *)comm->user;
+    c->d_capture = d_capture;
+    c->capture_capacity = capacity_bytes;
+    c->captured = 0;
+    return BJ_OK;
+}
+int bj_comm_replay_captured(const bj_comm *comm, size_t *bytes) {
+    if (!comm || comm->all_gather_stream != replay_on_stream || !comm->user || !bytes) return BJ_ERR_INVALID_ARG;
+    *bytes = ((const ReplayComm *)comm->user)->captured;
+    return BJ_OK;
+}
 int bj_comm_replay_stats(const bj_comm *comm, size_t *calls, size_t *bytes_received, size_t *mismatches) {
     if (!comm || comm->all_gather_stream != replay_on_stream || !comm->user) return BJ_ERR_INVALID_ARG;
     const ReplayComm *c = (const ReplayComm *)comm->user;

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 #include <string>
+#include <utility>
+#include <vector>
 
 #define BJ_MAX_KERNEL_PROBES 12
 
@@ -27,6 +29,13 @@ struct bj_ctx {
     // synchronising); grown on demand, reset at the start of every bj_prove_dev
     gl::u64 *arena = nullptr;
     size_t arena_elems = 0, arena_off = 0;
+    // A proof whose buffers outgrow the reservation does not fail: further blocks come out of overflow slabs (hipMalloc in the
+    // middle of a proof — slow, once), the proof reports its high-water mark (bj_proof_workspace_bytes) and the next reservation
+    // on this context is at least that large.  The suite asserts that no proof needed a slab (the reservation is an upper bound).
+    std::vector<std::pair<gl::u64 *, size_t>> arena_slabs;   // (base, elems), each slab bump-allocated like the arena
+    size_t slab_off = 0;                 // elements used in the last slab
+    size_t arena_high_water = 0;         // elements the proof in flight has taken (arena + slabs)
+    size_t arena_learned = 0;            // largest high-water mark seen on this context
     int hasher = BJ_HASHER_POSEIDON2;   // tree hasher of the bj_merkle_tree_* calls (bj_ctx_set_tree_hasher / bj_prove)
     bool in_proof = false;       // bj_prove_dev is running: temporaries come out of the arena instead of hipMalloc
     // pinned staging ring for the small host->device blocks between kernels (challenges, pointer tables, query indices):
@@ -69,6 +78,7 @@ int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
 inline gl::u64 *front_table(bj_ctx *ctx) { return ctx->d_small + 64 + 64 * 32 + 4096; }   // BJ_FRONT_TABLE_WORDS (kernels.h)
 int arena_reset(bj_ctx *ctx, size_t need_elems);
+int arena_drop_slabs(bj_ctx *ctx);
 gl::u64 *arena_alloc(bj_ctx *ctx, size_t elems);   // nullptr if the reservation was too small
 // short-lived device memory: from the arena inside a proof (no hipMalloc/hipFree, no implicit syncs), hipMalloc otherwise
 void *tmp_alloc(bj_ctx *ctx, size_t bytes, bool *from_arena);

@@ -114,6 +114,7 @@ struct bj_proof {
     float comm_ms = 0;             // sharded proofs: time between the start and the end of every collective on this rank, summed
     unsigned comm_calls = 0;
     size_t comm_bytes = 0;         // bytes received from the other ranks
+    size_t ws_reserved = 0, ws_high_water = 0, ws_overflow_slabs = 0;   // bj_proof_workspace_bytes
     struct KernelStat {            // bj_proof_kernel_stats: first launch of each probed kernel
         const char *name;
         float ms;
@@ -558,6 +559,26 @@ int bj_proof_kernel_stats(const bj_proof *p, unsigned index, const char **name, 
     if (algorithmic_bytes) *algorithmic_bytes = p->kernel_stats[index].bytes;
     return BJ_OK;
 }
+int bj_proof_workspace_bytes(const bj_proof *p, size_t *reserved, size_t *high_water, size_t *overflow_slabs) {
+    if (!p) return BJ_ERR_INVALID_ARG;
+    if (reserved) *reserved = p->ws_reserved;
+    if (high_water) *high_water = p->ws_high_water;
+    if (overflow_slabs) *overflow_slabs = p->ws_overflow_slabs;
+    return BJ_OK;
+}
+int bj_setup_device_bytes(const bj_setup *s, size_t *bytes) {
+    if (!s || !bytes) return BJ_ERR_INVALID_ARG;
+    const size_t n = (size_t)1 << s->log_n;
+    size_t b = 0;
+    if (s->d_nat) b += (size_t)s->n_cols * n * 8;
+    if (s->d_mono) b += (size_t)s->n_cols * n * 8;
+    if (s->d_lde) b += (size_t)s->n_cols * s->Ls * 8;
+    if (s->d_tree) b += bj_merkle_tree_digests(s->Nl, s->cap_l) * 32;
+    if (s->d_non_res) b += (size_t)s->V * 8;
+    if (s->d_inv_xm1) b += (n * s->q) / s->sh.world * 8;
+    *bytes = b;
+    return BJ_OK;
+}
 int bj_proof_stage_ms(const bj_proof *p, float *out8) {
     if (!p || !out8) return BJ_ERR_INVALID_ARG;
     std::memcpy(out8, p->stage_ms, sizeof(p->stage_ms));
@@ -637,7 +658,11 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                     + (sh.world > 1 ? 10 * n : 0)                                                  // sharded DEEP numerators: slices + gather staging
                     + (hw ? 4 * N : 0)                                                             // host witness hashed in groups: the leaves' capacity words
                     + (size_t)2 * N * (1 + S->pub_cols.size());                                    // DEEP: one extended numerator per large opening set beyond the first
+        // `need` is an upper bound by construction of the list above — checked on every proof the test suite makes (the binding
+        // raises when a proof had to take an overflow slab) — and a context that has seen a larger proof keeps its size
+        if (need < ctx->arena_learned) need = ctx->arena_learned;
         if ((rc = bj::arena_reset(ctx, need))) return rc;
+        proof->ws_reserved = ctx->arena_elems * 8;
     }
     struct InProof {   // temporaries of the ABI calls below come out of the arena while this is alive
         bj_ctx *c;
@@ -1390,6 +1415,9 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             proof->kernel_stats[proof->n_kernel_stats++] = {ctx->probes[i].name, e, ctx->probes[i].bytes};
         }
     }
+    proof->ws_high_water = ctx->arena_high_water * 8;
+    proof->ws_overflow_slabs = ctx->arena_slabs.size();
+    if (ctx->arena_high_water + ((size_t)1 << 17) > ctx->arena_learned) ctx->arena_learned = ctx->arena_high_water + ((size_t)1 << 17);
     guard.ok = true;
     *out = proof;
     return BJ_OK;

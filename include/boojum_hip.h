@@ -44,7 +44,7 @@ typedef struct bj_ctx bj_ctx;
 
 /* 2: bj_gate_desc.wit_stride, bj_comm.all_gather_stream (round 2); 3: op lists in any numbering, run-time compiled gates;
  * 4: bj_proof_config.pow_runner, bj_circuit.table_id_col = BJ_TABLE_ID_AS_VARIABLE (round 5) */
-#define BJ_ABI_VERSION 4
+#define BJ_ABI_VERSION 5
 int bj_abi_version(void);
 int bj_device_count(void);
 const char *bj_status_string(int status);
@@ -536,9 +536,21 @@ int bj_comm_replay_create(bj_ctx *ctx, unsigned rank, unsigned world, const void
                           size_t n_setup, size_t n_per_proof, int verify, bj_comm *out);
 void bj_comm_replay_destroy(bj_comm *comm);
 int bj_comm_replay_stats(const bj_comm *comm, size_t *calls, size_t *bytes_received, size_t *mismatches);
+/* Making the recording with ONE rank on the device at a time: a replay transport that holds the first k collectives and has a
+ * capture buffer does not serve collective k — it copies this rank's contribution to it into d_capture and fails the call,
+ * which ends the proof (bj_prove_dev returns BJ_ERR_HIP; bj_comm_replay_captured then reports the contribution's size, 0 when
+ * the proof ended without reaching an unrecorded collective).  The `world` contributions, rank-major, ARE the gathered buffer
+ * of collective k: every rank receives the same bytes and proofs of one witness are deterministic.  A 2^23-row proof over eight
+ * ranks is recorded this way on one 288 GB device, which cannot hold the eight ranks' workspaces side by side
+ * (era_boojum_amd/scale_replay.py). */
+int bj_comm_replay_capture(bj_comm *comm, void *d_capture, size_t capacity_bytes);
+int bj_comm_replay_captured(const bj_comm *comm, size_t *bytes);
 /* bj_prove / bj_prove_dev on a sharded setup are collective: every rank calls them with the same witness. */
 void bj_setup_destroy(bj_setup *s);
 int bj_setup_cap(const bj_setup *s, uint64_t *h_cap); /* vk.setup_merkle_tree_cap: cap_size*4 u64 */
+/* HBM held by a setup (its shard on a sharded setup): natural-order columns, monomials, the LDE of the cosets it owns, its
+ * Merkle subtree, 1 / (x - 1) on its quotient points — the "per rank" column of DESIGN.md §6's memory table. */
+int bj_setup_device_bytes(const bj_setup *s, size_t *bytes);
 int bj_setup_shape(const bj_setup *s, unsigned *log_n, unsigned *num_vars, unsigned *num_witness_cols,
                    unsigned *num_public_inputs); /* any out pointer may be NULL */
 
@@ -594,6 +606,11 @@ int bj_proof_kernel_stats(const bj_proof *p, unsigned index, const char **name, 
  * their end on the proof's stream: transfer + waiting for the slowest peer), how many there were and how many bytes arrived
  * from the other ranks.  Zeroes for a single-GPU proof.  Any out pointer may be NULL. */
 int bj_proof_comm_stats(const bj_proof *p, float *ms_in_collectives, size_t *calls, size_t *bytes_received);
+/* Workspace of the proof: bytes the context had reserved for it (one bump-allocated arena, sized from the setup's geometry
+ * before the first kernel), the high-water mark the proof reached, and the number of overflow slabs it had to take because the
+ * reservation was too small (0 on every configuration the test suite proves; a slab is a hipMalloc in the middle of a proof, and
+ * the context reserves the learned size from the next proof on).  With bj_setup_device_bytes: what a rank holds. */
+int bj_proof_workspace_bytes(const bj_proof *p, size_t *reserved, size_t *high_water, size_t *overflow_slabs);
 
 #ifdef __cplusplus
 }
