@@ -159,6 +159,25 @@ def poseidon2_permutation(state):
     return s
 
 
+def poseidon2_avx512_available():
+    """True when trees are hashed by oracle/poseidon2_avx512.c (the CPU has AVX-512 F + DQ and ORC_NO_AVX512 is unset; the choice
+    is made once per process)."""
+    return bool(lib().orc_poseidon2_avx512_available())
+
+
+def poseidon2_isa():
+    return "avx512 (8 permutations per call, lane = leaf)" if poseidon2_avx512_available() else "scalar (u128 accumulators)"
+
+
+def poseidon2_permutation_x8(states):
+    """Eight states (8 x 12) through the AVX-512 permutation; raises where the CPU has no AVX-512."""
+    if not poseidon2_avx512_available():
+        raise RuntimeError("no AVX-512 on this CPU (or ORC_NO_AVX512 is set)")
+    s = np.ascontiguousarray(_arr(states).reshape(8, 12)).copy()
+    lib().orc_poseidon2_permutation_x8(_p(s))
+    return s
+
+
 def poseidon_permutation(state):
     """Poseidon (v1, naive) permutation — bench-script transcript only."""
     s = _arr(state).copy()

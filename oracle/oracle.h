@@ -44,6 +44,13 @@ void orc_merkle_cap(const uint64_t *tree, size_t num_leaves, size_t cap_size, ui
 size_t orc_merkle_proof(const uint64_t *tree, size_t num_leaves, size_t cap_size, size_t idx, uint64_t *leaf_hash_out, uint64_t *path_out);
 int orc_merkle_verify(const uint64_t *path, size_t depth, const uint64_t *cap, const uint64_t *leaf_hash, size_t idx);
 
+/* ---- poseidon2_avx512.c (eight permutations lane-wise; run-time selected) ---- */
+int orc_poseidon2_avx512_available(void);           /* 1: the CPU has AVX-512 F + DQ and ORC_NO_AVX512 is not set */
+void orc_poseidon2_permutation_x8(uint64_t *states96);   /* eight states back to back; call only when available */
+void orc_hash_leaves_x8(const uint64_t *const *cols, size_t n_cols, size_t I, uint64_t *out32);
+void orc_hash_nodes_x8(const uint64_t *prev, size_t i, uint64_t *next);
+void orc_hash_chunked_x8(const uint64_t *const *srcs, size_t n_srcs, size_t E, size_t j, uint64_t *out32);
+
 /* ---- transcript.c ---- */
 typedef struct orc_transcript orc_transcript;
 orc_transcript *orc_transcript_new(void);

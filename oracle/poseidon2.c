@@ -9,6 +9,9 @@
  *   Merkle tree           cs/oracle/merkle_tree.rs:78-174 (construct), 176-386 (by chunking), 388-449 (nodes),
  *                         451-504 (cap / proof / verify)
  * Pinned bit-exactly by the reference's golden proof.json/vk.json (tests/test_oracle_fixture.py).
+ * Trees are hashed eight leaves / eight parents at a time by poseidon2_avx512.c where the CPU has AVX-512 (the same algorithm
+ * lane-wise; the reference's own fast path is AVX-512 too: implementations/poseidon2/state_avx512.rs); the code below is the
+ * definition, the remainder loop, and the path of ORC_NO_AVX512=1.
  */
 #include "oracle.h"
 #include "poseidon_rc.h"
@@ -121,8 +124,11 @@ void orc_merkle_nodes(uint64_t *tree, size_t num_leaves, size_t cap_size, int th
     while (len > cap_size) {
         uint64_t *next = prev + 4 * len;
         size_t nl = len / 2;
+        const size_t nv = orc_poseidon2_avx512_available() ? nl / 8 * 8 : 0;     /* eight parents per AVX-512 call */
 #pragma omp parallel for schedule(static) num_threads(threads)
-        for (size_t i = 0; i < nl; i++) orc_hash_node(prev + 8 * i, prev + 8 * i + 4, next + 4 * i);
+        for (size_t i = 0; i < nv; i += 8) orc_hash_nodes_x8(prev, i, next);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (size_t i = nv; i < nl; i++) orc_hash_node(prev + 8 * i, prev + 8 * i + 4, next + 4 * i);
         prev = next; len = nl;
     }
 }
@@ -131,11 +137,14 @@ void orc_merkle_nodes(uint64_t *tree, size_t num_leaves, size_t cap_size, int th
  * (= num_leaves contiguous values); leaf I = hash(cols[0][I], cols[1][I], ...). */
 void orc_merkle_construct(const uint64_t *const *cols, size_t n_cols, size_t num_leaves, size_t cap_size,
                           uint64_t *tree, int threads) {
+    const size_t nv = orc_poseidon2_avx512_available() ? num_leaves / 8 * 8 : 0;   /* eight leaves per AVX-512 call, lane = leaf */
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t I = 0; I < nv; I += 8) orc_hash_leaves_x8(cols, n_cols, I, tree + 4 * I);
 #pragma omp parallel num_threads(threads)
     {
         uint64_t *row = (uint64_t *)malloc(n_cols * sizeof(uint64_t));
 #pragma omp for schedule(static)
-        for (size_t I = 0; I < num_leaves; I++) {
+        for (size_t I = nv; I < num_leaves; I++) {
             for (size_t c = 0; c < n_cols; c++) row[c] = cols[c][I];
             orc_hash_leaf(row, n_cols, tree + 4 * I);
         }
@@ -157,11 +166,14 @@ void orc_merkle_construct_strided(const uint64_t *base, size_t stride, size_t n_
 void orc_merkle_construct_chunked(const uint64_t *const *srcs, size_t n_srcs, size_t len, size_t elems_per_leaf,
                                   size_t cap_size, uint64_t *tree, int threads) {
     size_t num_leaves = len / elems_per_leaf;
+    const size_t nv = orc_poseidon2_avx512_available() ? num_leaves / 8 * 8 : 0;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t j = 0; j < nv; j += 8) orc_hash_chunked_x8(srcs, n_srcs, elems_per_leaf, j, tree + 4 * j);
 #pragma omp parallel num_threads(threads)
     {
         uint64_t *row = (uint64_t *)malloc(n_srcs * elems_per_leaf * sizeof(uint64_t));
 #pragma omp for schedule(static)
-        for (size_t j = 0; j < num_leaves; j++) {
+        for (size_t j = nv; j < num_leaves; j++) {
             for (size_t s = 0; s < n_srcs; s++)
                 memcpy(row + s * elems_per_leaf, srcs[s] + j * elems_per_leaf, elems_per_leaf * sizeof(uint64_t));
             orc_hash_leaf(row, n_srcs * elems_per_leaf, tree + 4 * j);
