@@ -9,8 +9,17 @@
  *   transform_monomials_to_lde           cs/implementations/utils.rs:311-403
  */
 #include "oracle.h"
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* ntt_avx512.c: the butterfly loops eight at a time, where the CPU has AVX-512 (run-time check shared with the Poseidon2 path) */
+void orc_ct_bfly_x8(uint64_t *lo, uint64_t *hi, size_t count, uint64_t s);
+void orc_ct_addsub_x8(uint64_t *lo, uint64_t *hi, size_t count);
+void orc_scale_x8(uint64_t *a, size_t count, uint64_t s);
+void orc_distribute_powers_x8(uint64_t *a, size_t count, uint64_t el);
+void orc_canonicalize_x8(uint64_t *a, size_t count);
+static inline int vec(void) { return orc_poseidon2_avx512_available(); }
 
 /* T[j] = w^{bitrev_{log_n-1}(j)}, j < n/2; w = omega_n or its inverse (utils.rs:88-125) */
 void orc_twiddles(uint64_t *out, unsigned log_n, int inverse) {
@@ -25,6 +34,26 @@ void orc_twiddles(uint64_t *out, unsigned log_n, int inverse) {
     free(nat);
 }
 
+/* The batched drivers below ask for the same table again and again (the coset-streaming restatement: ~80 calls at one size, each
+ * n / 2 chained products and a scattered pass): the largest table per direction is kept — T for 2^k is a prefix of T for 2^(k+1),
+ * bitrev_k(j) = 2 bitrev_(k-1)(j) for j < 2^(k-1).  Tables that were outgrown are not freed (another thread may still read them). */
+static const gl_t *cached_twiddles(unsigned log_n, int inverse) {
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    static gl_t *tab[2];
+    static unsigned have[2];
+    inverse = inverse ? 1 : 0;
+    pthread_mutex_lock(&mu);
+    if (!tab[inverse] || have[inverse] < log_n) {
+        gl_t *t = (gl_t *)malloc((((size_t)1 << log_n) / 2 + 1) * sizeof(gl_t));
+        orc_twiddles(t, log_n, inverse);
+        tab[inverse] = t;
+        have[inverse] = log_n;
+    }
+    const gl_t *r = tab[inverse];
+    pthread_mutex_unlock(&mu);
+    return r;
+}
+
 void orc_bitreverse(uint64_t *a, unsigned log_n) {
     size_t n = (size_t)1 << log_n;
     for (size_t i = 0; i < n; i++) {
@@ -33,10 +62,15 @@ void orc_bitreverse(uint64_t *a, unsigned log_n) {
     }
 }
 
-void orc_canonicalize(uint64_t *a, size_t n) { for (size_t i = 0; i < n; i++) a[i] = gl_canon(a[i]); }
+void orc_canonicalize(uint64_t *a, size_t n) {
+    size_t i = 0;
+    if (vec()) { i = n / 8 * 8; orc_canonicalize_x8(a, i); }
+    for (; i < n; i++) a[i] = gl_canon(a[i]);
+}
 
 /* fft/mod.rs:308-317 */
 static void distribute_powers(gl_t *a, size_t n, gl_t el) {
+    if (vec() && n >= 8) { orc_distribute_powers_x8(a, n, el); return; }   /* n is a power of two */
     gl_t s = 1;
     for (size_t i = 0; i < n; i++) { a[i] = gl_mul(a[i], s); s = gl_mul(s, el); }
 }
@@ -54,6 +88,7 @@ static void ct_rounds_in_block(gl_t *a, size_t base, size_t len, size_t first_gr
         for (size_t g = 0; g < groups; g++) {
             size_t i1 = base + g * pairs * 2, i2 = i1 + pairs;
             gl_t s = tw[first_group * groups + g];
+            if (pairs >= 8 && vec()) { orc_ct_bfly_x8(a + i1, a + i2, pairs, s); continue; }
             for (size_t j = i1; j < i2; j++) {
                 gl_t u = a[j], v = gl_mul(a[j + pairs], s);
                 a[j + pairs] = gl_sub(u, v);
@@ -68,7 +103,8 @@ static void serial_ct_ntt(gl_t *a, unsigned log_n, const gl_t *tw) {
     size_t n = (size_t)1 << log_n;
     if (n == 1) return;
     size_t pairs = n / 2, groups = 1, dist = n / 2;
-    for (size_t j = 0; j < pairs; j++) {           /* omega = 1 special case */
+    if (pairs >= 8 && vec()) orc_ct_addsub_x8(a, a + dist, pairs);
+    else for (size_t j = 0; j < pairs; j++) {           /* omega = 1 special case */
         gl_t u = a[j], v = a[j + dist];
         a[j + dist] = gl_sub(u, v);
         a[j] = gl_add(u, v);
@@ -78,6 +114,7 @@ static void serial_ct_ntt(gl_t *a, unsigned log_n, const gl_t *tw) {
         for (size_t k = 0; k < groups; k++) {
             size_t i1 = k * pairs * 2, i2 = i1 + pairs;
             gl_t s = tw[k];
+            if (pairs >= 8 && vec()) { orc_ct_bfly_x8(a + i1, a + i1 + dist, pairs, s); continue; }
             for (size_t j = i1; j < i2; j++) {
                 gl_t u = a[j], v = gl_mul(a[j + dist], s);
                 a[j + dist] = gl_sub(u, v);
@@ -109,7 +146,8 @@ void orc_ifft_natural_to_natural(uint64_t *a, unsigned log_n, uint64_t coset, co
     if (coset != 1) distribute_powers(a, n, gl_inv(coset));
     if (n > 1) {
         gl_t n_inv = gl_inv(gl_from_u64((uint64_t)n));
-        for (size_t i = 0; i < n; i++) a[i] = gl_mul(a[i], n_inv);
+        if (vec() && n >= 8) orc_scale_x8(a, n, n_inv);
+        else for (size_t i = 0; i < n; i++) a[i] = gl_mul(a[i], n_inv);
     }
 }
 
@@ -148,38 +186,31 @@ void orc_lde_from_monomials(const uint64_t *mono, uint64_t *out, unsigned log_n,
  * These are what bench.py's cpu_baseline leg times. ---- */
 void orc_fft_batch(uint64_t *cols, unsigned log_n, size_t n_cols, uint64_t coset, int threads) {
     size_t n = (size_t)1 << log_n;
-    gl_t *tw = (gl_t *)malloc((n / 2 + 1) * sizeof(gl_t));
-    orc_twiddles(tw, log_n, 0);
+    const gl_t *tw = cached_twiddles(log_n, 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (size_t c = 0; c < n_cols; c++) orc_fft_natural_to_bitreversed(cols + c * n, log_n, coset, tw);
-    free(tw);
 }
 /* out-of-place: dst[c] = NTT(src[c]); the copy runs inside the parallel loop (a caller that reuses dst over many cosets does not
  * fault fresh pages in for every call — oracle/prover_streaming.py) */
 void orc_fft_batch_to(const uint64_t *src, uint64_t *dst, unsigned log_n, size_t n_cols, uint64_t coset, int threads) {
     size_t n = (size_t)1 << log_n;
-    gl_t *tw = (gl_t *)malloc((n / 2 + 1) * sizeof(gl_t));
-    orc_twiddles(tw, log_n, 0);
+    const gl_t *tw = cached_twiddles(log_n, 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (size_t c = 0; c < n_cols; c++) {
         memcpy(dst + c * n, src + c * n, n * sizeof(uint64_t));
         orc_fft_natural_to_bitreversed(dst + c * n, log_n, coset, tw);
     }
-    free(tw);
 }
 void orc_ifft_batch(uint64_t *cols, unsigned log_n, size_t n_cols, uint64_t coset, int threads) {
     size_t n = (size_t)1 << log_n;
-    gl_t *tw = (gl_t *)malloc((n / 2 + 1) * sizeof(gl_t));
-    orc_twiddles(tw, log_n, 1);
+    const gl_t *tw = cached_twiddles(log_n, 1);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (size_t c = 0; c < n_cols; c++) orc_ifft_natural_to_natural(cols + c * n, log_n, coset, tw);
-    free(tw);
 }
 /* mono [n_cols][n] -> out [n_cols][L][n] */
 void orc_lde_batch(const uint64_t *mono, uint64_t *out, unsigned log_n, unsigned log_lde, size_t n_cols, int threads) {
     size_t n = (size_t)1 << log_n, L = (size_t)1 << log_lde;
-    gl_t *tw = (gl_t *)malloc((n / 2 + 1) * sizeof(gl_t));
-    orc_twiddles(tw, log_n, 0);
+    const gl_t *tw = cached_twiddles(log_n, 0);
     gl_t shifts[64];
     orc_lde_coset_shifts(shifts, log_n, log_lde);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
@@ -189,5 +220,4 @@ void orc_lde_batch(const uint64_t *mono, uint64_t *out, unsigned log_n, unsigned
         memcpy(dst, mono + col * n, n * sizeof(uint64_t));
         orc_fft_natural_to_bitreversed(dst, log_n, shifts[c], tw);
     }
-    free(tw);
 }

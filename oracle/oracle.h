@@ -48,6 +48,7 @@ int orc_merkle_verify(const uint64_t *path, size_t depth, const uint64_t *cap, c
 int orc_poseidon2_avx512_available(void);           /* 1: the CPU has AVX-512 F + DQ and ORC_NO_AVX512 is not set */
 void orc_poseidon2_permutation_x8(uint64_t *states96);   /* eight states back to back; call only when available */
 void orc_hash_leaves_x8(const uint64_t *const *cols, size_t n_cols, size_t I, uint64_t *out32);
+void orc_hash_leaves_x16(const uint64_t *const *cols, size_t n_cols, size_t I, uint64_t *out64);   /* two interleaved groups of eight */
 void orc_hash_nodes_x8(const uint64_t *prev, size_t i, uint64_t *next);
 void orc_hash_chunked_x8(const uint64_t *const *srcs, size_t n_srcs, size_t E, size_t j, uint64_t *out32);
 

@@ -138,8 +138,10 @@ void orc_merkle_nodes(uint64_t *tree, size_t num_leaves, size_t cap_size, int th
 void orc_merkle_construct(const uint64_t *const *cols, size_t n_cols, size_t num_leaves, size_t cap_size,
                           uint64_t *tree, int threads) {
     const size_t nv = orc_poseidon2_avx512_available() ? num_leaves / 8 * 8 : 0;   /* eight leaves per AVX-512 call, lane = leaf */
+    const size_t nv16 = nv / 16 * 16;                                              /* sixteen where they are there: two interleaved groups */
 #pragma omp parallel for schedule(static) num_threads(threads)
-    for (size_t I = 0; I < nv; I += 8) orc_hash_leaves_x8(cols, n_cols, I, tree + 4 * I);
+    for (size_t I = 0; I < nv16; I += 16) orc_hash_leaves_x16(cols, n_cols, I, tree + 4 * I);
+    if (nv16 < nv) orc_hash_leaves_x8(cols, n_cols, nv16, tree + 4 * nv16);
 #pragma omp parallel num_threads(threads)
     {
         uint64_t *row = (uint64_t *)malloc(n_cols * sizeof(uint64_t));

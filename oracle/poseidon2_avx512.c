@@ -14,11 +14,9 @@
  */
 #include "oracle.h"
 #include "poseidon_rc.h"
-#include <immintrin.h>
+#include "gl_avx512.h"
 #include <stdlib.h>
 #include <string.h>
-
-#define AVX512 __attribute__((target("avx512f,avx512dq")))
 
 static const uint64_t RC[BJ_POSEIDON_NUM_RC] = BJ_POSEIDON_RC_TABLE;
 static const unsigned SH[12] = {4, 14, 11, 8, 0, 5, 2, 9, 13, 6, 3, 12};
@@ -33,35 +31,9 @@ int orc_poseidon2_avx512_available(void) {
     return cached;
 }
 
-typedef __m512i v8;
-
-/* (lo, hi) of a 128-bit value per lane -> canonical residue: gl_reduce128 of gl.h, lane-wise */
-AVX512 static inline v8 reduce128(v8 lo, v8 hi) {
-    const v8 eps = _mm512_set1_epi64((long long)GL_EPS), p = _mm512_set1_epi64((long long)GL_P);
-    const v8 hi_hi = _mm512_srli_epi64(hi, 32), hi_lo = _mm512_and_si512(hi, eps);
-    v8 t0 = _mm512_sub_epi64(lo, hi_hi);
-    t0 = _mm512_mask_sub_epi64(t0, _mm512_cmplt_epu64_mask(lo, hi_hi), t0, eps);      /* borrow: subtract 2^64 mod p */
-    const v8 t1 = _mm512_mul_epu32(hi_lo, eps);                                      /* hi_lo * (2^32 - 1) < 2^64 */
-    v8 r = _mm512_add_epi64(t0, t1);
-    r = _mm512_mask_add_epi64(r, _mm512_cmplt_epu64_mask(r, t1), r, eps);             /* carry */
-    return _mm512_mask_sub_epi64(r, _mm512_cmpge_epu64_mask(r, p), r, p);
-}
-AVX512 static inline v8 mul(v8 a, v8 b) {
-    const v8 m32 = _mm512_set1_epi64(0xFFFFFFFFLL);
-    const v8 ah = _mm512_srli_epi64(a, 32), bh = _mm512_srli_epi64(b, 32);
-    const v8 ll = _mm512_mul_epu32(a, b), lh = _mm512_mul_epu32(a, bh), hl = _mm512_mul_epu32(ah, b), hh = _mm512_mul_epu32(ah, bh);
-    const v8 mid = _mm512_add_epi64(lh, _mm512_srli_epi64(ll, 32));                   /* <= (2^32-1)^2 + 2^32 - 1: no wrap */
-    const v8 mid2 = _mm512_add_epi64(hl, _mm512_and_si512(mid, m32));                 /* no wrap */
-    const v8 lo = _mm512_or_si512(_mm512_and_si512(ll, m32), _mm512_slli_epi64(mid2, 32));
-    const v8 hi = _mm512_add_epi64(hh, _mm512_add_epi64(_mm512_srli_epi64(mid, 32), _mm512_srli_epi64(mid2, 32)));
-    return reduce128(lo, hi);
-}
-AVX512 static inline v8 add(v8 a, v8 b) {   /* canonical in, canonical out (gl_add) */
-    const v8 p = _mm512_set1_epi64((long long)GL_P);
-    const v8 s = _mm512_add_epi64(a, b);
-    const __mmask8 m = _mm512_cmplt_epu64_mask(s, a) | _mm512_cmpge_epu64_mask(s, p);
-    return _mm512_mask_sub_epi64(s, m, s, p);
-}
+#define reduce128 v8_reduce128
+#define mul v8_mul
+#define add v8_add
 AVX512 static inline v8 pow7(v8 x) {
     const v8 x2 = mul(x, x), x3 = mul(x2, x), x4 = mul(x2, x2);
     return mul(x4, x3);
@@ -116,9 +88,35 @@ AVX512 static inline void permute8(v8 *s) {                /* state_generic_impl
     for (int i = 0; i < 22; i++) partial_round(s, r++);
     for (int i = 0; i < 4; i++) full_round(s, r++);
 }
-AVX512 static inline v8 canon8(v8 a) {
-    const v8 p = _mm512_set1_epi64((long long)GL_P);
-    return _mm512_mask_sub_epi64(a, _mm512_cmpge_epu64_mask(a, p), a, p);
+#define canon8 v8_canon
+/* TWO groups of eight states: a partial round raises ONE word per state to the seventh power — four products that depend on each
+ * other, one register wide — so a single group leaves the multiplier idle for most of the 22 partial rounds; two groups side by
+ * side give the scheduler a second chain to fill the latency with.  Same permutation on each group. */
+AVX512 static inline void partial_round2(v8 *a, v8 *b, int r) {
+    const v8 m32 = _mm512_set1_epi64(0xFFFFFFFFLL), rc = _mm512_set1_epi64((long long)gl_canon(RC[12 * r]));
+    const v8 xa = add(a[0], rc), xb = add(b[0], rc);
+    const v8 xa2 = mul(xa, xa), xb2 = mul(xb, xb);
+    const v8 xa3 = mul(xa2, xa), xb3 = mul(xb2, xb);
+    const v8 xa4 = mul(xa2, xa2), xb4 = mul(xb2, xb2);
+    a[0] = mul(xa4, xa3);
+    b[0] = mul(xb4, xb3);
+    for (int g = 0; g < 2; g++) {
+        v8 *s = g ? b : a;
+        v8 lo[12], hi[12], sl = _mm512_setzero_si512(), sh = _mm512_setzero_si512();
+        for (int i = 0; i < 12; i++) {
+            lo[i] = _mm512_and_si512(s[i], m32); hi[i] = _mm512_srli_epi64(s[i], 32);
+            sl = _mm512_add_epi64(sl, lo[i]); sh = _mm512_add_epi64(sh, hi[i]);
+        }
+        for (int i = 0; i < 12; i++)
+            s[i] = fold_halves(_mm512_add_epi64(_mm512_slli_epi64(lo[i], SH[i]), sl), _mm512_add_epi64(_mm512_slli_epi64(hi[i], SH[i]), sh));
+    }
+}
+AVX512 static inline void permute8x2(v8 *a, v8 *b) {
+    ext_mds(a); ext_mds(b);
+    int r = 0;
+    for (int i = 0; i < 4; i++, r++) { full_round(a, r); full_round(b, r); }
+    for (int i = 0; i < 22; i++) partial_round2(a, b, r++);
+    for (int i = 0; i < 4; i++, r++) { full_round(a, r); full_round(b, r); }
 }
 
 /* eight states back to back (8 x 12 words, state-major as orc_poseidon2_permutation takes one): for the tests */
@@ -148,6 +146,27 @@ AVX512 void orc_hash_leaves_x8(const uint64_t *const *cols, size_t n_cols, size_
     }
     const __m512i idx = _mm512_setr_epi64(0, 4, 8, 12, 16, 20, 24, 28);
     for (int k = 0; k < 4; k++) _mm512_i64scatter_epi64((long long *)(out + k), idx, s[k], 8);
+}
+/* leaves I .. I+15 the same way, as two interleaved groups */
+AVX512 void orc_hash_leaves_x16(const uint64_t *const *cols, size_t n_cols, size_t I, uint64_t *out /* 16 digests */) {
+    v8 a[12], b[12];
+    for (int i = 0; i < 12; i++) a[i] = b[i] = _mm512_setzero_si512();
+    size_t c = 0;
+    while (c < n_cols) {
+        const size_t take = n_cols - c >= 8 ? 8 : n_cols - c;
+        for (size_t k = 0; k < take; k++) {
+            a[k] = canon8(_mm512_loadu_si512((const void *)(cols[c + k] + I)));
+            b[k] = canon8(_mm512_loadu_si512((const void *)(cols[c + k] + I + 8)));
+        }
+        for (size_t k = take; k < 8; k++) a[k] = b[k] = _mm512_setzero_si512();
+        permute8x2(a, b);
+        c += take;
+    }
+    const __m512i idx = _mm512_setr_epi64(0, 4, 8, 12, 16, 20, 24, 28);
+    for (int k = 0; k < 4; k++) {
+        _mm512_i64scatter_epi64((long long *)(out + k), idx, a[k], 8);
+        _mm512_i64scatter_epi64((long long *)(out + 32 + k), idx, b[k], 8);
+    }
 }
 /* parents i .. i+7 of a node layer (oracle/mod.rs:162-168): children 2i, 2i+1 of `prev` (4 words each) */
 AVX512 void orc_hash_nodes_x8(const uint64_t *prev, size_t i, uint64_t *next) {

@@ -322,14 +322,14 @@ def test_prover_checks_public_values_against_the_witness():
 @pytest.mark.timeout(900)
 def test_proof_at_2p23_rows_equals_the_streaming_oracle():
     """BASELINE config 5's size (2^23 rows, LDE 8 => 2^26-point oracles), prover.rs:153-168.  The coset-streaming restatement
-    (oracle/prover_streaming.py) recomputes from the witness alone: the cap nodes of cosets {0, 5} of the witness and
-    second-stage oracles (a coset of the witness oracle is 10^8 permutations on the host: all eight would not fit the suite),
-    the WHOLE quotient cap, and all 241 values at z, z*omega and 0 under the challenges of the HIP proof's transcript; all of
-    them must equal the HIP proof's.  Since round 5 the restatement goes on past the openings: DEEP on every one of the 2^26
-    points (a second pass over the cosets), do_fri, queries — FRI base cap, every intermediate cap, final monomials, every FRI
-    query opening, and the base-oracle openings of the queries that land in hashed cosets equal the HIP proof's too.  The
-    verifier restatement accepts the proof as a whole (public inputs included — their DEEP opening sets run over all 2^26 points;
-    one of those launches lost a loop's exit test to an undeclared SCC write until round 2, tests/test_gpu_openings.py)."""
+    (oracle/prover_streaming.py) recomputes from the witness alone EVERY transcript input: the caps of the witness, second-stage and
+    quotient oracles over all eight cosets (2^26 leaves each; since round 6 the oracle hashes eight leaves per AVX-512 call,
+    oracle/poseidon2_avx512.c, and no cap is taken as claimed any more), all eight cosets of the setup oracle against the
+    verification key's cap, all 241 values at z, z*omega and 0, then DEEP on every one of the 2^26 points (a second pass over the
+    cosets), do_fri, queries — FRI base cap, every intermediate cap, final monomials, every FRI query opening and the path + leaf
+    hash of every base-oracle opening of every query equal the HIP proof's.  The verifier restatement accepts the proof as a whole
+    (public inputs included — their DEEP opening sets run over all 2^26 points; one of those launches lost a loop's exit test to
+    an undeclared SCC write until round 2, tests/test_gpu_openings.py)."""
     from oracle import prover_streaming as PS
     c = S.sha_shaped_circuit(23, seed=42, table_bits=4)
     setup = E.ProverSetup(ctx(), c, 8, 16, 100)
@@ -343,22 +343,19 @@ def test_proof_at_2p23_rows_equals_the_streaming_oracle():
     ctx().release_workspace()      # ~150 GB of arena: give it back before the multi-process tests share this GPU
     pg = proof_format.parse(buf, security_level=100)
     assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg, verbose=True)
-    claimed = {k: pg[k] for k in ("witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap")}
-    po = PS.commitments_and_openings(c, cap, 8, 16, threads=oracle_threads(), transcript_kind=1, check_setup_cosets=(5,), cap_cosets=(0, 5),
-                                     claimed_caps=claimed, rest_of_the_proof=True, security_level=100)
-    for k in ("public_inputs", "quotient_oracle_cap", "values_at_z", "values_at_z_omega", "values_at_0"):
+    po = PS.commitments_and_openings(c, cap, 8, 16, threads=oracle_threads(), transcript_kind=1, check_setup_cosets=tuple(range(8)),
+                                     rest_of_the_proof=True, security_level=100)
+    for k in ("public_inputs", "witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z", "values_at_z_omega",
+              "values_at_0"):
         assert pg[k] == po[k], k
-    # past the openings (round 5): the DEEP accumulator of all 2^26 points coset by coset, every FRI cap, the final monomials and
-    # all FRI query openings byte for byte; the quotient opening + path of every query, the witness / second-stage ones of the
-    # queries in cosets {0, 5}, the setup ones of coset 5
-    compared = PS.compare_rest_of_the_proof(pg, po)
-    nq = len(pg["queries_per_fri_repetition"])
-    assert compared >= nq and len(po["query_indexes"]) == nq
-    for name in ("witness_oracle_cap", "stage_2_oracle_cap"):
-        for cs, frag in po["cap_fragments"][name].items():
-            assert np.array_equal(frag, np.asarray(pg[name], dtype=np.uint64)[2 * cs:2 * cs + 2]), (name, cs)
     for cs, frag in po["setup_cap_fragments"].items():
         assert np.array_equal(frag, cap[2 * cs:2 * cs + 2]), "setup cap nodes of coset %d" % cs
+    assert sorted(po["setup_cap_fragments"]) == list(range(8))
+    # past the openings: the DEEP accumulator of all 2^26 points coset by coset, every FRI cap, the final monomials and all FRI query
+    # openings byte for byte; the witness / second-stage / quotient / setup opening (leaf hash) + path of EVERY query
+    compared = PS.compare_rest_of_the_proof(pg, po)
+    nq = len(pg["queries_per_fri_repetition"])
+    assert compared == 4 * nq and len(po["query_indexes"]) == nq
 
 
 def test_two_contexts_on_two_host_threads_prove_concurrently():
@@ -398,6 +395,47 @@ def test_two_contexts_on_two_host_threads_prove_concurrently():
     for c in ctxs:
         c.release_workspace()
         c.close()
+
+
+def test_pipelined_drop_in_call_gives_the_serial_proofs():
+    """bj_prove_async / bj_proof_wait (csrc/prove_async.hip): the host loop over witnesses around prove_cpu_basic
+    (prover.rs:153-168, convenience.rs:119-196) with two proofs in flight from ONE host thread.  Two setups of different sizes share
+    the context's two lanes; every proof that comes back is the bytes the serial bj_prove gives, in submission order whatever
+    order the lanes finish in; a third submission waits for its lane; an unsatisfied witness fails in `wait` with the
+    prover's message and leaves the lanes usable; the lanes' workspaces go with bj_ctx_release_workspace."""
+    c1, c2 = S.sha_shaped_circuit(13, seed=31, table_bits=2), S.sha_shaped_circuit(11, seed=32, table_bits=2)
+    s1, s2 = E.ProverSetup(ctx(), c1, 8, 16, 40), E.ProverSetup(ctx(), c2, 8, 16, 40)
+    ref1, ref2 = s1.prove()[0].copy(), s2.prove()[0].copy()
+    assert OV.verify(OV.VerificationKey(c1, s1.cap(), 8, 16), proof_format.parse(ref1, security_level=40))
+    # the documented loop: t[k] = async(w[k]); wait(t[k-1])
+    order = [s1, s2, s1, s1, s2, s2, s1]
+    refs = {id(s1): ref1, id(s2): ref2}
+    prev = order[0].prove_async()
+    for k in range(1, len(order)):
+        cur = order[k].prove_async()
+        buf, stages = order[k - 1].wait(prev)
+        assert np.array_equal(buf, refs[id(order[k - 1])]), "proof %d" % (k - 1)
+        assert stages["witness_lde_and_tree"] > 0
+        prev = cur
+    buf, _ = order[-1].wait(prev)
+    assert np.array_equal(buf, refs[id(order[-1])])
+    # three submissions before the first wait (the third blocks inside the library until lane 0 is free), waited out of order
+    ts = [s1.prove_async(), s2.prove_async(), s1.prove_async()]
+    assert np.array_equal(s1.wait(ts[2])[0], ref1)
+    assert np.array_equal(s1.wait(ts[0])[0], ref1)
+    assert s2.done(ts[1]) in (True, False)
+    assert np.array_equal(s2.wait(ts[1])[0], ref2)
+    # an unsatisfied witness: the error arrives in wait, the other proof in flight is untouched
+    rows = np.nonzero(c1.constants[0] == 1)[0]
+    bad = c1.variables.copy()
+    bad[3, rows[0]] = (int(bad[3, rows[0]]) + 1) % E.P
+    tb, tg = s1.prove_async(variables=bad), s2.prove_async()
+    with pytest.raises(E.BoojumHipError, match="not satisfied"):
+        s1.wait(tb)
+    assert np.array_equal(s2.wait(tg)[0], ref2)
+    assert np.array_equal(s1.wait(s1.prove_async())[0], ref1)
+    s1.close(); s2.close()
+    ctx().release_workspace()          # frees the lanes' arenas and witness staging too
 
 
 def test_host_witness_group_plans_and_non_residue_paths_give_the_same_proof():

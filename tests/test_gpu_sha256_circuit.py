@@ -133,11 +133,11 @@ def test_hip_proof_at_2p22_rows_equals_the_oracle():
     HIP proof must equal its proof byte for byte: every cap, opening, FRI layer, final monomial and all 34 x 4 query openings
     with their paths (prover.rs:153-168 is the function replaced).  With less memory the coset-streaming restatement
     (oracle/prover_streaming.py, checked against the full prover on CPU) recomputes EVERY transcript input one coset at a time:
-    the three oracle caps over 2^25 leaves each, all 241 values at z, z*omega and 0, two cosets of the setup cap, then (round 5)
+    the three oracle caps over 2^25 leaves each, all 241 values at z, z*omega and 0, all eight cosets of the setup oracle against the
+    verification key's cap (round 6: the oracle hashes eight leaves per AVX-512 call, oracle/poseidon2_avx512.c), then (round 5)
     the DEEP accumulator of all 2^25 points from a second pass over the cosets, the FRI base oracle, every intermediate oracle
     and fold challenge, the final monomials, the query indices and every query opening (prover.rs:1803-2266, fri/mod.rs:49-345);
-    all of it equals the HIP proof's.  What stays "verifier accepts" only: the setup-oracle openings of queries outside cosets
-    {0, 5} (the setup is not part of the timed proof)."""
+    all of it equals the HIP proof's, the four base-oracle openings of every query included."""
     c = S.sha256_circuit(S.bench_message(S.message_len_for_log_n(22)))
     assert c.log_n == 22
     gsetup = E.ProverSetup(ctx(), c, 8, 16, 100, transcript="poseidon2")
@@ -153,7 +153,7 @@ def test_hip_proof_at_2p22_rows_equals_the_oracle():
         _compare(pg, po)
         return
     from oracle import prover_streaming as PS
-    po = PS.commitments_and_openings(c, cap, 8, 16, threads=oracle_threads(), transcript_kind=1, check_setup_cosets=(0, 5), rest_of_the_proof=True,
+    po = PS.commitments_and_openings(c, cap, 8, 16, threads=oracle_threads(), transcript_kind=1, check_setup_cosets=tuple(range(8)), rest_of_the_proof=True,
                                      security_level=100)
     for k in ("public_inputs", "witness_oracle_cap", "stage_2_oracle_cap", "quotient_oracle_cap", "values_at_z", "values_at_z_omega",
               "values_at_0"):
@@ -161,11 +161,11 @@ def test_hip_proof_at_2p22_rows_equals_the_oracle():
     for cs, frag in po["setup_cap_fragments"].items():
         assert np.array_equal(frag, cap[2 * cs:2 * cs + 2]), "setup cap nodes of coset %d" % cs
     # every transcript input after the openings, and the queries: FRI base cap, every intermediate cap, final monomials, all
-    # 34 x 7 FRI query openings with their paths byte for byte; witness / second-stage / quotient opening (through the leaf hash
-    # of the restatement's own tree) + path of all 34 queries, the setup ones of the queries in cosets {0, 5}
+    # 34 x 7 FRI query openings with their paths byte for byte; witness / second-stage / quotient / setup opening (through the leaf
+    # hash of the restatement's own tree) + path of all 34 queries
     compared = PS.compare_rest_of_the_proof(pg, po)
     nq = len(pg["queries_per_fri_repetition"])
-    assert nq == 34 and compared >= 3 * nq
+    assert nq == 34 and compared == 4 * nq
     assert OV.verify(OV.VerificationKey(c, cap, 8, 16), pg)
 
 
