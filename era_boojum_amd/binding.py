@@ -32,6 +32,10 @@ _SIGNATURES = {
     "bj_lde_cosets_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
     "bj_trace_to_lde_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint]),
     "bj_bitreverse_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t]),
+    "bj_monomials_tiled": (C.c_int, [C.c_uint]),
+    "bj_intt_batch_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t]),
+    "bj_lde_cosets_batch_tiled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint]),
+    "bj_tiled_permute_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_size_t, C.c_int]),
     "bj_canonicalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_field_op_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bj_ntt_forward_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint64]),
@@ -88,6 +92,9 @@ _SIGNATURES = {
     "bj_setup_cap": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_setup_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "bj_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_prove_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_proof_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_proof_poll": (C.c_int, [C.c_void_p]),
     "bj_prove_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_proof_destroy": (None, [C.c_void_p]),
     "bj_proof_size_u64": (C.c_size_t, [C.c_void_p]),
@@ -268,6 +275,23 @@ class Context:
         col_stride = (1 << log_n) if col_stride is None else col_stride
         self._check(self._lib.bj_lde_cosets_batch(self._h, d_mono, col_stride, d_out, log_n, n_cols, log_lde,
                                                   coset_begin, coset_count))
+
+    def monomials_tiled(self, log_n):
+        """True when bj_prove keeps the monomials of 2^log_n-row traces in the tiled layout (include/boojum_hip.h)."""
+        return bool(self._lib.bj_monomials_tiled(log_n))
+
+    def intt_batch_tiled(self, d_in, d_out, log_n, n_cols, col_stride=None):
+        col_stride = (1 << log_n) if col_stride is None else col_stride
+        self._check(self._lib.bj_intt_batch_tiled(self._h, d_in, d_out, log_n, n_cols, col_stride))
+
+    def lde_cosets_batch_tiled(self, d_mono, d_out, log_n, n_cols, log_lde, coset_begin, coset_count, col_stride=None):
+        col_stride = (1 << log_n) if col_stride is None else col_stride
+        self._check(self._lib.bj_lde_cosets_batch_tiled(self._h, d_mono, col_stride, d_out, log_n, n_cols, log_lde,
+                                                        coset_begin, coset_count))
+
+    def tiled_permute_batch(self, d_in, d_out, log_n, n_cols, to_tiled, col_stride=None):
+        col_stride = (1 << log_n) if col_stride is None else col_stride
+        self._check(self._lib.bj_tiled_permute_batch(self._h, d_in, d_out, log_n, n_cols, col_stride, 1 if to_tiled else 0))
 
     def trace_to_lde_batch(self, d_cols, d_out, log_n, n_cols, log_lde, col_stride=None):
         col_stride = (1 << log_n) if col_stride is None else col_stride
@@ -795,6 +819,13 @@ class TorchComm:
             return 1
 
 
+class _Ticket:
+    """A proof in flight (bj_ticket) + the host arrays it reads."""
+
+    def __init__(self, handle, keep):
+        self.handle, self.keep = handle, keep
+
+
 class ProverSetup:
     """Device-resident setup for a circuit of era_boojum_amd.synthetic.Circuit shape (bj_setup_create).
 
@@ -927,6 +958,35 @@ class ProverSetup:
         h = C.c_void_p()
         self._ctx._check(self._lib.bj_prove(self._ctx._h, self._h, _np_ptr(v), _np_ptr(m) if c.lookup_reps else None,
                                             _np_ptr(pv), C.byref(h)))
+        return self._finish(h)
+
+    def prove_async(self, variables=None, multiplicities=None, public_values=None):
+        """bj_prove_async: queues the proof on one of the context's two lanes and returns a ticket for `wait`.  Arrays passed in
+        are used in place when they are contiguous uint64 (e.g. views of pinned tensors) and kept alive by the ticket."""
+        c = self.circuit
+        v = np.ascontiguousarray(c.variables if variables is None else variables, dtype=np.uint64)
+        if self.num_witness_cols and v.shape[0] == c.num_vars:
+            v = np.ascontiguousarray(np.concatenate([v, c.witness], axis=0))
+        m = np.ascontiguousarray(c.multiplicities if multiplicities is None else multiplicities, dtype=np.uint64)
+        pv = np.array([p[2] for p in c.public_inputs] if public_values is None else public_values, dtype=np.uint64)
+        if pv.size == 0:
+            pv = np.zeros(1, dtype=np.uint64)
+        t = C.c_void_p()
+        self._ctx._check(self._lib.bj_prove_async(self._ctx._h, self._h, _np_ptr(v), _np_ptr(m) if c.lookup_reps else None,
+                                                  _np_ptr(pv), C.byref(t)))
+        return _Ticket(t, (v, m))
+
+    def done(self, ticket):
+        """bj_proof_poll: True when `wait` would not block."""
+        return bool(self._lib.bj_proof_poll(ticket.handle))
+
+    def wait(self, ticket):
+        """bj_proof_wait: blocks until the ticket's proof is complete; returns (serialised proof, per-stage ms) like `prove`."""
+        h = C.c_void_p()
+        t, ticket.handle = ticket.handle, None
+        rc = self._lib.bj_proof_wait(t, C.byref(h))
+        ticket.keep = None
+        self._ctx._check(rc)
         return self._finish(h)
 
     def prove_from_dumps(self, witness_vec_dump, variables_hint_dump, witness_hint_dump=None):

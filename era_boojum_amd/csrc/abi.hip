@@ -189,6 +189,8 @@ void load_env() {
     e.ntt_first4_v = str("BJ_NTT_FIRST4_V").rfind("1", 0) == 0 ? 1 : 2;
     if (set("BJ_NTT_FIRST4_MODE")) e.ntt_first4_mode = atoi(getenv("BJ_NTT_FIRST4_MODE"));
     e.ntt_two_pass = str("BJ_NTT_TWO_PASS").rfind("0", 0) != 0;
+    e.mono_tiled = str("BJ_MONO_TILED").rfind("0", 0) != 0;
+    e.async_no_copy_first = set("BJ_ASYNC_NO_COPY_FIRST");
     e.gate_no_aot = set("BJ_GATE_NO_AOT");
     e.gate_no_fuse = set("BJ_GATE_NO_FUSE");
     e.gate_no_jit = set("BJ_GATE_NO_JIT");
@@ -269,6 +271,7 @@ int bj_ctx_create(int device, bj_ctx **out) {
 void bj_ctx_destroy(bj_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    bj::pipeline_destroy(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->tw_fwd) (void)hipFree(ctx->tw_fwd);
     if (ctx->tw_inv) (void)hipFree(ctx->tw_inv);
@@ -296,6 +299,7 @@ void bj_ctx_destroy(bj_ctx *ctx) {
 int bj_ctx_release_workspace(bj_ctx *ctx) {
     if (int rc = bj::bind(ctx)) return rc;
     if (ctx->in_proof) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ctx_release_workspace: a proof is running");
+    if (int rc = bj::pipeline_release_workspace(ctx)) return rc;
     BJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->copy_stream) BJ_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     if (int rc = bj::arena_drop_slabs(ctx)) return rc;
@@ -466,20 +470,84 @@ namespace bj {
 // LDE of cosets [coset_begin, coset_begin+coset_count) of 2^log_lde with explicit input/output column strides;
 // output column c holds its cosets back to back starting at d_out + c*out_col_stride.
 int lde_cosets_strided(bj_ctx *ctx, const u64 *d_mono, size_t in_col_stride, u64 *d_out, size_t out_col_stride,
-                       unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count) {
+                       unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count, bool tiled_in) {
     if (int rc = ensure_twiddles(ctx, log_n, false)) return rc;
+    if (tiled_in && !bj::ntt_two_pass_applies(d_mono, d_out, log_n, coset_count, in_col_stride, out_col_stride))
+        return fail(ctx, BJ_ERR_UNSUPPORTED, "LDE of tiled monomials: 2^22-word columns on 16-byte boundaries with the two-pass plan enabled only");
     u64 shifts[64];
     u64 w = gl::omega(log_n + log_lde);
     for (unsigned i = 0; i < coset_count; i++)
         shifts[i] = gl::mul(gl::GEN, gl::pow(w, gl::bitrev32(coset_begin + i, log_lde)));  // utils.rs:345-346, 370-373
     bj::launch_round_scales(ctx->d_small + 64, shifts, coset_count, log_n ? log_n : 1, ctx->stream);
     bj::launch_ntt_passes(d_mono, d_out, ctx->tw_fwd, log_n ? ctx->d_small + 64 : nullptr, log_n, n_cols, coset_count,
-                          in_col_stride, out_col_stride, ctx->stream, bj::front_table(ctx));
+                          in_col_stride, out_col_stride, ctx->stream, bj::front_table(ctx), tiled_in);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
+
+// The monomial layout bj_prove keeps for 2^log_n-row columns: tiled (ntt_r16.hip) where the two-pass plan runs, natural elsewhere.
+bool mono_tiled(unsigned log_n) { return log_n == 22 && bj::env().ntt_two_pass && bj::env().mono_tiled && !bj::env().ntt_generic; }
+
+// ifft_natural_to_natural (fft/mod.rs:464-491) on the main domain with the result left in the TILED layout: front pass into scratch,
+// last pass storing the bit-reversed, 1/n-scaled positions directly — two HBM passes, no bit-reversal pass.  Columns on 16-byte
+// boundaries; d_in may equal d_out.
+int intt_to_tiled(bj_ctx *ctx, const u64 *d_in, size_t in_col_stride, u64 *d_out, size_t out_col_stride, unsigned log_n, unsigned n_cols) {
+    if (n_cols == 0) return BJ_OK;
+    if (!mono_tiled(log_n) || ((uintptr_t)d_in % 16) || ((uintptr_t)d_out % 16) || in_col_stride % 2 || out_col_stride % 2)
+        return fail(ctx, BJ_ERR_UNSUPPORTED, "inverse transform into the tiled layout: 2^22-word columns on 16-byte boundaries only");
+    if (int rc = ensure_twiddles(ctx, log_n, true)) return rc;
+    const size_t n = (size_t)1 << log_n;
+    const size_t cap_elems = (size_t)1 << 27;
+    unsigned group = (unsigned)(cap_elems / n);
+    if (group > n_cols) group = n_cols;
+    if (int rc = ensure_scratch(ctx, (size_t)group * n)) return rc;
+    const u64 n_inv = gl::inv(gl::canon((u64)n % gl::P));
+    for (unsigned c0 = 0; c0 < n_cols; c0 += group) {
+        const unsigned nc = n_cols - c0 < group ? n_cols - c0 : group;
+        bj::launch_ntt_front10(d_in + (size_t)c0 * in_col_stride, ctx->d_scratch, ctx->tw_inv, nullptr, bj::front_table(ctx), log_n, nc, 1,
+                               in_col_stride, n, ctx->stream);
+        bj::launch_ntt_local12_pair_tiled(ctx->d_scratch, d_out + (size_t)c0 * out_col_stride, ctx->tw_inv, n_inv, nc, n, out_col_stride, ctx->stream);
+    }
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;
 }
 }  // namespace bj
 }  // extern "C++"
+
+int bj_monomials_tiled(unsigned log_n) { return bj::mono_tiled(log_n) ? 1 : 0; }
+
+int bj_intt_batch_tiled(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols, size_t col_stride) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_intt_batch_tiled", d_in, d_out, log_n, n_cols, col_stride)) return rc;
+    return bj::intt_to_tiled(ctx, d_in, col_stride, d_out, col_stride, log_n, n_cols);
+}
+
+int bj_lde_cosets_batch_tiled(bj_ctx *ctx, const uint64_t *d_mono_tiled, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                              unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0 || coset_count == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_lde_cosets_batch_tiled", d_mono_tiled, d_out, log_n, n_cols, col_stride)) return rc;
+    if (log_lde == 0 || log_lde > 6 || log_n + log_lde > 32) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch_tiled: lde factor must be 2..64 inside the two-adicity");
+    const unsigned L = 1u << log_lde;
+    if (coset_begin >= L || coset_count > L - coset_begin)
+        return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch_tiled: coset range outside [0, lde_factor)");
+    if (d_out == d_mono_tiled) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_lde_cosets_batch_tiled: output must not alias the monomials");
+    return bj::lde_cosets_strided(ctx, d_mono_tiled, col_stride, d_out, ((size_t)coset_count) << log_n, log_n, n_cols, log_lde,
+                                  coset_begin, coset_count, true);
+}
+
+int bj_tiled_permute_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols, size_t col_stride,
+                           int to_tiled) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_cols == 0) return BJ_OK;
+    if (int rc = check_ntt_args(ctx, "bj_tiled_permute_batch", d_in, d_out, log_n, n_cols, col_stride)) return rc;
+    if (log_n != 22) return fail(ctx, BJ_ERR_UNSUPPORTED, "bj_tiled_permute_batch: the tiled layout is defined for 2^22-word columns");
+    if (d_in == d_out) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_tiled_permute_batch: out of place only");
+    bj::launch_tiled_permute(d_in, d_out, n_cols, col_stride, col_stride, to_tiled != 0, ctx->stream);
+    BJ_CHECK_LAUNCH(ctx);
+    return BJ_OK;
+}
 
 int bj_lde_cosets_batch(bj_ctx *ctx, const uint64_t *d_mono, size_t col_stride, uint64_t *d_out, unsigned log_n,
                         unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count) {

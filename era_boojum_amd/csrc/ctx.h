@@ -12,6 +12,10 @@
 
 #define BJ_MAX_KERNEL_PROBES 12
 
+namespace bj {
+struct Pipeline;   // prove_async.hip: the two lanes of bj_prove_async
+}
+
 struct bj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -63,6 +67,7 @@ struct bj_ctx {
         bool closed = false;      // the closing event was recorded in THIS proof (an unclosed probe still holds the previous proof's)
     } probes[BJ_MAX_KERNEL_PROBES];
     unsigned probe_n = 0;
+    bj::Pipeline *pipe = nullptr;   // bj_prove_async: created on first use, destroyed with the context
 };
 
 namespace bj {
@@ -77,6 +82,11 @@ int h2d_async(bj_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
 inline gl::u64 *front_table(bj_ctx *ctx) { return ctx->d_small + 64 + 64 * 32 + 4096; }   // BJ_FRONT_TABLE_WORDS (kernels.h)
+unsigned setup_world(const bj_setup *s);         // ranks of the proof a setup belongs to (1: single device)
+int prove_host_copy_first(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+                          const uint64_t *h_public_values, bj_proof **out);
+void pipeline_destroy(bj_ctx *ctx);              // waits for the asynchronous proofs in flight, ends the lanes
+int pipeline_release_workspace(bj_ctx *ctx);    // bj_ctx_release_workspace on every idle lane
 int arena_reset(bj_ctx *ctx, size_t need_elems);
 int arena_drop_slabs(bj_ctx *ctx);
 gl::u64 *arena_alloc(bj_ctx *ctx, size_t elems);   // nullptr if the reservation was too small
@@ -84,7 +94,11 @@ gl::u64 *arena_alloc(bj_ctx *ctx, size_t elems);   // nullptr if the reservation
 void *tmp_alloc(bj_ctx *ctx, size_t bytes, bool *from_arena);
 void tmp_free(bj_ctx *ctx, void *p, bool from_arena);
 int lde_cosets_strided(bj_ctx *ctx, const gl::u64 *d_mono, size_t in_col_stride, gl::u64 *d_out, size_t out_col_stride,
-                       unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count);
+                       unsigned log_n, unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count,
+                       bool tiled_in = false);
+bool mono_tiled(unsigned log_n);   // the monomial layout of bj_prove for this trace length (abi.hip)
+int intt_to_tiled(bj_ctx *ctx, const gl::u64 *d_in, size_t in_col_stride, gl::u64 *d_out, size_t out_col_stride, unsigned log_n,
+                  unsigned n_cols);
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 inline unsigned log2_exact(size_t x) {
     unsigned r = 0;

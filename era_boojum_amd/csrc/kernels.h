@@ -19,11 +19,13 @@ struct EnvConfig {
     int ntt_first4_v = 2;               // BJ_NTT_FIRST4_V: indices per lane of the four-round front pass
     int ntt_first4_mode = 0;            // BJ_NTT_FIRST4_MODE: 0 inputs of the front pass kept in registers across the cosets (round 3: two waves per SIMD); 3 / 4: re-read per coset (L2), that many waves
     bool ntt_two_pass = true;           // BJ_NTT_TWO_PASS=0: 2^22-point transforms as 4 + 8 + 10 rounds (rounds 3-5) instead of 10 + 12
+    bool mono_tiled = true;             // BJ_MONO_TILED=0: bj_prove keeps 2^22-row monomials in natural order (inverse transforms end in a bit-reversal pass)
     bool gate_no_aot = false, gate_no_fuse = false, gate_no_jit = false;
     bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
     bool prove_no_absorb = false;
     bool copy_perm_wide_k = false;       // BJ_COPY_PERM_WIDE_K: quotient_copy_perm with 64-bit non-residue products even when they fit 32 bits (A/B, tests)
     bool prove_uniform_groups = false;   // BJ_PROVE_UNIFORM_GROUPS: bj_prove's round-4 plan (equal groups, one absorption per eight columns)
+    bool async_no_copy_first = false;    // BJ_ASYNC_NO_COPY_FIRST: bj_prove_async lanes always take bj_prove's group-wise transfer (A/B)
     unsigned prove_h2d_group = 8;
     size_t nodes_lanepar_max = 16384;
     std::string jit_cache_dir, rccl_lib;
@@ -39,7 +41,9 @@ void launch_round_scales(u64 *d_out, const u64 *h_shifts, unsigned n_cosets, uns
 constexpr size_t BJ_FRONT_TABLE_WORDS = 64 * 1024;
 void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
                        unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s,
-                       u64 *d_front_table = nullptr);
+                       u64 *d_front_table = nullptr, bool tiled_in = false);
+// true when launch_ntt_passes would take the two-pass plan for these arguments (the only plan that reads the tiled layout)
+bool ntt_two_pass_applies(const u64 *d_in, const u64 *d_out, unsigned log_n, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride);
 void launch_bitrev_scale(const u64 *d_in, u64 *d_out, unsigned log_n, unsigned n_cols, size_t in_col_stride,
                          size_t out_col_stride, u64 scale, u64 step, hipStream_t s);
 void launch_canonicalize(u64 *d, size_t n, hipStream_t s);
@@ -50,7 +54,11 @@ void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round
                         unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride,
                         size_t out_col_stride, unsigned rounds /* 12, or 10 / 9 behind launch_ntt_first4 / first5 */, hipStream_t s);
 void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
-                        unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s);
+                        unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s, bool tiled_in = false);
+// 2^22-word columns in the tiled layout (ntt_r16.hip: tiled_index): last pass of an inverse transform storing it, re-layout kernel
+void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, u64 scale, unsigned n_cols, size_t in_col_stride,
+                                   size_t out_col_stride, hipStream_t s);
+void launch_tiled_permute(const u64 *in, u64 *out, unsigned n_cols, size_t in_col_stride, size_t out_col_stride, bool to_tiled, hipStream_t s);
 void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
                        unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s);
 void launch_ntt_first4(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,

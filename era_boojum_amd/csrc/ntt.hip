@@ -259,9 +259,13 @@ static bool force_generic() { return bj::env().ntt_generic; }
 // Pass plan.  log_n < 12 (or BJ_NTT_GENERIC=1): generic LDS passes.  Otherwise the last 12 rounds run in
 // ntt_local12, the rounds in front of it in radix-16 strided passes of 8 or 4 rounds, and a remainder of 1..3
 // rounds (log_n not of the form 12 + 4k) in one generic strided pass at the very front.
+bool ntt_two_pass_applies(const u64 *d_in, const u64 *d_out, unsigned log_n, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride) {
+    const bool io16 = ((uintptr_t)d_out % 16) == 0 && out_col_stride % 2 == 0 && ((uintptr_t)d_in % 16) == 0 && in_col_stride % 2 == 0;
+    return log_n == 22 && n_cosets <= 64 && io16 && bj::env().ntt_two_pass && !force_generic();
+}
 void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *d_round_scale, unsigned log_n,
                        unsigned n_cols, unsigned n_cosets, size_t in_col_stride, size_t out_col_stride,
-                       hipStream_t s, u64 *d_front_table) {
+                       hipStream_t s, u64 *d_front_table, bool tiled_in) {
     const size_t n = (size_t)1 << log_n;
     if (log_n == 0) {  // size-1 transform: canonicalising copy
         launch_generic_pass(d_in, d_out, d_tw, nullptr, 0, 0, 0, 0, n_cols, n_cosets, in_col_stride, 0,
@@ -298,9 +302,8 @@ void launch_ntt_passes(const u64 *d_in, u64 *d_out, const u64 *d_tw, const u64 *
     unsigned front = log_n - 12;
     // 22 rounds in two passes: ten in ntt_front10 (every coset from one tile of the caller's column), twelve in ntt_local12
     // (the front pass moves 16 bytes per lane on both sides: columns on 16-byte boundaries)
-    const bool io16 = ((uintptr_t)d_out % 16) == 0 && out_col_stride % 2 == 0 && ((uintptr_t)d_in % 16) == 0 && in_col_stride % 2 == 0;
-    if (log_n == 22 && d_front_table && n_cosets <= 64 && io16 && bj::env().ntt_two_pass) {
-        launch_ntt_front10(src, d_out, d_tw, d_round_scale, d_front_table, log_n, n_cols, n_cosets, src_col_stride, out_col_stride, s);
+    if (d_front_table && ntt_two_pass_applies(d_in, d_out, log_n, n_cosets, in_col_stride, out_col_stride)) {
+        launch_ntt_front10(src, d_out, d_tw, d_round_scale, d_front_table, log_n, n_cols, n_cosets, src_col_stride, out_col_stride, s, tiled_in);
         advance(10);
         launch_ntt_local12(src, d_out, d_tw, d_round_scale, log_n, n_cols, n_cosets, src_col_stride, src_coset_stride,
                            out_col_stride, 12, s);

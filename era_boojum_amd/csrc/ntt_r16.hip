@@ -562,6 +562,16 @@ struct F10Args {
     unsigned log_n, n_cols, cols_per_block, n_cosets;
     size_t in_col_stride, out_col_stride;
 };
+// TILED layout of a 2^22-word column (the monomial form between an inverse transform and the extensions that read it):
+// element e = m * 4096 + r * 16 + l (m: ten bits, r: eight, l: four) sits at word
+//     tiled(e) = r * 16384 + (l >> 1) * 2048 + m * 2 + (l & 1)
+// — the 16384 words one front-pass tile reads are contiguous, ordered so that (a) the pair of 4096-word chunks (b, b + 512) of the
+// inverse transform's last pass, whose results are the words (m, l = 2k) and (m, l = 2k + 1) of FOUR tiles for every m, leaves them
+// as 16-byte words in runs of 1 KB per wave store — the bit reversal of ifft_natural_to_natural (fft/mod.rs:464-491) happens in the
+// store addresses, no pass of its own — and (b) the front pass fetches 16-byte words (m, l pair) for its LDS tile in [m][l] order as before.
+__host__ __device__ constexpr size_t tiled_index(size_t e) {
+    return ((e >> 4) & 255u) * 16384u + ((e >> 1) & 7u) * 2048u + (e >> 12) * 2u + (e & 1u);
+}
 __global__ void front10_table_kernel(u64 *out, const u64 *__restrict__ T, const u64 *__restrict__ round_scale, unsigned n_cosets) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_cosets * 1024u) return;
@@ -628,8 +638,9 @@ typedef void __attribute__((address_space(3))) *f10_ldst;
 #ifndef BJ_F10_PRIO
 #define BJ_F10_PRIO 1
 #endif
-template <bool UNIT_FIRST, int LB>
+template <bool UNIT_FIRST, int LB, bool TILED_IN = false>
 __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
+    static_assert(!TILED_IN || LB == 4, "the tiled layout is the one of full-line tiles");
     constexpr u32 NT = 64u << LB, TILE_E = 1024u << LB, ROWS = 128u >> LB;   // threads, elements per tile, mid rows per 1-KB DMA piece
     __shared__ u64 lds[TILE_E + 1024];      // ONE object: tile (64 / 128 KB), twiddle table of this workgroup's coset (8 KB)
     u64 *lds_tw = lds + TILE_E;
@@ -657,17 +668,20 @@ __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
     const u32 offC = (((m92 * 4u) << s_log) + lhiC * 4u) * 8u;
     const u32 ixB1 = (((mhB * 64u + mllB) << LB) + lB) * 8u, ixB2 = f10_bc<LB>(mhB * 64u + mllB, lB) * 8u, ixC = f10_bc<LB>(m92 * 4u, lhiC * 4u) * 8u;
     // DMA source of this lane inside a piece: piece p = mid rows [ROWS p, ROWS (p + 1)), lane = (row, lo pair)
-    const u32 dma_off = (((lane >> (LB - 1)) << s_log) + (lane & ((1u << (LB - 1)) - 1u)) * 2u) * 8u;
+    // (tiled input: the lane's 16 bytes are the words (row, l pair) at pair * 2048 + row * 2 of the tile's 16384 contiguous words)
+    const u32 dma_off = TILED_IN ? ((lane & 7u) * 2048u + (lane >> 3) * 2u) * 8u
+                                 : (((lane >> (LB - 1)) << s_log) + (lane & ((1u << (LB - 1)) - 1u)) * 2u) * 8u;
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
     if (col0 >= col1) return;
     auto request_tile = [&](unsigned col) {
         const char __attribute__((address_space(1))) *src =
-            (const char __attribute__((address_space(1))) *)uniform_gptr(a.in + (size_t)col * a.in_col_stride + lo0) + dma_off;
+            (const char __attribute__((address_space(1))) *)uniform_gptr(a.in + (size_t)col * a.in_col_stride + (TILED_IN ? (size_t)tile * TILE_E : lo0)) + dma_off;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const u32 piece = wave * 8u + k;
-            __builtin_amdgcn_global_load_lds((f10_gsrc)(src + (((size_t)piece * ROWS) << s_log) * 8u), (f10_ldst)(lds + piece * 128u), 16, 0, 0);
+            const size_t piece_off = TILED_IN ? (size_t)piece * ROWS * 16u : (((size_t)piece * ROWS) << s_log) * 8u;
+            __builtin_amdgcn_global_load_lds((f10_gsrc)(src + piece_off), (f10_ldst)(lds + piece * 128u), 16, 0, 0);
         }
     };
     if (wave < 8u) {
@@ -729,6 +743,127 @@ __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// LAST pass of a 2^22-point INVERSE transform whose result is kept in the tiled layout: the twelve local rounds of ntt_local12 on the
+// chunk pair (b, b + 512) — one after the other through one LDS tile — the factor 1 / n, and the store.  After step C lane t holds
+// the words p = 16 t + j of a chunk; their natural index is bitrev22(4096 b + p) = m * 4096 + r * 16 + l with
+//     m = rev10(p & 1023) = rev4(j) * 64 + rev6(t & 63),   r = rev2(p >> 10) * 64 + (rev10(b) >> 4),   l = rev10(b) & 15,
+// and rev10(b + 512) = rev10(b) + 1: the two chunks are the two halves of every 16-byte word (m, l pair) of the tiled layout, and
+// for a fixed register j the 64 lanes of a wave cover 64 consecutive m — one wave store = 1 KB contiguous, straight from the
+// registers (ntt_local12's third transpose through LDS, there only for the stores' sake, is not needed here).  Twiddles of both
+// chunks stay resident (2 x 15 pairs in VGPRs for step C, 2 x (16 + 256) words in LDS): the kernel runs two waves per SIMD.
+struct PairArgs {
+    const u64 *in;
+    u64 *out;
+    const u64 *tw;           // bit-reversed twiddle table of the inverse root
+    u64 scale;               // 1 / n
+    unsigned n_cols, cols_per_block;
+    size_t in_col_stride, out_col_stride;
+};
+__global__ void __launch_bounds__(256, 2) ntt_local12_pair_tiled_kernel(PairArgs a) {
+    __shared__ u64 lds[LDS_ELEMS + 2 * 16 + 2 * 16 * 16];
+    u64 *lds_twA = lds + LDS_ELEMS;           // [chunk][15 (+1)]
+    u64 *lds_twB = lds_twA + 32;              // [chunk][t >> 4][15 (+1)]
+    const u32 t = threadIdx.x;
+    const u32 bp = blockIdx.x;                // chunks bp and bp + 512
+    constexpr unsigned r0 = 10;
+    u64 twC[2][15];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const u32 b = bp + 512u * h;
+        load_step_twiddles<false>(twC[h], a.tw, b * 256 + t, r0 + 8, nullptr);
+        if (t < 15) {
+            const int s = 31 - __clz(t + 1);
+            const int g = (int)(t + 1) - (1 << s);
+            lds_twA[h * 16 + t] = a.tw[((size_t)b << s) + g];
+        }
+        if (t < 240) {
+            const u32 m = t / 15, i = t % 15;
+            const int s = 31 - __clz(i + 1);
+            const int g = (int)(i + 1) - (1 << s);
+            lds_twB[h * 256 + m * 16 + i] = a.tw[(((size_t)b * 16 + m) << s) + g];
+        }
+    }
+    __syncthreads();
+    const unsigned col0 = blockIdx.y * a.cols_per_block;
+    const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
+    const u32 ta = t >> 4, tc = t & 15;
+    const u32 wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const u32 rb = gl::bitrev32(bp, 10);                      // even: bp < 512
+    const size_t tile_off = ((size_t)(gl::bitrev32(wave, 2) * 64u + (rb >> 4))) * 16384u + (size_t)((rb & 15u) >> 1) * 2048u;
+    const u32 off_st = gl::bitrev32(t & 63u, 6) * 16u;        // bytes: word pair m = rev6(lane) (+ rev4(j) * 64, a constant per store)
+    for (unsigned col = col0; col < col1; col++) {
+        u64 y[16];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const gcptr src = uniform_gptr(a.in + (size_t)col * a.in_col_stride + (size_t)(bp + 512u * h) * TILE);
+            u64 x[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = ld_off(src + j * 256, t * 8u);
+            radix16<false>(x, lds_twA + h * 16);
+#pragma unroll
+            for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = lds[pad(ta * 256 + j * 16 + tc)];
+            __syncthreads();
+            radix16_lds<false>(x, lds_twB + h * 256 + ta * 16);
+#pragma unroll
+            for (int j = 0; j < 16; j++) lds[pad(ta * 256 + j * 16 + tc)] = x[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = lds[pad(t * 16 + j)];
+            __syncthreads();
+            radix16<false>(x, twC[h]);
+            if (h == 0) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) y[j] = gl::mul(x[j], a.scale);
+            } else {
+                const gptr dst = (gptr)uniform_gptr(a.out + (size_t)col * a.out_col_stride + tile_off);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    constexpr u32 R4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+                    st_off2(dst + (size_t)R4[j] * 128u, off_st, y[j], gl::mul(x[j], a.scale));
+                }
+            }
+        }
+    }
+}
+
+// natural <-> tiled re-layout of 2^22-word columns (the quotient's chunks, whose monomials come out of a transform of another size,
+// and the operator-level entry points): block = (tile r, 64 consecutive m), 1024 words through LDS; natural side 64 runs of 128
+// bytes, tiled side 8 runs of 1 KB
+__global__ void __launch_bounds__(256) tiled_permute_kernel(const u64 *in, u64 *out, size_t in_col_stride, size_t out_col_stride, int to_tiled) {
+    __shared__ u64 tile[64 * 17];
+    const u32 t = threadIdx.x, r = blockIdx.x >> 4, m0 = (blockIdx.x & 15u) * 64u;
+    const u64 *src = in + (size_t)blockIdx.y * in_col_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_col_stride;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 q = t + 256u * k;
+        if (to_tiled) {          // natural read: q = (m local, l)
+            const u32 ml = q >> 4, l = q & 15u;
+            tile[ml * 17 + l] = src[((size_t)(m0 + ml) << 12) + r * 16u + l];
+        } else {                 // tiled read: q = (pair, m local, l & 1)
+            const u32 pair = q >> 7, ml = (q >> 1) & 63u, lb = q & 1u;
+            tile[ml * 17 + pair * 2 + lb] = src[(size_t)r * 16384u + pair * 2048u + (m0 + ml) * 2u + lb];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 q = t + 256u * k;
+        if (to_tiled) {
+            const u32 pair = q >> 7, ml = (q >> 1) & 63u, lb = q & 1u;
+            dst[(size_t)r * 16384u + pair * 2048u + (m0 + ml) * 2u + lb] = tile[ml * 17 + pair * 2 + lb];
+        } else {
+            const u32 ml = q >> 4, l = q & 15u;
+            dst[((size_t)(m0 + ml) << 12) + r * 16u + l] = tile[ml * 17 + l];
+        }
+    }
+}
+
 static unsigned pick_cols_per_block(unsigned tiles, unsigned n_cols, unsigned n_cosets) {
     // amortise the per-workgroup twiddle preparation over several columns, but keep >= ~4096 workgroups in flight
 #ifndef BJ_R16_CPB
@@ -760,6 +895,18 @@ void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round
         hipLaunchKernelGGL((ntt_local12_kernel<true, 12>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((ntt_local12_kernel<false, 12>), grid, dim3(256), 0, s, a);
+}
+
+// last pass of a 2^22-point inverse transform into the tiled layout (in: the front pass's output, chunk b at b * 4096)
+void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, u64 scale, unsigned n_cols, size_t in_col_stride,
+                                   size_t out_col_stride, hipStream_t s) {
+    unsigned cpb = 8;
+    while (cpb > 1 && (size_t)512 * ((n_cols + cpb - 1) / cpb) < 2048) cpb >>= 1;
+    PairArgs a{in, out, tw, scale, n_cols, cpb, in_col_stride, out_col_stride};
+    hipLaunchKernelGGL(ntt_local12_pair_tiled_kernel, dim3(512, (n_cols + cpb - 1) / cpb), dim3(256), 0, s, a);
+}
+void launch_tiled_permute(const u64 *in, u64 *out, unsigned n_cols, size_t in_col_stride, size_t out_col_stride, bool to_tiled, hipStream_t s) {
+    hipLaunchKernelGGL(tiled_permute_kernel, dim3(256 * 16, n_cols), dim3(256), 0, s, in, out, in_col_stride, out_col_stride, to_tiled ? 1 : 0);
 }
 
 void launch_ntt_strided8(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
@@ -831,7 +978,7 @@ void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
 #define BJ_F10_LB 4   // lo values per tile = 2^LB: 3 -> 64-byte runs, 512 threads, two workgroups per CU; 4 -> full lines, 1024 threads, one
 #endif
 void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
-                        unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s) {
+                        unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s, bool tiled_in) {
     hipLaunchKernelGGL(front10_table_kernel, dim3(n_cosets * 4), dim3(256), 0, s, d_table, tw, round_scale, n_cosets);
     constexpr int LB = BJ_F10_LB;
     const unsigned tiles = 1u << (log_n - 10 - LB);
@@ -842,7 +989,12 @@ void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round
         while (cpb > 1 && (size_t)tiles * nc * ((n_cols + cpb - 1) / cpb) < 4096) cpb >>= 1;
         F10Args a{in, out + (size_t)c0 * n, d_table + (size_t)c0 * 1024, log_n, n_cols, cpb, nc, in_col_stride, out_col_stride};
         dim3 grid(tiles * nc, (n_cols + cpb - 1) / cpb, 1);
-        if (round_scale)
+        if (tiled_in && LB == 4) {
+            if (round_scale)
+                hipLaunchKernelGGL((ntt_front10_kernel<false, 4, true>), grid, dim3(1024), 0, s, a);
+            else
+                hipLaunchKernelGGL((ntt_front10_kernel<true, 4, true>), grid, dim3(1024), 0, s, a);
+        } else if (round_scale)
             hipLaunchKernelGGL((ntt_front10_kernel<false, LB>), grid, dim3(64u << LB), 0, s, a);
         else
             hipLaunchKernelGGL((ntt_front10_kernel<true, LB>), grid, dim3(64u << LB), 0, s, a);

@@ -1,0 +1,203 @@
+// bj_prove_async / bj_proof_wait: two proofs in flight on ONE device from ONE host thread (include/boojum_hip.h).
+//
+// The call site replaced is a host loop over witnesses around prove_cpu_basic (src/cs/implementations/prover.rs:153-168,
+// convenience.rs:119-196).  A proof ends in a latency-bound tail — ~100 lane-parallel node layers, the FRI tail oracles, ~15
+// transcript round trips between host and device — during which most of the chip idles, and it starts with a PCIe transfer
+// during which the CUs only transform the columns that have landed.  Neither can be filled from inside the proof (the transcript
+// serialises it); the next proof's head can fill both.  A context therefore owns two LANES: each a private sub-context (its own
+// non-blocking HIP stream, copy stream, workspace arena, witness staging, twiddle tables, staging ring) driven by its own worker
+// thread.  bj_prove_async hands the witness to the next lane in turn and returns; the worker runs the ordinary bj_prove on the
+// lane's sub-context.  Nothing is shared between the lanes but the (read-only) setup, so every proof is the bytes bj_prove gives.
+// At most two proofs are in flight: a third submission waits for the lane it is due on.
+#include "ctx.h"
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct bj_ticket {
+    bj_ctx *parent = nullptr;
+    unsigned lane = 0;
+    const bj_setup *setup = nullptr;
+    const uint64_t *h_variables = nullptr, *h_multiplicities = nullptr;
+    std::vector<uint64_t> public_values;
+    bool has_public = false;
+    // result (written by the lane's worker under the lane's mutex)
+    bool done = false;
+    int rc = BJ_OK;
+    bj_proof *proof = nullptr;
+    std::string err;
+};
+
+namespace bj {
+
+struct Lane {
+    bj_ctx *sub = nullptr;
+    hipStream_t stream = nullptr;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    bj_ticket *job = nullptr;      // submitted, not finished
+    bool quit = false;
+    Lane *sibling = nullptr;
+
+    bool busy() {
+        std::lock_guard<std::mutex> lk(m);
+        return job != nullptr;
+    }
+
+    void run() {
+        for (;;) {
+            bj_ticket *t;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || (job && !job->done); });
+                if (quit) return;
+                t = job;
+            }
+            bj_proof *p = nullptr;
+            const uint64_t *pub = t->has_public ? t->public_values.data() : nullptr;
+            // the other lane is proving: let the whole witness cross PCIe under ITS kernels and prove as on a resident witness;
+            // alone on the device: bj_prove's own overlap of the transfer with the hashing of the columns that have landed
+            const bool overlapped = sibling && sibling->busy() && !bj::env().async_no_copy_first;
+            const int rc = overlapped ? prove_host_copy_first(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p)
+                                      : bj_prove(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                t->rc = rc;
+                t->proof = p;
+                if (rc) t->err = sub->err;
+                t->done = true;
+                job = nullptr;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+struct Pipeline {
+    Lane lanes[2];
+    unsigned next = 0;
+    unsigned created = 0;
+};
+
+static int lane_start(bj_ctx *ctx, Lane &L) {
+    if (int rc = bj_ctx_create(ctx->device, &L.sub)) return fail(ctx, rc, "bj_prove_async: creating a lane's context failed");
+    if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) {
+        bj_ctx_destroy(L.sub);
+        L.sub = nullptr;
+        return fail(ctx, BJ_ERR_HIP, "bj_prove_async: creating a lane's stream failed");
+    }
+    L.sub->stream = L.stream;
+    L.sub->hasher = ctx->hasher;
+    L.worker = std::thread([&L] { L.run(); });
+    return BJ_OK;
+}
+
+void pipeline_destroy(bj_ctx *ctx) {
+    Pipeline *P = ctx->pipe;
+    if (!P) return;
+    for (unsigned i = 0; i < P->created; i++) {
+        Lane &L = P->lanes[i];
+        {
+            std::unique_lock<std::mutex> lk(L.m);
+            L.cv.wait(lk, [&] { return L.job == nullptr; });   // a proof in flight finishes first (its ticket stays valid)
+            L.quit = true;
+        }
+        L.cv.notify_all();
+        if (L.worker.joinable()) L.worker.join();
+        if (L.sub) bj_ctx_destroy(L.sub);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    delete P;
+    ctx->pipe = nullptr;
+}
+
+int pipeline_release_workspace(bj_ctx *ctx) {
+    Pipeline *P = ctx->pipe;
+    if (!P) return BJ_OK;
+    for (unsigned i = 0; i < P->created; i++) {
+        Lane &L = P->lanes[i];
+        std::unique_lock<std::mutex> lk(L.m);
+        if (L.job) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_ctx_release_workspace: an asynchronous proof is running");
+        if (int rc = bj_ctx_release_workspace(L.sub)) return fail(ctx, rc, "%s", L.sub->err.c_str());
+    }
+    return BJ_OK;
+}
+
+}  // namespace bj
+
+extern "C" {
+
+int bj_prove_async(bj_ctx *ctx, const bj_setup *setup, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+                   const uint64_t *h_public_values, bj_ticket **out) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_async: null out pointer");
+    *out = nullptr;
+    if (!setup || !h_variables) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_async: null argument");
+    unsigned n_pub = 0;
+    if (int rc = bj_setup_shape(setup, nullptr, nullptr, nullptr, &n_pub)) return bj::fail(ctx, rc, "bj_prove_async: bad setup");
+    if (bj::setup_world(setup) != 1)
+        return bj::fail(ctx, BJ_ERR_UNSUPPORTED, "bj_prove_async: single-device setups only (the ranks of a sharded proof are concurrent already)");
+    if (n_pub && !h_public_values) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove_async: public input values required");
+    if (!ctx->pipe) {
+        ctx->pipe = new bj::Pipeline();
+        ctx->pipe->lanes[0].sibling = &ctx->pipe->lanes[1];
+        ctx->pipe->lanes[1].sibling = &ctx->pipe->lanes[0];
+    }
+    bj::Pipeline *P = ctx->pipe;
+    const unsigned li = P->next;
+    bj::Lane &L = P->lanes[li];
+    if (li >= P->created) {
+        if (int rc = bj::lane_start(ctx, L)) return rc;
+        P->created = li + 1;
+    }
+    bj_ticket *t = new bj_ticket();
+    t->parent = ctx;
+    t->lane = li;
+    t->setup = setup;
+    t->h_variables = h_variables;
+    t->h_multiplicities = h_multiplicities;
+    if (n_pub) {
+        t->public_values.assign(h_public_values, h_public_values + n_pub);   // the caller's array may go away; the witness may not
+        t->has_public = true;
+    }
+    {
+        std::unique_lock<std::mutex> lk(L.m);
+        L.cv.wait(lk, [&] { return L.job == nullptr; });   // at most two in flight: the proof this lane still runs comes first
+        L.job = t;
+    }
+    L.cv.notify_all();
+    P->next = (li + 1) % 2;
+    *out = t;
+    return BJ_OK;
+}
+
+int bj_proof_wait(bj_ticket *t, bj_proof **out) {
+    if (!t) return BJ_ERR_INVALID_ARG;
+    bj_ctx *ctx = t->parent;
+    bj::Lane &L = ctx->pipe->lanes[t->lane];
+    {
+        std::unique_lock<std::mutex> lk(L.m);
+        L.cv.wait(lk, [&] { return t->done; });
+    }
+    const int rc = t->rc;
+    if (rc) ctx->err = t->err;
+    if (out)
+        *out = t->proof;
+    else if (t->proof)
+        bj_proof_destroy(t->proof);
+    delete t;
+    return rc;
+}
+
+int bj_proof_poll(const bj_ticket *t) {
+    if (!t) return BJ_ERR_INVALID_ARG;
+    bj::Lane &L = t->parent->pipe->lanes[t->lane];
+    std::lock_guard<std::mutex> lk(L.m);
+    return t->done ? 1 : 0;
+}
+
+}  // extern "C"

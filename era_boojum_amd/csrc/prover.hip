@@ -101,6 +101,7 @@ struct bj_setup {
     size_t cap_l = 0;              // cap nodes of the local subtree (cap_size / world)
     u64 *d_nat = nullptr;          // [n_cols][n] natural-order values (replicated)
     u64 *d_mono = nullptr;         // [n_cols][n] monomial forms (replicated; the DEEP numerator is combined on them)
+    bool tiled = false;            // monomials (these and every proof's) in the tiled layout of ntt_r16.hip: 2^22-row traces
     u64 *d_lde = nullptr;          // [n_cols][cl][n]
     u64 *d_tree = nullptr;         // local subtree
     u64 *d_non_res = nullptr;
@@ -168,6 +169,7 @@ struct StageTimer {
 }  // namespace
 
 namespace bj {
+unsigned setup_world(const bj_setup *s) { return s ? s->sh.world : 0; }
 int all_gather(bj_ctx *ctx, const Shard &sh, const u64 *d_send, u64 *d_recv, size_t elems) {
     if (!elems) return BJ_OK;
     if (sh.world == 1) {
@@ -498,8 +500,10 @@ int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *c, const uint64_t *h_
     {   // monomials (kept), LDE into d_lde
         if (hipMalloc((void **)&s->d_mono, (size_t)s->n_cols * n * 8) != hipSuccess)
             return bail(bj::fail(ctx, BJ_ERR_OOM, "bj_setup_create: device allocation failed"));
-        rc = bj_intt_batch(ctx, s->d_nat, s->d_mono, s->log_n, s->n_cols, n, 1);
-        if (!rc) rc = bj_lde_cosets_batch(ctx, s->d_mono, n, s->d_lde, s->log_n, s->n_cols, s->log_L, s->c0, s->cl);
+        s->tiled = bj::mono_tiled(s->log_n);
+        rc = s->tiled ? bj::intt_to_tiled(ctx, s->d_nat, n, s->d_mono, n, s->log_n, s->n_cols)
+                      : bj_intt_batch(ctx, s->d_nat, s->d_mono, s->log_n, s->n_cols, n, 1);
+        if (!rc) rc = bj::lde_cosets_strided(ctx, s->d_mono, n, s->d_lde, s->Ls, s->log_n, s->n_cols, s->log_L, s->c0, s->cl, s->tiled);
         if (!rc) rc = bj_sync(ctx);
         if (rc) return bail(rc);
     }
@@ -657,7 +661,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                     + 4 * N + (N * sh.world) / 2                                                   // FRI layers + trees, DEEP argument blocks
                     + (sh.world > 1 ? 10 * n : 0)                                                  // sharded DEEP numerators: slices + gather staging
                     + (hw ? 4 * N : 0)                                                             // host witness hashed in groups: the leaves' capacity words
-                    + (size_t)2 * N * (1 + S->pub_cols.size());                                    // DEEP: one extended numerator per large opening set beyond the first
+                    + (size_t)2 * N * (1 + S->pub_cols.size())                                     // DEEP: one extended numerator per large opening set beyond the first
+                    + (S->tiled ? 2 * Q : 0);                                                      // the quotient's chunks once more, in the tiled layout
         // `need` is an upper bound by construction of the list above — checked on every proof the test suite makes (the binding
         // raises when a proof had to take an overflow slab) — and a context that has seen a larger proof keeps its size
         if (need < ctx->arena_learned) need = ctx->arena_learned;
@@ -721,10 +726,18 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     if ((rc = wit_lde.alloc(ctx, (size_t)nW * Ln))) return rc;
     if ((rc = mono.alloc(ctx, (size_t)nW * n))) return rc;
     if ((rc = mono_s2.alloc(ctx, (size_t)nS2 * n))) return rc;
+    // inverse transform of columns of the main domain into the monomial layout of this trace length; extension out of it
+    const bool tiled = S->tiled;
+    auto intt_cols = [&](const u64 *d_in, u64 *d_out, unsigned nc) -> int {
+        return tiled ? bj::intt_to_tiled(ctx, d_in, n, d_out, n, log_n, nc) : bj_intt_batch(ctx, d_in, d_out, log_n, nc, n, 1);
+    };
+    auto lde_cols = [&](const u64 *d_m, u64 *d_out, size_t out_stride, unsigned nc, unsigned log_lde, unsigned cb, unsigned cc) -> int {
+        return bj::lde_cosets_strided(ctx, d_m, n, d_out, out_stride, log_n, nc, log_lde, cb, cc, tiled);
+    };
     if (!hw) {
-        rc = bj_intt_batch(ctx, d_variables, mono.p, log_n, VW, n, 1);
-        if (!rc && has_lookup) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)VW * n, log_n, 1, n, 1);
-        if (!rc) rc = bj_lde_cosets_batch(ctx, mono.p, n, wit_lde.p, log_n, nW, S->log_L, S->c0, S->cl);
+        rc = intt_cols(d_variables, mono.p, VW);
+        if (!rc && has_lookup) rc = intt_cols(d_multiplicities, mono.p + (size_t)VW * n, 1);
+        if (!rc) rc = lde_cols(mono.p, wit_lde.p, Ln, nW, S->log_L, S->c0, S->cl);
     } else {
         // all copies are queued on the copy stream at once (they run back to back at PCIe speed); the proof stream picks the
         // groups up as they land.  Column nW - 1 is the multiplicity column when there are lookups.
@@ -794,11 +807,9 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
             const unsigned v1 = c1 < VW ? c1 : VW;
             BJ_HIP(ctx, hipStreamWaitEvent(st, ctx->copy_ev[g], 0));
-            if (c0 < v1) rc = bj_intt_batch(ctx, d_variables + (size_t)c0 * n, mono.p + (size_t)c0 * n, log_n, v1 - c0, n, 1);
-            if (!rc && has_lookup && c1 == nW) rc = bj_intt_batch(ctx, d_multiplicities, mono.p + (size_t)VW * n, log_n, 1, n, 1);
-            if (!rc)
-                rc = bj::lde_cosets_strided(ctx, mono.p + (size_t)c0 * n, n, wit_lde.p + (size_t)c0 * Ln, Ln, log_n, c1 - c0, S->log_L,
-                                            S->c0, S->cl);
+            if (c0 < v1) rc = intt_cols(d_variables + (size_t)c0 * n, mono.p + (size_t)c0 * n, v1 - c0);
+            if (!rc && has_lookup && c1 == nW) rc = intt_cols(d_multiplicities, mono.p + (size_t)VW * n, 1);
+            if (!rc) rc = lde_cols(mono.p + (size_t)c0 * n, wit_lde.p + (size_t)c0 * Ln, Ln, c1 - c0, S->log_L, S->c0, S->cl);
             if (absorb && !rc && plan[g].absorb_from != NONE) {
                 const unsigned a0 = plan[g].absorb_from;
                 bj::launch_poseidon2_leaves_absorb(wit_lde.p + (size_t)a0 * Ln, Ln, c1 - a0, N, capacity.p, wit_tree.p, a0 == 0, c1 == nW, st);
@@ -843,8 +854,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     }
     BJ_CHECK_LAUNCH(ctx);
     if ((rc = s2_lde.alloc(ctx, (size_t)nS2 * Ln))) return rc;
-    rc = bj_intt_batch(ctx, s2_nat.p, mono_s2.p, log_n, nS2, n, 1);
-    if (!rc) rc = bj_lde_cosets_batch(ctx, mono_s2.p, n, s2_lde.p, log_n, nS2, S->log_L, S->c0, S->cl);
+    rc = intt_cols(s2_nat.p, mono_s2.p, nS2);
+    if (!rc) rc = lde_cols(mono_s2.p, s2_lde.p, Ln, nS2, S->log_L, S->c0, S->cl);
     if (rc) return rc;
     if ((rc = s2_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
     rc = bj_merkle_tree_build(ctx, s2_lde.p, Ln, nS2, N, capl, s2_tree.p);
@@ -969,11 +980,17 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     if (rc) return rc;
     if (top[0] != 0 || top[1] != 0)
         return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: constraint system is not satisfied (quotient is not a polynomial; prover.rs:1425-1438)");
-    ArenaBuf q_lde, q_tree;
+    ArenaBuf q_lde, q_tree, Tt;
+    const u64 *Tm = T.p;   // the 2 q chunks of n coefficients each, in the monomial layout of this trace length
+    if (tiled) {           // they come out of a transform of another size: one re-layout pass over 2 q n words
+        if ((rc = Tt.alloc(ctx, 2 * Q))) return rc;
+        bj::launch_tiled_permute(T.p, Tt.p, 2 * q, n, n, true, st);
+        BJ_CHECK_LAUNCH(ctx);
+        Tm = Tt.p;
+    }
     if ((rc = q_lde.alloc(ctx, (size_t)2 * q * N))) return rc;
     for (unsigned e = 0; e < 2 && !rc; e++)   // chunk j of c_e -> column 2j+e (prover.rs:1445-1467)
-        rc = bj::lde_cosets_strided(ctx, T.p + (size_t)e * Q, n, q_lde.p + (size_t)e * N, 2 * N, log_n, q, S->log_fri,
-                                    sh.world > 1 ? S->c0 : 0, sh.world > 1 ? S->cl : fri);
+        rc = lde_cols(Tm + (size_t)e * Q, q_lde.p + (size_t)e * N, 2 * N, q, S->log_fri, sh.world > 1 ? S->c0 : 0, sh.world > 1 ? S->cl : fri);
     if (rc) return rc;
     if ((rc = q_tree.alloc(ctx, bj_merkle_tree_digests(N, capl) * 4))) return rc;
     rc = bj_merkle_tree_build(ctx, q_lde.p, N, 2 * q, N, capl, q_tree.p);
@@ -1010,7 +1027,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
     }
     for (unsigned j = 0; j < q; j++) {   // chunk j of the quotient: coefficients [j*n, (j+1)*n) of T's monomial form
         srcs.push_back({q_lde.p + (size_t)(2 * j) * N, q_lde.p + (size_t)(2 * j + 1) * N});
-        msrcs.push_back({T.p + (size_t)j * n, T.p + Q + (size_t)j * n});
+        msrcs.push_back({Tm + (size_t)j * n, Tm + Q + (size_t)j * n});
     }
     // every rank evaluates from ITS first coset (shift 7*w^bitrev(c0)): the polynomials have degree < n, so the value
     // is the same field element whichever coset it is interpolated from — no exchange, identical transcripts
@@ -1185,9 +1202,9 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         }
         if (r) return r;
         if (sh.world > 1)
-            r = bj_lde_cosets_batch(ctx, num_mono.p, n, num_lde.p, log_n, 2, S->log_L, S->c0, S->cl);
+            r = lde_cols(num_mono.p, num_lde.p, (size_t)S->cl << log_n, 2, S->log_L, S->c0, S->cl);
         else
-            r = bj::lde_cosets_strided(ctx, num_mono.p, n, num_lde.p, N, log_n, 2, S->log_fri, 0, fri);
+            r = lde_cols(num_mono.p, num_lde.p, N, 2, S->log_fri, 0, fri);
         if (r) return r;
         gl::e2 C{0, 0};   // sum_k ch_k * v_k
         for (size_t k = 0; k < ms.size(); k++) C = gl::e2_add(C, gl::e2_mul(e2c(ch + 2 * k), e2c(vals + 2 * k)));
@@ -1427,11 +1444,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
 
 extern "C" {
 
-int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
-             const uint64_t *h_public_values, bj_proof **out) {
-    if (int rc = bj::bind(ctx)) return rc;
-    if (!S || !h_variables || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
-    if (S->lookup_reps && !h_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
+static int stage_witness(bj_ctx *ctx, const bj_setup *S) {
     const size_t n = (size_t)1 << S->log_n, need = (size_t)(S->V + S->Wc + 1) * n;
     if (ctx->wit_stage_elems < need) {   // device staging of the witness, kept for the next proof (no 3 GB hipMalloc per proof)
         if (ctx->wit_stage) BJ_HIP(ctx, hipFree(ctx->wit_stage));
@@ -1440,6 +1453,16 @@ int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const 
         BJ_HIP(ctx, hipMalloc((void **)&ctx->wit_stage, need * 8));
         ctx->wit_stage_elems = need;
     }
+    return BJ_OK;
+}
+
+int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+             const uint64_t *h_public_values, bj_proof **out) {
+    if (int rc = bj::bind(ctx)) return rc;
+    if (!S || !h_variables || !out) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
+    if (S->lookup_reps && !h_multiplicities) return bj::fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
+    if (int rc = stage_witness(ctx, S)) return rc;
+    const size_t n = (size_t)1 << S->log_n;
     const unsigned group = bj::env().prove_h2d_group;
     const HostWitness hw{h_variables, h_multiplicities, group};
     // the copies are queued inside the proof (after the workspace is reserved); a previous proof on this context has drained
@@ -1447,3 +1470,22 @@ int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const 
 }
 
 }  // extern "C"
+
+namespace bj {
+// bj_prove for a lane of bj_prove_async whose sibling is busy: the whole witness crosses PCIe first (one copy on the proof's
+// stream, while the other lane's proof has the CUs), then the proof runs as on a resident witness — one leaf kernel instead of
+// the group-wise absorption that bj_prove uses to hide the transfer behind its own hashing.  Same bytes either way.
+int prove_host_copy_first(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+                          const uint64_t *h_public_values, bj_proof **out) {
+    if (int rc = bind(ctx)) return rc;
+    if (!S || !h_variables || !out) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
+    if (S->lookup_reps && !h_multiplicities) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
+    if (int rc = stage_witness(ctx, S)) return rc;
+    const size_t n = (size_t)1 << S->log_n, vw = (size_t)(S->V + S->Wc) * n;
+    BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage, h_variables, vw * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (S->lookup_reps) BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage + vw, h_multiplicities, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int rc = prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, nullptr);
+    (void)hipStreamSynchronize(ctx->stream);   // no queued copy may read the caller's witness after this returns
+    return rc;
+}
+}  // namespace bj

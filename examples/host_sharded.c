@@ -177,6 +177,25 @@ int main(int argc, char **argv) {
             return 1;
         }
         bj_proof_destroy(proof);
+        {   /* the pipelined drop-in call: five witnesses (here the same one), two proofs in flight from this one thread */
+            bj_ticket *prev = NULL, *cur = NULL;
+            int k, same = 1;
+            CHECK(bj_prove_async(ctx, plain, vars, NULL, NULL, &prev));
+            for (k = 1; k <= 5; k++) {
+                if (k < 5) CHECK(bj_prove_async(ctx, plain, vars, NULL, NULL, &cur));
+                CHECK(bj_proof_wait(prev, &proof));
+                if (bj_proof_size_u64(proof) != words) return 1;
+                CHECK(bj_proof_serialize(proof, buf2));
+                same = same && memcmp(buf, buf2, words * 8) == 0;
+                bj_proof_destroy(proof);
+                prev = cur;
+            }
+            if (!same) {
+                fprintf(stderr, "a pipelined proof differs from the serial one\n");
+                return 1;
+            }
+            printf("pipelined: 5 proofs through bj_prove_async / bj_proof_wait, all identical to the serial one\n");
+        }
         vars[3 * n + 5] = fadd(vars[3 * n + 5], 1);
         proof = NULL;
         const int rc = bj_prove(ctx, plain, vars, NULL, NULL, &proof);

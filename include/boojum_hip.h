@@ -118,6 +118,24 @@ int bj_trace_to_lde_batch(bj_ctx *ctx, uint64_t *d_cols, size_t col_stride, uint
 int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols,
                         size_t col_stride);
 
+/* The monomial form between ifft_natural_to_natural (fft/mod.rs:464-491) and transform_monomials_to_lde (utils.rs:311-403) in the
+ * layout bj_prove keeps it in.  For 2^22-row traces (the size with a two-pass transform plan) that is a TILED layout — coefficient
+ * e = m * 4096 + r * 16 + l at word r * 16384 + (l >> 1) * 2048 + m * 2 + (l & 1) — which the inverse transform's last pass
+ * stores directly (the bit reversal and the 1/n factor of the reference's inverse happen in that store: two HBM passes, no
+ * bit-reversal pass) and the extension's first pass reads as contiguous 128 KB tiles; every other size keeps natural order and
+ * these calls return BJ_ERR_UNSUPPORTED.  Pointwise work on monomials (linear combinations) is layout-blind.
+ * bj_monomials_tiled: 1 when bj_prove uses the tiled layout for this trace length (BJ_MONO_TILED=0 / BJ_NTT_TWO_PASS=0 turn it off).
+ * bj_intt_batch_tiled: values on the subgroup, natural order -> tiled monomials (main domain, no coset; in place allowed).
+ * bj_lde_cosets_batch_tiled: bj_lde_cosets_batch reading tiled monomials; the output is the same as from natural ones.
+ * bj_tiled_permute_batch: natural -> tiled (to_tiled != 0) or back, out of place.
+ * Columns must start on 16-byte boundaries with an even stride. */
+int bj_monomials_tiled(unsigned log_n);
+int bj_intt_batch_tiled(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols, size_t col_stride);
+int bj_lde_cosets_batch_tiled(bj_ctx *ctx, const uint64_t *d_mono_tiled, size_t col_stride, uint64_t *d_out, unsigned log_n,
+                              unsigned n_cols, unsigned log_lde, unsigned coset_begin, unsigned coset_count);
+int bj_tiled_permute_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned n_cols, size_t col_stride,
+                           int to_tiled);
+
 /* Reduce every element to its canonical residue (what the reference does on serialisation, goldilocks/mod.rs:98-107). */
 int bj_canonicalize(bj_ctx *ctx, uint64_t *d_data, size_t n);
 
@@ -585,6 +603,24 @@ int bj_prove(bj_ctx *ctx, const bj_setup *setup, const uint64_t *h_variables, co
 /* same with the witness already resident in HBM ([num_vars + num_witness_cols][n] contiguous; not modified) */
 int bj_prove_dev(bj_ctx *ctx, const bj_setup *setup, const uint64_t *d_variables, const uint64_t *d_multiplicities,
                  const uint64_t *h_public_values, bj_proof **out);
+/* The host loop over witnesses around prove_cpu_basic (prover.rs:153-168, convenience.rs:119-196), pipelined from ONE host
+ * thread: bj_prove_async queues bj_prove(setup, witness) on one of the context's two internal lanes (each its own HIP stream,
+ * workspace and witness staging, driven by a library-owned worker thread; created on first use) and returns at once;
+ * bj_proof_wait blocks until that proof is complete, hands it over (bj_proof_destroy as usual) and frees the ticket.  With
+ *     t[0] = async(w[0]);  for k = 1..: t[k] = async(w[k]); wait(t[k-1]);
+ * the PCIe transfer, inverse transforms and first leaf absorptions of proof k run under the latency-bound tail (node layers,
+ * FRI tail, transcript round trips) of proof k-1: throughput of the drop-in call >= the rate of bj_prove_dev on a resident
+ * witness; every proof is byte for byte what bj_prove returns.  At most two proofs are in flight — a third submission blocks
+ * until the lane it is due on is free.  h_variables / h_multiplicities (pinned host memory for full PCIe speed) must stay
+ * valid and unchanged until bj_proof_wait returns; h_public_values is copied.  Errors of the proof (unsatisfied witness, out
+ * of memory) come back from bj_proof_wait with the text in bj_last_error(ctx).  Every ticket must be waited for exactly once.
+ * Memory: each lane holds a workspace of its own (bj_proof_workspace_bytes); bj_ctx_release_workspace frees the lanes' too.
+ * Single-device setups only (a sharded proof is a collective: its ranks are already concurrent). */
+typedef struct bj_ticket bj_ticket;
+int bj_prove_async(bj_ctx *ctx, const bj_setup *setup, const uint64_t *h_variables, const uint64_t *h_multiplicities,
+                   const uint64_t *h_public_values, bj_ticket **out);
+int bj_proof_wait(bj_ticket *ticket, bj_proof **out);
+int bj_proof_poll(const bj_ticket *ticket); /* 1: complete (bj_proof_wait will not block), 0: still running */
 void bj_proof_destroy(bj_proof *p);
 /* Flat little-endian u64 serialisation of Proof (proof.rs:121-136); layout documented in era_boojum_amd/proof_format.py:
  * header | schedule | public inputs | witness / stage-2 / quotient caps | values at z, z*omega, 0 | FRI caps |

@@ -51,10 +51,11 @@ def test_c_sharded_host_builds_and_refuses_to_run_without_a_gpu(tmp_path):
 @pytest.mark.gpu
 def test_c_host_proves_through_the_sharded_entry_point_with_the_rccl_transport(tmp_path):
     """examples/host_sharded.c: a whole proof from C — circuit arrays, bj_rccl_unique_id / bj_comm_rccl_create,
-    bj_setup_create_sharded, bj_prove — as rank 0 of a world of 1 (one GPU here; `host_sharded <rank> <world> <id file>` is the
+    bj_setup_create_sharded, bj_prove, the pipelined bj_prove_async / bj_proof_wait loop — as rank 0 of a world of 1 (one GPU here; `host_sharded <rank> <world> <id file>` is the
     same program on every GPU of a node).  It checks the proof against the unsharded entry point and that a broken witness is
     refused."""
     exe = _build(tmp_path, "host_sharded")
     r = subprocess.run([exe, "0", "1", os.path.join(str(tmp_path), "rccl.id")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "fingerprint" in r.stdout and "identical proof" in r.stdout and r.stdout.strip().endswith("ok")
+    assert "pipelined: 5 proofs" in r.stdout

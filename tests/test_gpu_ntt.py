@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+import era_boojum_amd as E
 from gpu_util import DevBuf, ctx, rand_gl, P
 
 pytestmark = pytest.mark.gpu
@@ -197,6 +198,52 @@ def test_lde_at_bench_sizes_matches_oracle(log_n, log_lde, n_cols):
         assert np.array_equal(d_c.get(mono.shape), O.canonical(mono))
         d_c.free()
     d_m.free(); d_o.free()
+
+
+def _tiled_index(e):
+    """The tiled layout of a 2^22-word column (include/boojum_hip.h, csrc/ntt_r16.hip: tiled_index)."""
+    e = np.asarray(e, dtype=np.int64)
+    return ((e >> 4) & 255) * 16384 + ((e >> 1) & 7) * 2048 + (e >> 12) * 2 + (e & 1)
+
+
+@pytest.mark.parametrize("n_cols", [1, 5, 40])
+def test_tiled_monomials_inverse_transform_and_extension_match_the_oracle(n_cols):
+    """What bj_prove runs at 2^22 rows since round 6 (ifft_natural_to_natural fft/mod.rs:464-491 without a bit-reversal pass;
+    transform_monomials_to_lde utils.rs:311-403 reading contiguous tiles): bj_intt_batch_tiled = the oracle's monomials at their
+    tiled positions, in place and out of place, for column counts that take one workgroup column loop, several, and more than one
+    scratch group (32 columns per GiB); bj_lde_cosets_batch_tiled of them = the oracle's LDE, all eight cosets and a rank's single
+    coset; bj_tiled_permute_batch both ways; every other size is refused."""
+    log_n, n = 22, 1 << 22
+    assert ctx().monomials_tiled(22) and not ctx().monomials_tiled(21) and not ctx().monomials_tiled(23)
+    rng = np.random.default_rng(2200 + n_cols)
+    vals = rand_gl(rng, (n_cols, n), noncanonical=True)
+    mono = O.ifft_batch(vals, 1, threads=32)
+    perm = _tiled_index(np.arange(n))
+    want_tiled = np.empty_like(mono)
+    want_tiled[:, perm] = mono
+    d_v, d_m = DevBuf(vals), DevBuf(nelems=vals.size)
+    ctx().intt_batch_tiled(d_v.ptr, d_m.ptr, log_n, n_cols)
+    assert np.array_equal(d_m.get(vals.shape), want_tiled)
+    ctx().intt_batch_tiled(d_v.ptr, d_v.ptr, log_n, n_cols)                  # in place
+    assert np.array_equal(d_v.get(vals.shape), want_tiled)
+    d_b = DevBuf(nelems=vals.size)
+    ctx().tiled_permute_batch(d_m.ptr, d_b.ptr, log_n, n_cols, to_tiled=False)
+    assert np.array_equal(d_b.get(vals.shape), mono)
+    ctx().tiled_permute_batch(d_b.ptr, d_v.ptr, log_n, n_cols, to_tiled=True)
+    assert np.array_equal(d_v.get(vals.shape), want_tiled)
+    k = min(n_cols, 3)                                                       # the extension: a few columns against the oracle
+    want = O.lde_batch(mono[:k], 3, threads=32)
+    d_o = DevBuf(nelems=want.size)
+    ctx().lde_cosets_batch_tiled(d_m.ptr, d_o.ptr, log_n, k, 3, 0, 8)
+    assert np.array_equal(d_o.get(want.shape), want)
+    ctx().lde_cosets_batch_tiled(d_m.ptr, d_o.ptr, log_n, k, 3, 5, 1)         # one coset, as a rank of eight extends it
+    assert np.array_equal(d_o.get((k * n,)).reshape(k, n), want[:, 5, :])
+    with pytest.raises(E.BoojumHipError):
+        ctx().intt_batch_tiled(d_v.ptr, d_m.ptr, 21, 1)
+    with pytest.raises(E.BoojumHipError):
+        ctx().lde_cosets_batch_tiled(d_m.ptr, d_o.ptr, 20, 1, 3, 0, 8)
+    for d in (d_v, d_m, d_b, d_o):
+        d.free()
 
 
 @pytest.mark.parametrize("log_n,n_cols", [(14, 5), (15, 3), (18, 3), (19, 2), (22, 2)])
