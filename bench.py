@@ -497,15 +497,34 @@ def main():
             lcols, L = 93, args.fri_lde
             mono = torch.randint(0, 1 << 62, (lcols, n), dtype=torch.int64, device=dev)
             lde = torch.empty((lcols, L, n), dtype=torch.int64, device=dev)
-            ctx.lde_batch(mono.data_ptr(), lde.data_ptr(), log_n, lcols, L.bit_length() - 1)
+            log_L = L.bit_length() - 1
+            tiled = ctx.monomials_tiled(log_n)      # the layout bj_prove keeps monomials of this size in (2^22: tiled, contiguous front-pass tiles)
+            run_lde = (lambda: ctx.lde_cosets_batch_tiled(mono.data_ptr(), lde.data_ptr(), log_n, lcols, log_L, 0, L)) if tiled else \
+                      (lambda: ctx.lde_batch(mono.data_ptr(), lde.data_ptr(), log_n, lcols, log_L))
+            run_lde()
             ctx.timer_start()
             for _ in range(3):
-                ctx.lde_batch(mono.data_ptr(), lde.data_ptr(), log_n, lcols, L.bit_length() - 1)
+                run_lde()
             lms = ctx.timer_stop_ms() / 3
             lb = 8.0 * n * (1 + L) * lcols
-            out["ntt"]["lde_at_bench_size"] = {"workload": "LDE %d columns x 2^%d x %d cosets (the witness round's)" % (lcols, log_n, L),
+            out["ntt"]["lde_at_bench_size"] = {"workload": "LDE %d columns x 2^%d x %d cosets (the witness round's), monomials in the %s layout as bj_prove keeps them"
+                                                           % (lcols, log_n, L, "tiled" if tiled else "natural"),
                                                "ms": round(lms, 3), "achieved": round(lb / lms / 1e6, 2), "unit": "GB/s",
                                                "frac": round(lb / lms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": lb}
+            # the inverse transforms in front of it: values -> monomials, 93 columns (8 n bytes in + 8 n out per column)
+            run_inv = (lambda: ctx.intt_batch_tiled(mono.data_ptr(), lde.data_ptr(), log_n, lcols)) if tiled else \
+                      (lambda: ctx.intt_batch(mono.data_ptr(), lde.data_ptr(), log_n, lcols))
+            run_inv()
+            ctx.timer_start()
+            for _ in range(3):
+                run_inv()
+            ims = ctx.timer_stop_ms() / 3
+            ib = 16.0 * n * lcols
+            out["ntt"]["intt_at_bench_size"] = {"workload": "inverse transform of %d columns x 2^%d into %s monomials%s" % (
+                                                    lcols, log_n, "tiled" if tiled else "natural-order",
+                                                    " (two passes, the bit reversal in the last pass's store addresses)" if tiled else " (passes + bit-reversal pass)"),
+                                                "ms": round(ims, 3), "achieved": round(ib / ims / 1e6, 2), "unit": "GB/s",
+                                                "frac": round(ib / ims / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": ib}
             del mono, lde
 
     if rank == 0:

@@ -275,6 +275,7 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->tw_fwd) (void)hipFree(ctx->tw_fwd);
     if (ctx->tw_inv) (void)hipFree(ctx->tw_inv);
+    if (ctx->tw_inv_scaled22) (void)hipFree(ctx->tw_inv_scaled22);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_ptrs) (void)hipFree((void *)ctx->d_ptrs);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -502,11 +503,15 @@ int intt_to_tiled(bj_ctx *ctx, const u64 *d_in, size_t in_col_stride, u64 *d_out
     if (group > n_cols) group = n_cols;
     if (int rc = ensure_scratch(ctx, (size_t)group * n)) return rc;
     const u64 n_inv = gl::inv(gl::canon((u64)n % gl::P));
+    if (!ctx->tw_inv_scaled22) {   // a table for 2^22 is a prefix of every larger one: built once per context, whatever tw_inv grows to
+        BJ_HIP(ctx, hipMalloc((void **)&ctx->tw_inv_scaled22, (n / 2) * sizeof(u64)));
+        bj::launch_scale_table(ctx->tw_inv, ctx->tw_inv_scaled22, n / 2, n_inv, ctx->stream);
+    }
     for (unsigned c0 = 0; c0 < n_cols; c0 += group) {
         const unsigned nc = n_cols - c0 < group ? n_cols - c0 : group;
         bj::launch_ntt_front10(d_in + (size_t)c0 * in_col_stride, ctx->d_scratch, ctx->tw_inv, nullptr, bj::front_table(ctx), log_n, nc, 1,
                                in_col_stride, n, ctx->stream);
-        bj::launch_ntt_local12_pair_tiled(ctx->d_scratch, d_out + (size_t)c0 * out_col_stride, ctx->tw_inv, n_inv, nc, n, out_col_stride, ctx->stream);
+        bj::launch_ntt_local12_pair_tiled(ctx->d_scratch, d_out + (size_t)c0 * out_col_stride, ctx->tw_inv, ctx->tw_inv_scaled22, n_inv, nc, n, out_col_stride, ctx->stream);
     }
     BJ_CHECK_LAUNCH(ctx);
     return BJ_OK;

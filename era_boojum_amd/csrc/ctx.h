@@ -23,6 +23,7 @@ struct bj_ctx {
     // twiddle caches (bit-reversed tables; a table for 2^k serves every smaller size as a prefix)
     gl::u64 *tw_fwd = nullptr, *tw_inv = nullptr;
     unsigned tw_fwd_log = 0, tw_inv_log = 0;
+    gl::u64 *tw_inv_scaled22 = nullptr;   // tw_inv[j] / 2^22, j < 2^21: the last round of a 2^22-point inverse transform into the tiled layout
     gl::u64 *d_small = nullptr;  // 64 shifts + 64*32 per-round scales + 4096 for gathered Merkle caps + the front-pass twiddle table
     const gl::u64 **d_ptrs = nullptr;
     size_t d_ptrs_cap = 0;

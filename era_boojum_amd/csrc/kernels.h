@@ -56,8 +56,9 @@ void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round
 void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
                         unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s, bool tiled_in = false);
 // 2^22-word columns in the tiled layout (ntt_r16.hip: tiled_index): last pass of an inverse transform storing it, re-layout kernel
-void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, u64 scale, unsigned n_cols, size_t in_col_stride,
-                                   size_t out_col_stride, hipStream_t s);
+void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, const u64 *tw_scaled /* tw[j] * scale, j < 2^21 */, u64 scale,
+                                   unsigned n_cols, size_t in_col_stride, size_t out_col_stride, hipStream_t s);
+void launch_scale_table(const u64 *in, u64 *out, size_t count, u64 scale, hipStream_t s);
 void launch_tiled_permute(const u64 *in, u64 *out, unsigned n_cols, size_t in_col_stride, size_t out_col_stride, bool to_tiled, hipStream_t s);
 void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned n_cols,
                        unsigned n_cosets, size_t in_col_stride, size_t in_coset_stride, size_t out_col_stride, hipStream_t s);

@@ -197,6 +197,29 @@ __device__ __forceinline__ void radix16(u64 (&x)[16], const u64 *tw) {
 }
 template <bool UNIT_FIRST>
 __device__ __forceinline__ void radix16_lds(u64 (&x)[16], const u64 *tw) { radix16<UNIT_FIRST>(x, tw); }
+// the same four rounds with every output multiplied by s: the last round runs (s u + (s w) v, s u - (s w) v) — the caller passes its
+// eight twiddles tw[7..14] already multiplied by s — so the factor costs one product per butterfly, half a product per element
+__device__ __forceinline__ void radix16_scaled(u64 (&x)[16], const u64 *tw, u64 s) {
+#pragma unroll
+    for (int st = 0; st < 3; st++) {
+        const int half = 8 >> st;
+#pragma unroll
+        for (int g = 0; g < (1 << st); g++) {
+            const u64 w = tw[(1 << st) - 1 + g];
+#pragma unroll
+            for (int j = 0; j < half; j += 2) {
+                const int iu = g * 2 * half + j, iv = iu + half;
+                gl::butterfly2_weak(x[iu], x[iv], w, x[iu + 1], x[iv + 1], w);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) {
+        x[2 * g] = gl::mul_weak(x[2 * g], s);
+        x[2 * g + 2] = gl::mul_weak(x[2 * g + 2], s);
+        gl::butterfly2_weak(x[2 * g], x[2 * g + 1], tw[7 + g], x[2 * g + 2], x[2 * g + 3], tw[8 + g]);
+    }
+}
 
 // block-uniform step twiddles: 15 lanes compute them once, everyone reads them back as LDS broadcasts
 template <bool SCALED>
@@ -751,28 +774,35 @@ __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
 //     m = rev10(p & 1023) = rev4(j) * 64 + rev6(t & 63),   r = rev2(p >> 10) * 64 + (rev10(b) >> 4),   l = rev10(b) & 15,
 // and rev10(b + 512) = rev10(b) + 1: the two chunks are the two halves of every 16-byte word (m, l pair) of the tiled layout, and
 // for a fixed register j the 64 lanes of a wave cover 64 consecutive m — one wave store = 1 KB contiguous, straight from the
-// registers (ntt_local12's third transpose through LDS, there only for the stores' sake, is not needed here).  Twiddles of both
-// chunks stay resident (2 x 15 pairs in VGPRs for step C, 2 x (16 + 256) words in LDS): the kernel runs two waves per SIMD.
+// registers (ntt_local12's third transpose through LDS, there only for the stores' sake, is not needed here).  Step C is free to
+// choose WHICH sixteen-word group a lane takes: lane t takes group pi(t) = t with its low six bits reversed, so that m = rev4(j) * 64
+// + (t & 63) and the lanes of a store are in address order (in lane order rev6 the same kilobyte leaves as 64 separate 16-byte
+// writes: measured, the pass is then bound by them).  The twiddles of steps
+// A and B of both chunks stay in LDS (2 x (16 + 256) words); step C's fifteen per lane are fetched again for every chunk of every
+// column (L2 hits, issued with the chunk's sixteen data loads) — resident for both chunks they cost 60 VGPRs and the third wave of a SIMD.
 struct PairArgs {
     const u64 *in;
     u64 *out;
     const u64 *tw;           // bit-reversed twiddle table of the inverse root
+    const u64 *tw_scaled;    // the same 2^21 entries times 1 / n (the last round's twiddles: radix16_scaled)
     u64 scale;               // 1 / n
     unsigned n_cols, cols_per_block;
     size_t in_col_stride, out_col_stride;
 };
-__global__ void __launch_bounds__(256, 2) ntt_local12_pair_tiled_kernel(PairArgs a) {
+#ifndef BJ_PAIR_WAVES
+#define BJ_PAIR_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, BJ_PAIR_WAVES) ntt_local12_pair_tiled_kernel(PairArgs a) {
     __shared__ u64 lds[LDS_ELEMS + 2 * 16 + 2 * 16 * 16];
     u64 *lds_twA = lds + LDS_ELEMS;           // [chunk][15 (+1)]
     u64 *lds_twB = lds_twA + 32;              // [chunk][t >> 4][15 (+1)]
     const u32 t = threadIdx.x;
     const u32 bp = blockIdx.x;                // chunks bp and bp + 512
     constexpr unsigned r0 = 10;
-    u64 twC[2][15];
+    (void)r0;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const u32 b = bp + 512u * h;
-        load_step_twiddles<false>(twC[h], a.tw, b * 256 + t, r0 + 8, nullptr);
         if (t < 15) {
             const int s = 31 - __clz(t + 1);
             const int g = (int)(t + 1) - (1 << s);
@@ -792,15 +822,26 @@ __global__ void __launch_bounds__(256, 2) ntt_local12_pair_tiled_kernel(PairArgs
     const u32 wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const u32 rb = gl::bitrev32(bp, 10);                      // even: bp < 512
     const size_t tile_off = ((size_t)(gl::bitrev32(wave, 2) * 64u + (rb >> 4))) * 16384u + (size_t)((rb & 15u) >> 1) * 2048u;
-    const u32 off_st = gl::bitrev32(t & 63u, 6) * 16u;        // bytes: word pair m = rev6(lane) (+ rev4(j) * 64, a constant per store)
+    const u32 pi = (t & ~63u) | gl::bitrev32(t & 63u, 6);     // the group of sixteen words this lane takes in step C
+    const u32 off_st = (t & 63u) * 16u;                       // bytes: word pair m = lane (+ rev4(j) * 64, a constant per store)
     for (unsigned col = col0; col < col1; col++) {
         u64 y[16];
-#pragma unroll
+#pragma nounroll   // ONE copy of the twelve rounds serves both chunks (unrolled, the loop body is ~50 KB of code for a 64 KB instruction cache)
         for (int h = 0; h < 2; h++) {
             const gcptr src = uniform_gptr(a.in + (size_t)col * a.in_col_stride + (size_t)(bp + 512u * h) * TILE);
             u64 x[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) x[j] = ld_off(src + j * 256, t * 8u);
+            // step C's twiddles of this chunk: T[(kb << s) + g], kb = 256 b + t; the last round's from the scaled table
+            u64 twC[15];
+            {
+                u32 kb = (bp + 512u * h) * 256u + pi;
+                asm volatile("" : "+v"(kb));          // a fresh index per chunk and column: the loads stay inside the loop
+#pragma unroll
+                for (int st = 0; st < 4; st++)
+#pragma unroll
+                    for (int g = 0; g < (1 << st); g++) twC[(1 << st) - 1 + g] = (st == 3 ? a.tw_scaled : a.tw)[((size_t)kb << st) + g];
+            }
             radix16<false>(x, lds_twA + h * 16);
 #pragma unroll
             for (int j = 0; j < 16; j++) lds[pad(j * 256 + t)] = x[j];
@@ -813,18 +854,18 @@ __global__ void __launch_bounds__(256, 2) ntt_local12_pair_tiled_kernel(PairArgs
             for (int j = 0; j < 16; j++) lds[pad(ta * 256 + j * 16 + tc)] = x[j];
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = lds[pad(t * 16 + j)];
+            for (int j = 0; j < 16; j++) x[j] = lds[pad(pi * 16 + j)];
             __syncthreads();
-            radix16<false>(x, twC[h]);
+            radix16_scaled(x, twC, a.scale);
             if (h == 0) {
 #pragma unroll
-                for (int j = 0; j < 16; j++) y[j] = gl::mul(x[j], a.scale);
+                for (int j = 0; j < 16; j++) y[j] = gl::canon(x[j]);
             } else {
                 const gptr dst = (gptr)uniform_gptr(a.out + (size_t)col * a.out_col_stride + tile_off);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     constexpr u32 R4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-                    st_off2(dst + (size_t)R4[j] * 128u, off_st, y[j], gl::mul(x[j], a.scale));
+                    st_off2(dst + (size_t)R4[j] * 128u, off_st, y[j], gl::canon(x[j]));
                 }
             }
         }
@@ -898,11 +939,18 @@ void launch_ntt_local12(const u64 *in, u64 *out, const u64 *tw, const u64 *round
 }
 
 // last pass of a 2^22-point inverse transform into the tiled layout (in: the front pass's output, chunk b at b * 4096)
-void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, u64 scale, unsigned n_cols, size_t in_col_stride,
-                                   size_t out_col_stride, hipStream_t s) {
+__global__ void scale_table_kernel(const u64 *in, u64 *out, size_t count, u64 s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = gl::mul(in[i], s);
+}
+void launch_scale_table(const u64 *in, u64 *out, size_t count, u64 scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, in, out, count, scale);
+}
+void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, const u64 *tw_scaled, u64 scale, unsigned n_cols,
+                                   size_t in_col_stride, size_t out_col_stride, hipStream_t s) {
     unsigned cpb = 8;
     while (cpb > 1 && (size_t)512 * ((n_cols + cpb - 1) / cpb) < 2048) cpb >>= 1;
-    PairArgs a{in, out, tw, scale, n_cols, cpb, in_col_stride, out_col_stride};
+    PairArgs a{in, out, tw, tw_scaled, scale, n_cols, cpb, in_col_stride, out_col_stride};
     hipLaunchKernelGGL(ntt_local12_pair_tiled_kernel, dim3(512, (n_cols + cpb - 1) / cpb), dim3(256), 0, s, a);
 }
 void launch_tiled_permute(const u64 *in, u64 *out, unsigned n_cols, size_t in_col_stride, size_t out_col_stride, bool to_tiled, hipStream_t s) {

@@ -65,6 +65,29 @@ for two in (False, True):
     lb = 8.0 * n * (1 + L) * n_cols
     print("%s: LDE %d x 2^22 x 8: %.3f ms (%.1f GB/s, frac %.4f)   iNTT: %.3f ms   one coset of eight: %.3f ms"
           % ("two-pass  " if two else "three-pass", n_cols, t_lde, lb / t_lde / 1e6, lb / t_lde / 1e6 / 8000, t_intt, t_l1))
+# round 6: the same two-pass transforms through the TILED monomial layout (no bit-reversal pass behind the inverse transform)
+plan(True)
+if ctx.monomials_tiled(log_n):
+    tl = torch.empty((n_cols, n), dtype=torch.int64, device=dev)
+    ctx.intt_batch(mono.data_ptr(), tmp.data_ptr(), log_n, n_cols)
+    ctx.intt_batch_tiled(mono.data_ptr(), tl.data_ptr(), log_n, n_cols)
+    back = torch.empty_like(tl)
+    ctx.tiled_permute_batch(tl.data_ptr(), back.data_ptr(), log_n, n_cols, to_tiled=False)
+    torch.cuda.synchronize()
+    print("intt tiled == intt natural (after re-layout):", bool(torch.equal(back, tmp)))
+    ctx.lde_batch(tmp.data_ptr(), lde.data_ptr(), log_n, n_cols, 3)
+    torch.cuda.synchronize()
+    want = lde[: min(n_cols, 4)].clone()
+    ctx.lde_cosets_batch_tiled(tl.data_ptr(), lde.data_ptr(), log_n, n_cols, 3, 0, 8)
+    torch.cuda.synchronize()
+    print("lde from tiled == lde from natural:", bool(torch.equal(lde[: min(n_cols, 4)], want)))
+    t_i = timed(lambda: ctx.intt_batch_tiled(mono.data_ptr(), tl.data_ptr(), log_n, n_cols))
+    t_n = timed(lambda: ctx.intt_batch(mono.data_ptr(), tmp.data_ptr(), log_n, n_cols))
+    t_l = timed(lambda: ctx.lde_cosets_batch_tiled(tl.data_ptr(), lde.data_ptr(), log_n, n_cols, 3, 0, 8))
+    t_ln = timed(lambda: ctx.lde_batch(tmp.data_ptr(), lde.data_ptr(), log_n, n_cols, 3))
+    t_p = timed(lambda: ctx.tiled_permute_batch(tl.data_ptr(), back.data_ptr(), log_n, n_cols, to_tiled=False))
+    print("tiled     : iNTT %.3f ms (natural %.3f)   LDE %.3f ms (natural %.3f)   re-layout pass %.3f ms" % (t_i, t_n, t_l, t_ln, t_p))
+    del tl, back
 sys.stdout.flush()
 del mono, lde, tmp, res
 torch.cuda.synchronize()
