@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--security", type=int, default=100)
     ap.add_argument("--cpu-log-n", type=int, default=20)
     ap.add_argument("--cpu-micro-log-n", type=int, default=18, help="second, smaller oracle proof reported under cpu_baseline.micro")
+    ap.add_argument("--test-die-rank", type=int, default=-1,
+                    help="fault injection for tests/test_bench_launcher.py only: this rank exits right after the rendezvous")
     ap.add_argument("--no-host-witness", action="store_true", help="skip the bj_prove (host witness, PCIe inclusive) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
@@ -122,13 +124,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if world > 1 and "BJ_BENCH_TEST_DIE_RANK" in os.environ:
+    if world > 1 and args.test_die_rank >= 0:
         # tests/test_bench_launcher.py (runs without a GPU): one rank dies right after the rendezvous, the others are left in a
         # collective — the launcher must notice and end the whole command with an error instead of hanging
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group("gloo", rank=rank, world_size=world)
-        if os.environ["BJ_BENCH_TEST_DIE_RANK"] == str(rank):
+        if args.test_die_rank == rank:
             os._exit(3)
         tdist.barrier()
         raise SystemExit("the rank that was told to die is still alive")

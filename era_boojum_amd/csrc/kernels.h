@@ -24,7 +24,7 @@ struct EnvConfig {
     bool gates_windowed = true;         // BJ_GATES_WINDOWED=0: per-gate kernel for the hand-written kinds
     bool prove_no_absorb = false;
     bool copy_perm_wide_k = false;       // BJ_COPY_PERM_WIDE_K: quotient_copy_perm with 64-bit non-residue products even when they fit 32 bits (A/B, tests)
-    bool prove_uniform_groups = false;   // BJ_PROVE_UNIFORM_GROUPS: bj_prove's round-4 plan (equal groups, one absorption per eight columns)
+    bool prove_uniform_groups = false;   // BJ_PROVE_UNIFORM_GROUPS: equal groups of G columns, one multi-block absorption run per group (round 4's GROUPING only: its launches absorbed eight columns each)
     bool async_no_copy_first = false;    // BJ_ASYNC_NO_COPY_FIRST: bj_prove_async lanes always take bj_prove's group-wise transfer (A/B)
     unsigned prove_h2d_group = 8;
     size_t nodes_lanepar_max = 16384;

@@ -40,7 +40,10 @@ __device__ __forceinline__ u64 omega_pow_nat(const u64 *tw, unsigned log_n, u32 
 // A lane handles RAT_PTS rows (256 apart, so every access stays coalesced) of one chunk and inverts their denominators
 // together (Montgomery's trick: one F_p^2 inversion = one x^(p-2) chain per RAT_PTS rows instead of per row — the inversion
 // was 60 % of this kernel's multiplications).
-static constexpr int RAT_PTS = 4;
+#ifndef BJ_RAT_PTS
+#define BJ_RAT_PTS 4
+#endif
+static constexpr int RAT_PTS = BJ_RAT_PTS;
 // SMALLK: every non-residue fits 32 bits (make_non_residues' output always does; the launcher is told): k_c * (x * beta) as a
 // 32 x 64-bit product (gl::mul_u32_weak) instead of a 64 x 64 one
 template <bool SMALLK>

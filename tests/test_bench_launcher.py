@@ -38,11 +38,11 @@ def test_a_rank_that_dies_after_rendezvous_ends_the_run_with_an_error():
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, BJ_BENCH_BACKEND="gloo", BJ_BENCH_TEST_DIE_RANK="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, BJ_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--steps", "1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--steps", "1", "--test-die-rank", "1"]
     t0 = time.time()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and time.time() - t0 < 120

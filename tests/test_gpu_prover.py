@@ -319,6 +319,7 @@ def test_prover_checks_public_values_against_the_witness():
     gsetup.close()
 
 
+@pytest.mark.streaming(260)
 @pytest.mark.timeout(900)
 def test_proof_at_2p23_rows_equals_the_streaming_oracle():
     """BASELINE config 5's size (2^23 rows, LDE 8 => 2^26-point oracles), prover.rs:153-168.  The coset-streaming restatement

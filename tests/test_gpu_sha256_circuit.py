@@ -126,6 +126,7 @@ def _host_ram_gb():
     return avail
 
 
+@pytest.mark.streaming(140)
 def test_hip_proof_at_2p22_rows_equals_the_oracle():
     """BASELINE config 4's size, the bench's own workload (cfg4): the real SHA-256 circuit at 2^22 rows (SHA-256 of 557 kB,
     bench parameters: LDE 8, cap 16, security 100, Poseidon2 tree + golden-pinned Poseidon2 transcript).
