@@ -78,6 +78,9 @@ def self_launch(n_ranks):
 
 
 def main():
+    if os.environ.get("BJ_BENCH_FAULTHANDLER_S"):       # debugging aid: dump every thread's stack if the run is still going after that long
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BJ_BENCH_FAULTHANDLER_S"]), repeat=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -95,8 +98,13 @@ def main():
     ap.add_argument("--security", type=int, default=100)
     ap.add_argument("--cpu-log-n", type=int, default=20)
     ap.add_argument("--cpu-micro-log-n", type=int, default=18, help="second, smaller oracle proof reported under cpu_baseline.micro")
+    ap.add_argument("--bulk-transport", choices=["base", "peer"], default=os.environ.get("BJ_COMM_BULK", "base"),
+                    help="N > 1: how the bulk exchanges (quotient residues, first folded FRI layer, DEEP numerator slices) of the TIMED proofs "
+                         "travel: base = the transport chosen above (RCCL ring all-gather); peer = full-mesh peer copies (bj_comm_peer_create). "
+                         "The other one is timed on a few extra proofs after the headline either way (comm.other_bulk_transport)")
     ap.add_argument("--test-die-rank", type=int, default=-1,
                     help="fault injection for tests/test_bench_launcher.py only: this rank exits right after the rendezvous")
+    ap.add_argument("--no-other-bulk", action="store_true", help="N > 1: skip the extra proofs on the other bulk transport")
     ap.add_argument("--no-host-witness", action="store_true", help="skip the bj_prove (host witness, PCIe inclusive) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
@@ -272,6 +280,18 @@ def main():
                 comm = None
         if comm is None:
             comm, transport = E.TorchComm(ctx), "torch.distributed all_gather_into_tensor through the bj_comm host callback"
+        base_comm, peer_comm, peer_err = comm, None, None
+        try:     # collective (a gloo control group); every rank reports, all agree
+            peer_comm = E.PeerComm(ctx, base_comm)
+            okp = 1
+        except Exception as e:                    # noqa: BLE001
+            peer_err, okp = repr(e)[:200], 0
+        flagp = torch.tensor([okp], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flagp, op=dist.ReduceOp.MIN)
+        if int(flagp.item()) != 1:
+            peer_comm = None
+        if args.bulk_transport == "peer" and peer_comm is not None:
+            comm, transport = peer_comm, transport + " + full-mesh peer copies (HIP IPC) for the exchanges of >= 1 MiB per rank"
     setup = E.ProverSetup(ctx, circuit, args.fri_lde, args.cap, args.security, comm=comm, transcript=args.transcript)
     # witness resident in HBM (torch owns the allocations)
     d_vars = torch.from_numpy(circuit.variables.view(np.int64)).to(dev)
@@ -322,7 +342,7 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be collected from inside this process; the committed summary of the
     # separate rocprofv3 --pmc passes over this same command (tools/pmc_bench.sh) is used when it matches the launch shape
     traffic, traffic_src, valu = None, None, None
-    for prof in ("r05_pmc_bench_2p22_leaf_traffic.json", "r04_pmc_bench_2p22_leaf_traffic.json", "r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
+    for prof in ("r06_pmc_bench_2p22_leaf_traffic.json", "r05_pmc_bench_2p22_leaf_traffic.json", "r04_pmc_bench_2p22_leaf_traffic.json", "r03_pmc_bench_2p22_leaf_traffic.json", "r02_pmc_bench_2p22_leaf_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", prof)))
             if abs(pm["WRITE_SIZE_KiB_mean"] * 1024 - leaves * 32.0) < 1.0 and W == 93:   # same leaves per launch, same width
@@ -407,6 +427,40 @@ def main():
                                 "the slowest peer), summed over a proof; replicated work is ~25 ms per rank, measured by the replayed ranks of scale_replay (DESIGN.md §6)",
                         "transport": transport}
 
+    if sharded and peer_comm is not None and not args.no_other_bulk:
+        # the OTHER bulk transport on a few extra proofs (after the headline's timed region, under a watchdog: a hang here must not cost the line)
+        import threading
+        other = base_comm if comm is peer_comm else peer_comm
+        other_name = "base (ring all-gather)" if comm is peer_comm else "full-mesh peer copies (bj_comm_peer_create)"
+        res2 = {}
+
+        def other_leg():
+            try:
+                torch.cuda.set_device(local_rank)
+                setup.set_comm(other)
+                buf2, _ = step()
+                k3, acc, t3 = 3, 0.0, time.perf_counter()
+                for _ in range(k3):
+                    buf2, _ = step()
+                    acc += setup.last_comm["ms_in_collectives"]
+                torch.cuda.synchronize()
+                res2.update(ms_per_step=(time.perf_counter() - t3) / k3 * 1e3, ms_in_collectives=acc / k3, same=bool(np.array_equal(buf2, proof_buf)))
+                setup.set_comm(comm)
+            except Exception as e:                # noqa: BLE001
+                res2["error"] = repr(e)[:300]
+
+        th2 = threading.Thread(target=other_leg, daemon=True)
+        th2.start()
+        th2.join(float(os.environ.get("BJ_BENCH_OTHER_BULK_TIMEOUT_S", "180")))
+        if th2.is_alive():
+            res2 = {"error": "did not finish within the watchdog"}
+        if "error" not in res2 and not res2.get("same"):
+            res2["error"] = "proof differs from the timed one"
+        out["comm"]["other_bulk_transport"] = dict(res2, transport=other_name, proofs=3,
+                                                   peer_stats=peer_comm.stats() if "error" not in res2 else None,
+                                                   note="rank 0's wall time and time in collectives per proof with the bulk exchanges on the other transport; "
+                                                        "the timed headline used: " + transport)
+        other_bulk_stuck = th2.is_alive()
     # ---- the drop-in call with a host witness (bj_prove): PCIe transfer of the 93 columns inside the timed region
     if world == 1 and not args.no_host_witness:
         hv = torch.from_numpy(circuit.variables.view(np.int64)).pin_memory()
@@ -427,7 +481,7 @@ def main():
         # the same drop-in call pipelined from this ONE host thread (bj_prove_async / bj_proof_wait, csrc/prove_async.hip): proof
         # k + 1's PCIe transfer, inverse transforms and first absorptions run under proof k's latency-bound tail
         try:
-            psteps = max(4, min(2 * args.steps, 12))
+            psteps = max(6, min(4 * args.steps, 24))
             pbuf, _ = setup.wait(setup.prove_async(variables=hvn, multiplicities=hmn))      # warm-up of both lanes
             t_prev = setup.prove_async(variables=hvn, multiplicities=hmn)
             pbuf2, _ = setup.wait(setup.prove_async(variables=hvn, multiplicities=hmn))
@@ -435,21 +489,29 @@ def main():
             torch.cuda.synchronize()
             p0 = time.perf_counter()
             t_prev = setup.prove_async(variables=hvn, multiplicities=hmn)
-            same = True
+            same, done_at = True, []
             for _ in range(psteps - 1):
                 t_cur = setup.prove_async(variables=hvn, multiplicities=hmn)
                 pb, _ = setup.wait(t_prev)
+                done_at.append(time.perf_counter())
                 same = same and np.array_equal(pb, proof_buf)
                 t_prev = t_cur
             pb, _ = setup.wait(t_prev)
-            pms = (time.perf_counter() - p0) / psteps * 1e3
+            done_at.append(time.perf_counter())
+            pms = (done_at[-1] - p0) / psteps * 1e3
+            # proofs leave the pipeline at the steady rate from the first one on until the last but one; the last one has the device to
+            # itself (drain) and the first one started on an idle device (fill): the interval between them is the rate a long-running host sees
+            steady = (done_at[-2] - done_at[0]) / (psteps - 2) * 1e3
             assert same and np.array_equal(pb, proof_buf) and np.array_equal(pbuf, proof_buf) and np.array_equal(pbuf2, proof_buf), \
                 "a pipelined proof differs from the serial one"
             out["host_witness_pipelined"] = {
                 "entry_point": "bj_prove_async / bj_proof_wait from one host thread, two proofs in flight (witness in pinned host memory)",
                 "ms_per_proof_aggregate": round(pms, 3), "value": round(n / pms * 1e3, 1), "unit": "rows/s", "proofs": psteps,
                 "vs_resident_single_proof": round((n / pms * 1e3) / value, 4),
-                "what": "every proof equals the serial one byte for byte; includes the fill and drain of the two-deep pipeline"}
+                "steady_state_ms_per_proof": round(steady, 3), "steady_state_value": round(n / steady * 1e3, 1),
+                "steady_state_vs_resident_single_proof": round((n / steady * 1e3) / value, 4),
+                "what": "every proof equals the serial one byte for byte; `value` includes the fill and the drain of the two-deep pipeline "
+                        "(first proof on an idle device, last proof alone); steady_state = completion of proof 1 to completion of proof N - 1"}
         except Exception as e:                    # noqa: BLE001 — secondary leg
             out["host_witness_pipelined"] = {"error": repr(e)[:300]}
         ctx.release_workspace()                   # the two lanes' arenas and witness staging (2 x 65 GB at 2^22): the legs below need the room
@@ -472,7 +534,7 @@ def main():
                       "achieved": round(nb / ms / 1e6, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": round(nb / ms / 1e6 / HBM_PEAK_GBPS, 4), "algorithmic_bytes": nb,
                       "kernels": "bj::ntt_strided8_kernel + bj::ntt_local12_kernel (HIP events on the launch stream)"}
-        for prof in ("r05_cfg2_ntt_summary.json", "r04_cfg2_ntt_summary.json", "r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
+        for prof in ("r06_cfg2_ntt_summary.json", "r05_cfg2_ntt_summary.json", "r04_cfg2_ntt_summary.json", "r03_cfg2_ntt_summary.json", "r02_cfg2_ntt_summary.json"):
             try:   # counters of the same two kernels from the committed rocprofv3 passes over tools/cfg2_ntt.py --cfg2-only
                 cs = json.load(open(os.path.join(ROOT, "profiles", prof)))
                 out["ntt"]["pmc_from_committed_profile"] = {
@@ -539,6 +601,8 @@ def main():
         out["config"]["verified"] = "oracle/verifier.py accepts the last timed proof"
     transcript_kind = setup.transcript_kind
     stuck_legs = []          # secondary legs whose helper threads did not return: the process then leaves through os._exit
+    if locals().get("other_bulk_stuck"):
+        stuck_legs.append("other bulk transport")
     if rank == 0 and world == 1 and not args.no_two_in_flight:
         # secondary throughput figure: TWO proofs of the same circuit in flight on this one GPU — two contexts, two HIP streams, two
         # host threads (the shape of tests/test_gpu_prover.py::test_two_contexts_on_two_host_threads_prove_concurrently).  The

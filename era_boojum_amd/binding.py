@@ -92,6 +92,9 @@ _SIGNATURES = {
     "bj_setup_cap": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bj_setup_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "bj_prove": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bj_comm_peer_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "bj_comm_peer_destroy": (None, [C.c_void_p]),
+    "bj_comm_peer_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "bj_prove_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_proof_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bj_proof_poll": (C.c_int, [C.c_void_p]),
@@ -817,6 +820,69 @@ class TorchComm:
             traceback.print_exc()
             self.error = e
             return 1
+
+
+_HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class PeerComm:
+    """bj_comm_peer_create: full-mesh peer copies for the bulk exchanges of a sharded proof (every rank writes its contribution
+    straight into every peer's receive buffer, mapped through HIP IPC), everything smaller through `base` (a TorchComm or RcclComm).
+    The control channel — a blocking all-gather of a few host bytes — is torch.distributed on a CPU (gloo) group: `ctrl_group`,
+    or a new gloo group over the default group's ranks when the default backend cannot move host tensors.  Collective: every rank
+    of the proof constructs it."""
+
+    def __init__(self, ctx, base, ctrl_group=None, bulk_threshold_bytes=1 << 20):
+        import torch
+        import torch.distributed as dist
+        self._ctx, self._lib, self._base = ctx, ctx._lib, base
+        self._torch, self._dist = torch, dist
+        self.rank, self.world = base.rank, base.world
+        if ctrl_group is None and dist.get_backend() != "gloo":
+            ctrl_group = dist.new_group(backend="gloo")          # collective
+        self._ctrl = ctrl_group
+        self.error = None
+        self._fn = _HOST_EXCHANGE_FN(self._exchange)             # keep the trampoline alive
+        self.struct = _Comm()
+        ctx._check(self._lib.bj_comm_peer_create(ctx._h, C.byref(base.struct), self._fn, None, bulk_threshold_bytes, C.byref(self.struct)))
+
+    def _exchange(self, _user, h_send, h_recv, nbytes):
+        try:
+            t = self._torch
+            send = t.frombuffer((C.c_ubyte * nbytes).from_address(h_send), dtype=t.uint8).clone()
+            recv = t.empty(nbytes * self.world, dtype=t.uint8)
+            self._dist.all_gather_into_tensor(recv, send, group=self._ctrl)
+            C.memmove(h_recv, recv.data_ptr(), nbytes * self.world)
+            return 0
+        except Exception as e:  # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            self.error = e
+            return 1
+
+    def stats(self):
+        a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._lib.bj_comm_peer_stats(C.byref(self.struct), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return {"bulk_calls": a.value, "bulk_bytes_received": b.value, "small_calls": c.value, "fallbacks": d.value}
+
+    @property
+    def calls(self):
+        s = self.stats()
+        return s["bulk_calls"] + s["small_calls"]
+
+    @property
+    def bytes(self):
+        return self.stats()["bulk_bytes_received"] + getattr(self._base, "bytes", 0)
+
+    def close(self):
+        if self.struct.user:
+            self._lib.bj_comm_peer_destroy(C.byref(self.struct))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class _Ticket:

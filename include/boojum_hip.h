@@ -537,6 +537,22 @@ int bj_rccl_unique_id(void *out_id);
 int bj_comm_rccl_create(bj_ctx *ctx, const void *unique_id, unsigned rank, unsigned world, bj_comm *out);
 void bj_comm_rccl_destroy(bj_comm *comm);
 int bj_comm_rccl_stats(const bj_comm *comm, size_t *calls, size_t *bytes_received); /* collectives issued, bytes received */
+/* Full-mesh peer transport for the BULK exchanges ("direct full-mesh peer copies so all 7 xGMI links carry
+ * traffic"; the reference has no multi-device path, the exchanged data are those of proof.rs:89-91 / merkle_tree.rs:112-157): wraps
+ * `base` (bj_comm_rccl_create or a host callback) and serves every exchange of at least bulk_threshold_bytes per rank (0: 1 MiB) —
+ * the quotient residues, the first folded FRI layer, the DEEP numerator slices — by copying this rank's contribution straight into
+ * slot `rank` of every peer's receive buffer (hipIpcGetMemHandle / hipIpcOpenMemHandle once per allocation, world concurrent
+ * copies: one per link) instead of a ring that is bound by ONE link; smaller exchanges go to `base` unchanged.  `exchange` is the
+ * host's control channel: a BLOCKING all-gather of `bytes` host bytes per rank, rank-major into h_recv (MPI_Allgather, a TCP store,
+ * torch.distributed's gloo group); it carries the IPC handles and serves as the completion barrier (three calls per bulk exchange).
+ * When any rank cannot export or map a buffer all ranks agree to use `base` for that exchange (bj_comm_peer_stats: fallbacks).
+ * Same bytes in the same slots: proofs do not change.  Selectable beside RCCL, never the default; its author had one GPU (the
+ * tests run the ranks as processes sharing the device) — no link-level timing exists.  `base` must outlive the returned comm. */
+typedef int (*bj_host_exchange_fn)(void *user, const void *h_send, void *h_recv, size_t bytes);
+int bj_comm_peer_create(bj_ctx *ctx, const bj_comm *base, bj_host_exchange_fn exchange, void *exchange_user, size_t bulk_threshold_bytes,
+                        bj_comm *out);
+void bj_comm_peer_destroy(bj_comm *comm);
+int bj_comm_peer_stats(const bj_comm *comm, size_t *bulk_calls, size_t *bulk_bytes_received, size_t *small_calls, size_t *fallbacks);
 int bj_setup_create_sharded(bj_ctx *ctx, const bj_circuit *circuit, const uint64_t *h_sigmas, const uint64_t *h_constants,
                             const uint64_t *h_tables, const bj_proof_config *config, const bj_comm *comm, bj_setup **out);
 /* Replaces the transport of a sharded setup (a host that re-creates its communicator, or switches between its own callback and

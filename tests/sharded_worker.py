@@ -33,7 +33,9 @@ def main():
                                        **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else
                                     {"table_id_as_variable": True, "boolean_columns": 2} if log_n == 13 else {}))
     ctx = E.Context(dev)
-    comm = E.TorchComm(ctx)
+    comm = base = E.TorchComm(ctx)
+    if os.environ.get("BJ_COMM_BULK") == "peer":   # full-mesh peer copies for everything of at least BJ_COMM_BULK_MIN bytes per rank
+        comm = E.PeerComm(ctx, base, bulk_threshold_bytes=int(os.environ.get("BJ_COMM_BULK_MIN", str(1 << 20))))
     setup = E.ProverSetup(ctx, circuit, fri, cap, sec, comm=comm)
     proof, _ = setup.prove()
     np.save(os.path.join(out_dir, "proof_%d.npy" % rank), proof)
@@ -41,6 +43,12 @@ def main():
     if rank == 0:
         with open(os.path.join(out_dir, "comm.txt"), "w") as f:
             f.write("%d %d\n" % (comm.calls, comm.bytes))
+    if comm is not base:
+        import json
+        with open(os.path.join(out_dir, "peer_%d.json" % rank), "w") as f:
+            json.dump(comm.stats(), f)
+        proof2, _ = setup.prove()          # a second proof reuses the mapped allocations
+        assert np.array_equal(proof2, proof)
     setup.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -63,6 +63,40 @@ def test_sharded_proof_equals_single_gpu_proof(tmp_path, world, log_n, fri_lde, 
     assert calls >= 5 and nbytes > 0      # setup cap + 3 oracle caps + FRI cap/layer + queries
 
 
+@pytest.mark.parametrize("world,log_n,fri_lde,cap,sec,bulk_min", [(2, 12, 8, 16, 30, 4096), (4, 13, 8, 16, 30, 4096), (8, 11, 8, 16, 40, 1024),
+                                                                  (8, 0, 8, 16, 30, 1 << 20)])
+def test_sharded_proof_with_full_mesh_peer_copies(tmp_path, world, log_n, fri_lde, cap, sec, bulk_min):
+    """bj_comm_peer_create (csrc/comm_peer.hip, SURVEY §8e "direct full-mesh peer copies"): the ranks are processes sharing this
+    GPU; every exchange of at least bulk_min bytes per rank is served by each rank copying its contribution straight into the
+    receive buffers of its peers, mapped through HIP IPC (handles and the completion barrier travel over a gloo control group),
+    the smaller ones by the base transport.  Every rank's proof is the single-GPU proof, bulk exchanges were really served by
+    peer copies (no fallback), and a second proof reuses the mappings.  The last case keeps the default threshold (1 MiB): only
+    the real bulk exchanges of the SHA-256 circuit at 8 ranks qualify."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", BJ_COMM_BULK="peer", BJ_COMM_BULK_MIN=str(bulk_min))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "sharded_worker.py"), str(tmp_path),
+           str(log_n), str(fri_lde), str(cap), str(sec)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    if log_n == 0:
+        from era_boojum_amd import sha256_circuit as SHA
+        c = SHA.sha256_circuit(SHA.bench_message(100, seed=7))
+    else:
+        c = S.sha_shaped_circuit(log_n, seed=7, table_bits=4 if log_n >= 14 else 2,
+                                 **({"boolean_columns": 2, "specialized_constant_columns": 3} if log_n == 12 else
+                                    {"table_id_as_variable": True, "boolean_columns": 2} if log_n == 13 else {}))
+    single = E.ProverSetup(ctx(), c, fri_lde, cap, sec)
+    ref, _ = single.prove()
+    single.close()
+    for rank in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "proof_%d.npy" % rank)), ref), "rank %d" % rank
+        st = json.load(open(os.path.join(str(tmp_path), "peer_%d.json" % rank)))
+        assert st["fallbacks"] == 0 and st["small_calls"] > 0, st
+        if bulk_min < (1 << 20):
+            assert st["bulk_calls"] >= 2 and st["bulk_bytes_received"] >= 2 * world * bulk_min, st
+
+
 def test_sharded_setup_rejects_bad_world():
     c = S.sha_shaped_circuit(8, seed=1, table_bits=2)
 

@@ -19,6 +19,9 @@ SCALARS = {
 }
 
 
+FN_TYPEDEFS = {}     # name -> Rust `Option<unsafe extern "C" fn(..)>` of every `typedef ret (*name)(params);` in the header
+
+
 def strip_comments(src):
     return re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
 
@@ -42,6 +45,8 @@ def rust_type(ctype, enums, structs):
         else:
             name_parts.append(tok)
     name = " ".join(name_parts)
+    if name in FN_TYPEDEFS and not consts:          # typedef'd function pointer, passed by value
+        return FN_TYPEDEFS[name]
     if name in SCALARS:
         r = SCALARS[name]
     elif name in enums:
@@ -141,6 +146,12 @@ def parse_header(path=HEADER):
             for nm in names:
                 fields.append(parse_param(ctype + " " + nm, enums, struct_names))
         structs.append((m.group(1), fields))
+    fn_types = []
+    for m in re.finditer(r"typedef\s+([A-Za-z_][A-Za-z0-9_ \*]*?)\(\s*\*\s*(bj_[A-Za-z0-9_]+)\s*\)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        nm, rt = parse_fn_pointer("%s (*%s)(%s)" % (m.group(1), m.group(2), " ".join(m.group(3).split())), enums, struct_names)
+        FN_TYPEDEFS[nm] = nm
+        fn_types.append((nm, rt))
+    src = re.sub(r"typedef\s+[A-Za-z_][A-Za-z0-9_ \*]*?\(\s*\*\s*bj_[A-Za-z0-9_]+\s*\)\s*\([^;]*?\)\s*;", " ", src, flags=re.S)
     body = re.sub(r"typedef\s+struct\s+[A-Za-z_0-9]+\s*\{.*?\}\s*[A-Za-z_0-9]+\s*;", " ", src, flags=re.S)
     body = re.sub(r"(typedef\s+)?enum\s*[A-Za-z_0-9]*\s*\{.*?\}\s*[A-Za-z_0-9]*\s*;", " ", body, flags=re.S)
     body = re.sub(r"^#.*$", " ", body, flags=re.M)
@@ -152,7 +163,7 @@ def parse_header(path=HEADER):
             continue
         ps = [] if params in ("void", "") else [parse_param(p, enums, struct_names, decay=True) for p in split_params(params)]
         funcs.append((name, rust_type(ret, enums, struct_names), ps))
-    return dict(defines=defines, enums=enums, enum_consts=enum_consts, opaque=opaque, structs=structs, funcs=funcs)
+    return dict(defines=defines, enums=enums, enum_consts=enum_consts, opaque=opaque, structs=structs, funcs=funcs, fn_types=fn_types)
 
 
 def generate():
@@ -171,6 +182,8 @@ def generate():
     for k, v in h["enum_consts"]:
         o.append("pub const %s: c_int = %d;" % (k, v))
     o.append("")
+    for name, sig in h["fn_types"]:
+        o.append("pub type %s = %s;" % (name, sig))
     for name in h["opaque"]:
         o += ["#[repr(C)]", "pub struct %s {" % name, "    _private: [u8; 0],", "}"]
     o.append("")
