@@ -518,7 +518,10 @@ def main():
         del hv, hm
 
     # ---- secondary leg: cfg2 NTT (2^20 x 256 columns), the "NTT GB/s vs HBM peak" half of the metric
-    if not args.no_ntt:
+    shared_device = world > 1 and backend == "gloo" and torch.cuda.device_count() < world
+    if not args.no_ntt and shared_device:
+        out["ntt"] = {"skipped": "ranks share a device (functional gloo mode): the stand-alone transform legs need ~30 GB of their own"}
+    if not args.no_ntt and not shared_device:
         nlog, ncols = 20, 256
         src = torch.randint(0, 1 << 62, (ncols, 1 << nlog), dtype=torch.int64, device=dev)
         dst = torch.empty_like(src)
@@ -808,8 +811,10 @@ def main():
                                                     ("estimated %.0f s at 2^%d on this host" % (est_main, args.cpu_log_n) if est_main >= 150.0
                                                      else "%.0f GB of host memory available, %.0f GB wanted" % (ram_gb, 2.5 * need_gb))),
                                "cpu_model": cpu_model, "affinity_cpus": affinity, "cgroup_quota_cores": quota, "busy_cores_measured": round(busy_cores, 1),
+                               "isa": "Poseidon2 trees and NTT butterflies: " + O.poseidon2_isa() + " (run-time selected; the reference's CPU path is AVX-512 MixedGL / "
+                                      "state_avx512.rs); pointwise stages scalar",
                                "sample": "one proof of the same circuit at 2^%d rows by the oracle prover (C bulk ops + python "
-                                         "orchestration, OpenMP, -O3 -march=x86-64-v3), %.1f s" % (main_log, t_cpu),
+                                         "orchestration, OpenMP, -O3 -march=x86-64-v3 + AVX-512 kernels where the CPU has them), %.1f s" % (main_log, t_cpu),
                                "micro": {**({"proof_2p%d" % small[0]: {"s": round(small[1], 2), "rows_per_s": round((1 << small[0]) / small[1], 1),
                                                                        "busy_cores_measured": round(small[2], 1),
                                                                        "what": "the same oracle proof at the size earlier rounds reported"}} if small else {}),

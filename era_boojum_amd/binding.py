@@ -150,7 +150,7 @@ def exported_symbols():
 _lib = None
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def load_library():

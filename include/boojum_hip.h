@@ -43,8 +43,9 @@ typedef enum bj_status {
 typedef struct bj_ctx bj_ctx;
 
 /* 2: bj_gate_desc.wit_stride, bj_comm.all_gather_stream (round 2); 3: op lists in any numbering, run-time compiled gates;
- * 4: bj_proof_config.pow_runner, bj_circuit.table_id_col = BJ_TABLE_ID_AS_VARIABLE (round 5) */
-#define BJ_ABI_VERSION 5
+ * 4: bj_proof_config.pow_runner, bj_circuit.table_id_col = BJ_TABLE_ID_AS_VARIABLE (round 5); 5: bj_comm_replay_capture,
+ * bj_proof_workspace_bytes, bj_setup_device_bytes; 6: bj_prove_async / bj_proof_wait, the tiled-monomial operators, bj_comm_peer_create (round 6) */
+#define BJ_ABI_VERSION 6
 int bj_abi_version(void);
 int bj_device_count(void);
 const char *bj_status_string(int status);

@@ -415,6 +415,64 @@ impl<P: crate::field::traits::field_like::PrimeFieldLikeVectorized<Base = F>, CF
         unsafe { bj_proof_destroy(proof) };
         proof_from_bjpf::<H, EXT>(&words, proof_config)
     }
+
+    /// The pipelined form of `prove_hip` for a host that loops over witnesses (the shape of convenience.rs:119-196 called in a
+    /// loop): queues the proof on one of the context's two lanes and returns at once; `HipTicket::wait` hands the `Proof` over.
+    ///     let mut prev = cs.prove_hip_async(&ctx, &setup, ws[0].clone());
+    ///     for w in &ws[1..] { let cur = cs.prove_hip_async(&ctx, &setup, w.clone()); proofs.push(prev.wait(cfg)); prev = cur; }
+    /// The next proof's PCIe transfer and first transforms run under the previous proof's latency-bound tail; every proof is the
+    /// bytes `prove_hip` returns.  The ticket owns the flattened witness (the library reads it until `wait` returns).
+    pub fn prove_hip_async<'a>(&self, ctx: &'a HipCtx, setup: &HipSetup, witness_set: WitnessSet<F>) -> HipTicket<'a> {
+        let WitnessSet { public_inputs_values, public_inputs_with_locations, variables, witness, multiplicities } = witness_set;
+        assert_eq!(public_inputs_values.len(), public_inputs_with_locations.len());
+        assert_eq!(variables.len(), setup.num_vars);
+        let vars = flatten(variables.iter().chain(witness.iter()).map(|p| &p.storage[..]), setup.n);
+        let mult = flatten(multiplicities.iter().map(|p| &p.storage[..]), setup.n);
+        let publics: Vec<u64> = public_inputs_values.iter().map(|el| el.as_u64_reduced()).collect();
+        let mut raw = std::ptr::null_mut();
+        ctx.check(unsafe {
+            bj_prove_async(
+                ctx.raw,
+                setup.raw,
+                vars.as_ptr(),
+                if setup.has_lookup { mult.as_ptr() } else { std::ptr::null() },
+                if publics.is_empty() { std::ptr::null() } else { publics.as_ptr() },
+                &mut raw,
+            )
+        });
+        HipTicket { ctx, raw, _vars: vars, _mult: mult }
+    }
+}
+
+/// A proof in flight (`bj_ticket`).  Dropping it without `wait` waits for the proof and discards it.
+pub struct HipTicket<'a> {
+    ctx: &'a HipCtx,
+    raw: *mut bj_ticket,
+    _vars: Vec<u64>,
+    _mult: Vec<u64>,
+}
+
+impl<'a> HipTicket<'a> {
+    pub fn is_done(&self) -> bool {
+        unsafe { bj_proof_poll(self.raw) == 1 }
+    }
+    pub fn wait<H: TreeHasher<F>, EXT: FieldExtension<2, BaseField = F>>(mut self, proof_config: ProofConfig) -> Proof<F, H, EXT> {
+        let mut proof = std::ptr::null_mut();
+        let raw = std::mem::replace(&mut self.raw, std::ptr::null_mut());
+        self.ctx.check(unsafe { bj_proof_wait(raw, &mut proof) });
+        let mut words = vec![0u64; unsafe { bj_proof_size_u64(proof) }];
+        self.ctx.check(unsafe { bj_proof_serialize(proof, words.as_mut_ptr()) });
+        unsafe { bj_proof_destroy(proof) };
+        proof_from_bjpf::<H, EXT>(&words, proof_config)
+    }
+}
+
+impl<'a> Drop for HipTicket<'a> {
+    fn drop(&mut self) {
+        if !self.raw.is_null() {
+            unsafe { bj_proof_wait(self.raw, std::ptr::null_mut()) };
+        }
+    }
 }
 
 /// The same proof from the reference's own dumps — for a host that keeps the witness as `WitnessVec` + `DenseVariablesCopyHint`

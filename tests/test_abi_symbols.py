@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), "libboojum_hip.so does not export %s" % name
     # the python binding covers the whole header, nothing more
     assert declared == E.exported_symbols()
-    assert lib.bj_abi_version() == E.binding.ABI_VERSION == 5
+    assert lib.bj_abi_version() == E.binding.ABI_VERSION == 6
 
 
 def test_status_strings():
