@@ -586,14 +586,21 @@ struct F10Args {
     size_t in_col_stride, out_col_stride;
 };
 // TILED layout of a 2^22-word column (the monomial form between an inverse transform and the extensions that read it):
-// element e = m * 4096 + r * 16 + l (m: ten bits, r: eight, l: four) sits at word
-//     tiled(e) = r * 16384 + (l >> 1) * 2048 + m * 2 + (l & 1)
-// — the 16384 words one front-pass tile reads are contiguous, ordered so that (a) the pair of 4096-word chunks (b, b + 512) of the
+// element e = m * 4096 + r * 2^LB + l (m: ten bits, r: 12 - LB, l: LB = TILED_LB bits) sits at word
+//     tiled(e) = r * (1024 * 2^LB) + (l >> 1) * 2048 + m * 2 + (l & 1)
+// — the 1024 * 2^LB words one front-pass tile reads are contiguous, ordered so that (a) the pair of 4096-word chunks (b, b + 512) of the
 // inverse transform's last pass, whose results are the words (m, l = 2k) and (m, l = 2k + 1) of FOUR tiles for every m, leaves them
 // as 16-byte words in runs of 1 KB per wave store — the bit reversal of ifft_natural_to_natural (fft/mod.rs:464-491) happens in the
 // store addresses, no pass of its own — and (b) the front pass fetches 16-byte words (m, l pair) for its LDS tile in [m][l] order as before.
-__host__ __device__ constexpr size_t tiled_index(size_t e) {
-    return ((e >> 4) & 255u) * 16384u + ((e >> 1) & 7u) * 2048u + (e >> 12) * 2u + (e & 1u);
+#ifndef BJ_TILED_LB
+#define BJ_TILED_LB 3   // lo values per front-pass tile of the tiled layout = 2^LB.  3: 1024 x 8 tiles (64 KB), 512-thread workgroups, TWO per CU —
+                        // their barrier phases interleave; the half-line stores of tiles 2u, 2u + 1 meet in one XCD's L2 (blocks b, b + 8).
+                        // Measured with tiled (contiguous) reads: LDE 93 x 2^22 x 8 27.10 ms against 27.76 ms for 4 (full-line tiles, one
+                        // 1024-thread workgroup per CU); with natural-order reads (64-byte runs) the half-line tiles had lost.
+#endif
+constexpr int TILED_LB = BJ_TILED_LB;
+__host__ __device__ constexpr size_t tiled_index(size_t e) {   // e = m * 4096 + r * 2^LB + l
+    return ((e & 4095u) >> TILED_LB) * ((size_t)1024 << TILED_LB) + ((e & ((1u << TILED_LB) - 1u)) >> 1) * 2048u + (e >> 12) * 2u + (e & 1u);
 }
 __global__ void front10_table_kernel(u64 *out, const u64 *__restrict__ T, const u64 *__restrict__ round_scale, unsigned n_cosets) {
     const u32 idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,7 +670,7 @@ typedef void __attribute__((address_space(3))) *f10_ldst;
 #endif
 template <bool UNIT_FIRST, int LB, bool TILED_IN = false>
 __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
-    static_assert(!TILED_IN || LB == 4, "the tiled layout is the one of full-line tiles");
+    static_assert(!TILED_IN || LB == TILED_LB, "the tiled layout is defined for one tile width");
     constexpr u32 NT = 64u << LB, TILE_E = 1024u << LB, ROWS = 128u >> LB;   // threads, elements per tile, mid rows per 1-KB DMA piece
     __shared__ u64 lds[TILE_E + 1024];      // ONE object: tile (64 / 128 KB), twiddle table of this workgroup's coset (8 KB)
     u64 *lds_tw = lds + TILE_E;
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
     const u32 ixB1 = (((mhB * 64u + mllB) << LB) + lB) * 8u, ixB2 = f10_bc<LB>(mhB * 64u + mllB, lB) * 8u, ixC = f10_bc<LB>(m92 * 4u, lhiC * 4u) * 8u;
     // DMA source of this lane inside a piece: piece p = mid rows [ROWS p, ROWS (p + 1)), lane = (row, lo pair)
     // (tiled input: the lane's 16 bytes are the words (row, l pair) at pair * 2048 + row * 2 of the tile's 16384 contiguous words)
-    const u32 dma_off = TILED_IN ? ((lane & 7u) * 2048u + (lane >> 3) * 2u) * 8u
+    const u32 dma_off = TILED_IN ? ((lane & ((1u << (LB - 1)) - 1u)) * 2048u + (lane >> (LB - 1)) * 2u) * 8u
                                  : (((lane >> (LB - 1)) << s_log) + (lane & ((1u << (LB - 1)) - 1u)) * 2u) * 8u;
     const unsigned col0 = blockIdx.y * a.cols_per_block;
     const unsigned col1 = min(col0 + a.cols_per_block, a.n_cols);
@@ -821,7 +828,8 @@ __global__ void __launch_bounds__(256, BJ_PAIR_WAVES) ntt_local12_pair_tiled_ker
     const u32 ta = t >> 4, tc = t & 15;
     const u32 wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const u32 rb = gl::bitrev32(bp, 10);                      // even: bp < 512
-    const size_t tile_off = ((size_t)(gl::bitrev32(wave, 2) * 64u + (rb >> 4))) * 16384u + (size_t)((rb & 15u) >> 1) * 2048u;
+    const u32 rl = gl::bitrev32(wave, 2) * 1024u + rb;        // the twelve bits (r, l) below m of this wave's natural indices (l & 1 = 0)
+    const size_t tile_off = (size_t)(rl >> TILED_LB) * ((size_t)1024 << TILED_LB) + (size_t)((rl & ((1u << TILED_LB) - 1u)) >> 1) * 2048u;
     const u32 pi = (t & ~63u) | gl::bitrev32(t & 63u, 6);     // the group of sixteen words this lane takes in step C
     const u32 off_st = (t & 63u) * 16u;                       // bytes: word pair m = lane (+ rev4(j) * 64, a constant per store)
     for (unsigned col = col0; col < col1; col++) {
@@ -876,31 +884,32 @@ __global__ void __launch_bounds__(256, BJ_PAIR_WAVES) ntt_local12_pair_tiled_ker
 // and the operator-level entry points): block = (tile r, 64 consecutive m), 1024 words through LDS; natural side 64 runs of 128
 // bytes, tiled side 8 runs of 1 KB
 __global__ void __launch_bounds__(256) tiled_permute_kernel(const u64 *in, u64 *out, size_t in_col_stride, size_t out_col_stride, int to_tiled) {
-    __shared__ u64 tile[64 * 17];
+    constexpr u32 LW = 1u << TILED_LB, PER = 64u * LW, TILE_W = 1024u * LW;   // lo values per row, words per block, words per tile
+    __shared__ u64 tile[64 * (LW + 1)];
     const u32 t = threadIdx.x, r = blockIdx.x >> 4, m0 = (blockIdx.x & 15u) * 64u;
     const u64 *src = in + (size_t)blockIdx.y * in_col_stride;
     u64 *dst = out + (size_t)blockIdx.y * out_col_stride;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (u32 k = 0; k < PER / 256u; k++) {
         const u32 q = t + 256u * k;
         if (to_tiled) {          // natural read: q = (m local, l)
-            const u32 ml = q >> 4, l = q & 15u;
-            tile[ml * 17 + l] = src[((size_t)(m0 + ml) << 12) + r * 16u + l];
+            const u32 ml = q >> TILED_LB, l = q & (LW - 1u);
+            tile[ml * (LW + 1) + l] = src[((size_t)(m0 + ml) << 12) + r * LW + l];
         } else {                 // tiled read: q = (pair, m local, l & 1)
             const u32 pair = q >> 7, ml = (q >> 1) & 63u, lb = q & 1u;
-            tile[ml * 17 + pair * 2 + lb] = src[(size_t)r * 16384u + pair * 2048u + (m0 + ml) * 2u + lb];
+            tile[ml * (LW + 1) + pair * 2 + lb] = src[(size_t)r * TILE_W + pair * 2048u + (m0 + ml) * 2u + lb];
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (u32 k = 0; k < PER / 256u; k++) {
         const u32 q = t + 256u * k;
         if (to_tiled) {
             const u32 pair = q >> 7, ml = (q >> 1) & 63u, lb = q & 1u;
-            dst[(size_t)r * 16384u + pair * 2048u + (m0 + ml) * 2u + lb] = tile[ml * 17 + pair * 2 + lb];
+            dst[(size_t)r * TILE_W + pair * 2048u + (m0 + ml) * 2u + lb] = tile[ml * (LW + 1) + pair * 2 + lb];
         } else {
-            const u32 ml = q >> 4, l = q & 15u;
-            dst[((size_t)(m0 + ml) << 12) + r * 16u + l] = tile[ml * 17 + l];
+            const u32 ml = q >> TILED_LB, l = q & (LW - 1u);
+            dst[((size_t)(m0 + ml) << 12) + r * LW + l] = tile[ml * (LW + 1) + l];
         }
     }
 }
@@ -954,7 +963,7 @@ void launch_ntt_local12_pair_tiled(const u64 *in, u64 *out, const u64 *tw, const
     hipLaunchKernelGGL(ntt_local12_pair_tiled_kernel, dim3(512, (n_cols + cpb - 1) / cpb), dim3(256), 0, s, a);
 }
 void launch_tiled_permute(const u64 *in, u64 *out, unsigned n_cols, size_t in_col_stride, size_t out_col_stride, bool to_tiled, hipStream_t s) {
-    hipLaunchKernelGGL(tiled_permute_kernel, dim3(256 * 16, n_cols), dim3(256), 0, s, in, out, in_col_stride, out_col_stride, to_tiled ? 1 : 0);
+    hipLaunchKernelGGL(tiled_permute_kernel, dim3((4096u >> TILED_LB) * 16, n_cols), dim3(256), 0, s, in, out, in_col_stride, out_col_stride, to_tiled ? 1 : 0);
 }
 
 void launch_ntt_strided8(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, unsigned log_n, unsigned r0,
@@ -1028,8 +1037,9 @@ void launch_ntt_first5(const u64 *in, u64 *out, const u64 *tw, const u64 *round_
 void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round_scale, u64 *d_table, unsigned log_n, unsigned n_cols,
                         unsigned n_cosets, size_t in_col_stride, size_t out_col_stride, hipStream_t s, bool tiled_in) {
     hipLaunchKernelGGL(front10_table_kernel, dim3(n_cosets * 4), dim3(256), 0, s, d_table, tw, round_scale, n_cosets);
-    constexpr int LB = BJ_F10_LB;
-    const unsigned tiles = 1u << (log_n - 10 - LB);
+    constexpr int LBN = BJ_F10_LB;
+    const int lb = tiled_in ? TILED_LB : LBN;
+    const unsigned tiles = 1u << (log_n - 10 - lb);
     const size_t n = (size_t)1 << log_n;
     for (unsigned c0 = 0; c0 < n_cosets; c0 += 8) {   // at most eight cosets per launch: a tile's workgroups are one dispatch window on one XCD
         const unsigned nc = n_cosets - c0 < 8 ? n_cosets - c0 : 8;
@@ -1037,15 +1047,15 @@ void launch_ntt_front10(const u64 *in, u64 *out, const u64 *tw, const u64 *round
         while (cpb > 1 && (size_t)tiles * nc * ((n_cols + cpb - 1) / cpb) < 4096) cpb >>= 1;
         F10Args a{in, out + (size_t)c0 * n, d_table + (size_t)c0 * 1024, log_n, n_cols, cpb, nc, in_col_stride, out_col_stride};
         dim3 grid(tiles * nc, (n_cols + cpb - 1) / cpb, 1);
-        if (tiled_in && LB == 4) {
+        if (tiled_in) {
             if (round_scale)
-                hipLaunchKernelGGL((ntt_front10_kernel<false, 4, true>), grid, dim3(1024), 0, s, a);
+                hipLaunchKernelGGL((ntt_front10_kernel<false, TILED_LB, true>), grid, dim3(64u << TILED_LB), 0, s, a);
             else
-                hipLaunchKernelGGL((ntt_front10_kernel<true, 4, true>), grid, dim3(1024), 0, s, a);
+                hipLaunchKernelGGL((ntt_front10_kernel<true, TILED_LB, true>), grid, dim3(64u << TILED_LB), 0, s, a);
         } else if (round_scale)
-            hipLaunchKernelGGL((ntt_front10_kernel<false, LB>), grid, dim3(64u << LB), 0, s, a);
+            hipLaunchKernelGGL((ntt_front10_kernel<false, LBN>), grid, dim3(64u << LBN), 0, s, a);
         else
-            hipLaunchKernelGGL((ntt_front10_kernel<true, LB>), grid, dim3(64u << LB), 0, s, a);
+            hipLaunchKernelGGL((ntt_front10_kernel<true, LBN>), grid, dim3(64u << LBN), 0, s, a);
     }
 }
 

@@ -121,9 +121,9 @@ int bj_bitreverse_batch(bj_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsi
 
 /* The monomial form between ifft_natural_to_natural (fft/mod.rs:464-491) and transform_monomials_to_lde (utils.rs:311-403) in the
  * layout bj_prove keeps it in.  For 2^22-row traces (the size with a two-pass transform plan) that is a TILED layout — coefficient
- * e = m * 4096 + r * 16 + l at word r * 16384 + (l >> 1) * 2048 + m * 2 + (l & 1) — which the inverse transform's last pass
+ * e = m * 4096 + r * 8 + l (l < 8) at word r * 8192 + (l >> 1) * 2048 + m * 2 + (l & 1) — which the inverse transform's last pass
  * stores directly (the bit reversal and the 1/n factor of the reference's inverse happen in that store: two HBM passes, no
- * bit-reversal pass) and the extension's first pass reads as contiguous 128 KB tiles; every other size keeps natural order and
+ * bit-reversal pass) and the extension's first pass reads as contiguous 64 KB tiles; every other size keeps natural order and
  * these calls return BJ_ERR_UNSUPPORTED.  Pointwise work on monomials (linear combinations) is layout-blind.
  * bj_monomials_tiled: 1 when bj_prove uses the tiled layout for this trace length (BJ_MONO_TILED=0 / BJ_NTT_TWO_PASS=0 turn it off).
  * bj_intt_batch_tiled: values on the subgroup, natural order -> tiled monomials (main domain, no coset; in place allowed).

@@ -202,8 +202,8 @@ def test_lde_at_bench_sizes_matches_oracle(log_n, log_lde, n_cols):
 
 def _tiled_index(e):
     """The tiled layout of a 2^22-word column (include/boojum_hip.h, csrc/ntt_r16.hip: tiled_index)."""
-    e = np.asarray(e, dtype=np.int64)
-    return ((e >> 4) & 255) * 16384 + ((e >> 1) & 7) * 2048 + (e >> 12) * 2 + (e & 1)
+    e = np.asarray(e, dtype=np.int64)       # e = m * 4096 + r * 8 + l: tile r (nine bits) = 8192 contiguous words, ordered (l pair, m, l & 1)
+    return ((e >> 3) & 511) * 8192 + ((e >> 1) & 3) * 2048 + (e >> 12) * 2 + (e & 1)
 
 
 @pytest.mark.parametrize("n_cols", [1, 5, 40])

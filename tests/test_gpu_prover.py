@@ -435,7 +435,15 @@ def test_pipelined_drop_in_call_gives_the_serial_proofs():
         s1.wait(tb)
     assert np.array_equal(s2.wait(tg)[0], ref2)
     assert np.array_equal(s1.wait(s1.prove_async())[0], ref1)
-    s1.close(); s2.close()
+    # a circuit whose gates are op lists (generated / run-time compiled kernels, non-copiable witness columns): both lanes launch the
+    # same uploaded programs concurrently
+    c3 = S.recursion_like_circuit(10, seed=7)
+    s3 = E.ProverSetup(ctx(), c3, 8, 16, 30)
+    ref3 = s3.prove()[0].copy()
+    ts = [s3.prove_async(), s3.prove_async(), s3.prove_async(), s3.prove_async()]
+    for t in ts:
+        assert np.array_equal(s3.wait(t)[0], ref3)
+    s1.close(); s2.close(); s3.close()
     ctx().release_workspace()          # frees the lanes' arenas and witness staging too
 
 
