@@ -200,6 +200,7 @@ int peer_on_stream(void *user, const void *d_send, void *d_recv, size_t bytes, v
     for (unsigned k = 0; k < W; k++) {               // start with the next rank: at any moment every link carries one copy
         const unsigned p = (c->rank + 1 + k) % W;
         char *dst = p == c->rank ? (char *)d_recv : (char *)c->peer_box[p] + half_sel * c->peer_half[p];   // the own slot goes straight home
+        if (dst + (size_t)c->rank * bytes == (const char *)d_send) continue;                                // in-place gather: it is there already
         if (hipMemcpyAsync(dst + (size_t)c->rank * bytes, d_send, bytes, hipMemcpyDeviceToDevice, c->streams[p]) != hipSuccess) return -3;
     }
     PEER_DBG("copies queued");

@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(64 << LB, 4) ntt_front10_kernel(F10Args a) {
     const u32 offC = (((m92 * 4u) << s_log) + lhiC * 4u) * 8u;
     const u32 ixB1 = (((mhB * 64u + mllB) << LB) + lB) * 8u, ixB2 = f10_bc<LB>(mhB * 64u + mllB, lB) * 8u, ixC = f10_bc<LB>(m92 * 4u, lhiC * 4u) * 8u;
     // DMA source of this lane inside a piece: piece p = mid rows [ROWS p, ROWS (p + 1)), lane = (row, lo pair)
-    // (tiled input: the lane's 16 bytes are the words (row, l pair) at pair * 2048 + row * 2 of the tile's 16384 contiguous words)
+    // (tiled input: the lane's 16 bytes are the words (row, l pair) at pair * 2048 + row * 2 of the tile's 1024 * 2^LB contiguous words)
     const u32 dma_off = TILED_IN ? ((lane & ((1u << (LB - 1)) - 1u)) * 2048u + (lane >> (LB - 1)) * 2u) * 8u
                                  : (((lane >> (LB - 1)) << s_log) + (lane & ((1u << (LB - 1)) - 1u)) * 2u) * 8u;
     const unsigned col0 = blockIdx.y * a.cols_per_block;
