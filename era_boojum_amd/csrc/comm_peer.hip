@@ -156,6 +156,8 @@ int peer_on_stream(void *user, const void *d_send, void *d_recv, size_t bytes, v
             mine.capacity = c->mailbox_bytes;
             mine.ok = 1;
         }
+        if (const char *f = getenv("BJ_PEER_TEST_FAIL_RANK"))      // test hook: this rank pretends it could not export its mailbox
+            if ((unsigned)atoi(f) == c->rank) mine.ok = 0;
         PEER_DBG("mailbox %p (%zu bytes), ok %d: exchanging", c->mailbox, c->mailbox_bytes, (int)mine.ok);
         std::vector<PeerRecord> all(W);
         if (c->exchange(c->exchange_user, &mine, all.data(), sizeof(PeerRecord))) return -2;

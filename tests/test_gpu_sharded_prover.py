@@ -97,6 +97,29 @@ def test_sharded_proof_with_full_mesh_peer_copies(tmp_path, world, log_n, fri_ld
             assert st["bulk_calls"] >= 2 and st["bulk_bytes_received"] >= 2 * world * bulk_min, st
 
 
+def test_peer_transport_falls_back_together_when_one_rank_cannot_export(tmp_path):
+    """One rank of four reports that it could not export its mailbox (BJ_PEER_TEST_FAIL_RANK, a test hook in comm_peer.hip): ALL
+    ranks serve that exchange size through the base transport from then on — the decision travels in the negotiation, nobody is
+    left waiting in a copy — and the proofs are still the single-GPU bytes."""
+    import json
+    world, log_n, fri_lde, cap, sec = 4, 12, 8, 16, 30
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", BJ_COMM_BULK="peer", BJ_COMM_BULK_MIN="4096",
+               BJ_PEER_TEST_FAIL_RANK="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "sharded_worker.py"), str(tmp_path),
+           str(log_n), str(fri_lde), str(cap), str(sec)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    c = S.sha_shaped_circuit(log_n, seed=7, table_bits=2, boolean_columns=2, specialized_constant_columns=3)
+    single = E.ProverSetup(ctx(), c, fri_lde, cap, sec)
+    ref, _ = single.prove()
+    single.close()
+    for rank in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "proof_%d.npy" % rank)), ref), "rank %d" % rank
+        st = json.load(open(os.path.join(str(tmp_path), "peer_%d.json" % rank)))
+        assert st["fallbacks"] >= 2 and st["bulk_calls"] == 0, st
+
+
 def test_sharded_setup_rejects_bad_world():
     c = S.sha_shaped_circuit(8, seed=1, table_bits=2)
 
