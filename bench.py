@@ -281,7 +281,7 @@ def main():
         if comm is None:
             comm, transport = E.TorchComm(ctx), "torch.distributed all_gather_into_tensor through the bj_comm host callback"
         base_comm, peer_comm, peer_err = comm, None, None
-        try:     # collective (a gloo control group); every rank reports, all agree
+        try:     # no collective of its own (the control channel rides on the default group); every rank reports, all agree
             peer_comm = E.PeerComm(ctx, base_comm)
             okp = 1
         except Exception as e:                    # noqa: BLE001
@@ -461,6 +461,7 @@ def main():
                                                    note="rank 0's wall time and time in collectives per proof with the bulk exchanges on the other transport; "
                                                         "the timed headline used: " + transport)
         other_bulk_stuck = th2.is_alive()
+        ran_other_bulk = True
     # ---- the drop-in call with a host witness (bj_prove): PCIe transfer of the 93 columns inside the timed region
     if world == 1 and not args.no_host_witness:
         hv = torch.from_numpy(circuit.variables.view(np.int64)).pin_memory()
@@ -826,6 +827,12 @@ def main():
         print(json.dumps(out), flush=True)
     if stuck_legs:           # a helper thread is still inside the library: no orderly teardown behind it
         print("bench.py: leaving through os._exit, stuck: %s" % ", ".join(stuck_legs), file=sys.stderr, flush=True)
+        os._exit(0)
+    if locals().get("ran_other_bulk"):
+        # the extra proofs on the other bulk transport may have ended differently on different ranks (a watchdog on one, not on another):
+        # no collective may follow them — every rank leaves on its own, the line is out
+        sys.stdout.flush()
+        sys.stderr.flush()
         os._exit(0)
     barrier()           # rank 0 may still have been verifying / timing the CPU baseline: leave the group together
     setup.close()

@@ -828,9 +828,8 @@ _HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c
 class PeerComm:
     """bj_comm_peer_create: full-mesh peer copies for the bulk exchanges of a sharded proof (every rank writes its contribution
     straight into every peer's receive buffer, mapped through HIP IPC), everything smaller through `base` (a TorchComm or RcclComm).
-    The control channel — a blocking all-gather of a few host bytes — is torch.distributed on a CPU (gloo) group: `ctrl_group`,
-    or a new gloo group over the default group's ranks when the default backend cannot move host tensors.  Collective: every rank
-    of the proof constructs it."""
+    The control channel — a blocking all-gather of a few host bytes — is torch.distributed on `ctrl_group` (default: the default
+    group): host tensors over gloo, tiny device tensors over nccl.  Every rank of the proof constructs it."""
 
     def __init__(self, ctx, base, ctrl_group=None, bulk_threshold_bytes=1 << 20):
         import torch
@@ -838,9 +837,11 @@ class PeerComm:
         self._ctx, self._lib, self._base = ctx, ctx._lib, base
         self._torch, self._dist = torch, dist
         self.rank, self.world = base.rank, base.world
-        if ctrl_group is None and dist.get_backend() != "gloo":
-            ctrl_group = dist.new_group(backend="gloo")          # collective
+        # the control channel rides on the process group the host already has (no second rendezvous that could fail on its own):
+        # host tensors over gloo, tiny device tensors over nccl (= RCCL)
         self._ctrl = ctrl_group
+        self._on_device = dist.get_backend(ctrl_group) == "nccl"
+        self._device = torch.device("cuda", ctx.device)
         self.error = None
         self._fn = _HOST_EXCHANGE_FN(self._exchange)             # keep the trampoline alive
         self.struct = _Comm()
@@ -850,8 +851,14 @@ class PeerComm:
         try:
             t = self._torch
             send = t.frombuffer((C.c_ubyte * nbytes).from_address(h_send), dtype=t.uint8).clone()
-            recv = t.empty(nbytes * self.world, dtype=t.uint8)
-            self._dist.all_gather_into_tensor(recv, send, group=self._ctrl)
+            if self._on_device:
+                d_send = send.to(self._device)
+                d_recv = t.empty(nbytes * self.world, dtype=t.uint8, device=self._device)
+                self._dist.all_gather_into_tensor(d_recv, d_send, group=self._ctrl)
+                recv = d_recv.cpu()
+            else:
+                recv = t.empty(nbytes * self.world, dtype=t.uint8)
+                self._dist.all_gather_into_tensor(recv, send, group=self._ctrl)
             C.memmove(h_recv, recv.data_ptr(), nbytes * self.world)
             return 0
         except Exception as e:  # an exception must not unwind through the C frames
