@@ -827,10 +827,16 @@ def main():
         print(json.dumps(out), flush=True)
     if stuck_legs:           # a helper thread is still inside the library: no orderly teardown behind it
         print("bench.py: leaving through os._exit, stuck: %s" % ", ".join(stuck_legs), file=sys.stderr, flush=True)
+        if sharded and rank == 0 and cache:
+            import shutil
+            shutil.rmtree(cache, ignore_errors=True)
         os._exit(0)
     if locals().get("ran_other_bulk"):
         # the extra proofs on the other bulk transport may have ended differently on different ranks (a watchdog on one, not on another):
         # no collective may follow them — every rank leaves on its own, the line is out
+        if sharded and rank == 0 and cache:      # the mapped copy of the circuit (the other ranks' mappings outlive the unlink)
+            import shutil
+            shutil.rmtree(cache, ignore_errors=True)
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)
