@@ -230,14 +230,16 @@ def test_plain_bench_command_refuses_more_gpus_than_visible():
     assert r.returncode != 0 and "refusing" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 11), (4, 12), (8, 12), (8, 18)])
+@pytest.mark.parametrize("world,log_n", [(2, 11), (4, 12), (8, 12), (8, 18), (8, 22)])
 def test_one_rank_alone_with_recorded_peers(world, log_n):
     """bench.py's scale_replay leg in small (era_boojum_amd/scale_replay.py): the gathered buffer of every collective is recorded
     with ONE rank on the device at a time (a replay transport that serves collectives 0 .. k-1 and captures the rank's contribution
     to collective k: bj_comm_replay_capture), the last sweep ends with every rank holding the single-GPU proof; then every rank
     runs ALONE behind the recorded-peer transport (bj_comm_replay_create, installed with bj_setup_set_comm): each of its
     contributions equals the slice the recording holds for it, and its proof is again the single-GPU proof, byte for byte.  The
-    rank's HBM (setup + workspace high-water mark) comes back too; no proof needed an overflow slab."""
+    rank's HBM (setup + workspace high-water mark) comes back too; no proof needed an overflow slab.  The last case is the bench's
+    size: eight ranks of a 2^22-row proof, each with its monomials in the tiled layout, its single coset extended by the two-pass
+    plan, DEEP numerator slices combined on tiled coefficients — every rank's proof = the single-GPU bytes."""
     from era_boojum_amd import scale_replay
     c = S.sha_shaped_circuit(log_n, seed=23, table_bits=2)
     single = E.ProverSetup(ctx(), c, 8, 16, 30)
@@ -251,9 +253,7 @@ def test_one_rank_alone_with_recorded_peers(world, log_n):
     for v in got["ranks"].values():
         assert v["setup_bytes"] > 0 and v["workspace"]["overflow_slabs"] == 0
         assert 0 < v["workspace"]["high_water_bytes"] <= v["workspace"]["reserved_bytes"]
-    for v in got["ranks"].values():
-        assert v["setup_bytes"] > 0 and v["workspace"]["overflow_slabs"] == 0
-        assert 0 < v["workspace"]["high_water_bytes"] <= v["workspace"]["reserved_bytes"]
+    ctx().release_workspace()
 
 
 def test_replay_transport_refuses_what_was_not_recorded():
