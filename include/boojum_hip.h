@@ -542,13 +542,15 @@ int bj_comm_rccl_stats(const bj_comm *comm, size_t *calls, size_t *bytes_receive
  * traffic"; the reference has no multi-device path, the exchanged data are those of proof.rs:89-91 / merkle_tree.rs:112-157): wraps
  * `base` (bj_comm_rccl_create or a host callback) and serves every exchange of at least bulk_threshold_bytes per rank (0: 1 MiB) —
  * the quotient residues, the first folded FRI layer, the DEEP numerator slices — by copying this rank's contribution straight into
- * slot `rank` of every peer's receive buffer (hipIpcGetMemHandle / hipIpcOpenMemHandle once per allocation, world concurrent
- * copies: one per link) instead of a ring that is bound by ONE link; smaller exchanges go to `base` unchanged.  `exchange` is the
- * host's control channel: a BLOCKING all-gather of `bytes` host bytes per rank, rank-major into h_recv (MPI_Allgather, a TCP store,
- * torch.distributed's gloo group); it carries the IPC handles and serves as the completion barrier (three calls per bulk exchange).
- * When any rank cannot export or map a buffer all ranks agree to use `base` for that exchange (bj_comm_peer_stats: fallbacks).
- * Same bytes in the same slots: proofs do not change.  Selectable beside RCCL, never the default; its author had one GPU (the
- * tests run the ranks as processes sharing the device) — no link-level timing exists.  `base` must outlive the returned comm. */
+ * slot `rank` of every peer's MAILBOX (a double-buffered receive buffer owned by the transport, exported once with
+ * hipIpcGetMemHandle and mapped by the peers with hipIpcOpenMemHandle; world concurrent copies: one per link) instead of a ring that
+ * is bound by ONE link, followed by one device copy from the mailbox into d_recv; smaller exchanges go to `base` unchanged.
+ * `exchange` is the host's control channel: a BLOCKING all-gather of `bytes` host bytes per rank, rank-major into h_recv
+ * (MPI_Allgather, a TCP store, torch.distributed); it carries the IPC handles and a vote once per exchange size and then serves as
+ * the completion barrier, one call per bulk exchange.  When any rank cannot export or map a mailbox all ranks agree to use `base`
+ * for that size (bj_comm_peer_stats: fallbacks).  Same bytes in the same slots: proofs do not change.  Selectable beside RCCL, never
+ * the default; its author had one GPU (the tests run the ranks as processes sharing the device) — no link-level timing exists.
+ * `base` must outlive the returned comm. */
 typedef int (*bj_host_exchange_fn)(void *user, const void *h_send, void *h_recv, size_t bytes);
 int bj_comm_peer_create(bj_ctx *ctx, const bj_comm *base, bj_host_exchange_fn exchange, void *exchange_user, size_t bulk_threshold_bytes,
                         bj_comm *out);
