@@ -190,7 +190,8 @@ void load_env() {
     if (set("BJ_NTT_FIRST4_MODE")) e.ntt_first4_mode = atoi(getenv("BJ_NTT_FIRST4_MODE"));
     e.ntt_two_pass = str("BJ_NTT_TWO_PASS").rfind("0", 0) != 0;
     e.mono_tiled = str("BJ_MONO_TILED").rfind("0", 0) != 0;
-    e.async_no_copy_first = set("BJ_ASYNC_NO_COPY_FIRST");
+    if (set("BJ_ASYNC_MODE")) e.async_mode = atoi(getenv("BJ_ASYNC_MODE"));
+    e.async_stagger = str("BJ_ASYNC_STAGGER").rfind("0", 0) != 0;
     e.gate_no_aot = set("BJ_GATE_NO_AOT");
     e.gate_no_fuse = set("BJ_GATE_NO_FUSE");
     e.gate_no_jit = set("BJ_GATE_NO_JIT");

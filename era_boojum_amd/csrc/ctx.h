@@ -84,8 +84,9 @@ int ensure_twiddles(bj_ctx *ctx, unsigned log_n, bool inverse);
 int ensure_scratch(bj_ctx *ctx, size_t elems);
 inline gl::u64 *front_table(bj_ctx *ctx) { return ctx->d_small + 64 + 64 * 32 + 4096; }   // BJ_FRONT_TABLE_WORDS (kernels.h)
 unsigned setup_world(const bj_setup *s);         // ranks of the proof a setup belongs to (1: single device)
+// mode 1: whole witness first, then as on a resident witness; mode 2: groups transferred and transformed as they land, hashed once
 int prove_host_copy_first(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
-                          const uint64_t *h_public_values, bj_proof **out);
+                          const uint64_t *h_public_values, bj_proof **out, int mode);
 void pipeline_destroy(bj_ctx *ctx);              // waits for the asynchronous proofs in flight, ends the lanes
 int pipeline_release_workspace(bj_ctx *ctx);    // bj_ctx_release_workspace on every idle lane
 int arena_reset(bj_ctx *ctx, size_t need_elems);

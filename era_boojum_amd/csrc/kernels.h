@@ -25,7 +25,8 @@ struct EnvConfig {
     bool prove_no_absorb = false;
     bool copy_perm_wide_k = false;       // BJ_COPY_PERM_WIDE_K: quotient_copy_perm with 64-bit non-residue products even when they fit 32 bits (A/B, tests)
     bool prove_uniform_groups = false;   // BJ_PROVE_UNIFORM_GROUPS: equal groups of G columns, one multi-block absorption run per group (round 4's GROUPING only: its launches absorbed eight columns each)
-    bool async_no_copy_first = false;    // BJ_ASYNC_NO_COPY_FIRST: bj_prove_async lanes always take bj_prove's group-wise transfer (A/B)
+    bool async_stagger = true;           // BJ_ASYNC_STAGGER=0: bj_prove_async lanes start whenever they are given work (A/B)
+    int async_mode = -1;                 // BJ_ASYNC_MODE: what a bj_prove_async lane does while its sibling proves: -1 by witness size (default), 0 bj_prove as is (+ stagger), 1 whole witness first, 2 groups + one hash
     unsigned prove_h2d_group = 8;
     size_t nodes_lanepar_max = 16384;
     std::string jit_cache_dir, rccl_lib;

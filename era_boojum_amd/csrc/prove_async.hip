@@ -11,6 +11,7 @@
 // At most two proofs are in flight: a third submission waits for the lane it is due on.
 #include "ctx.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -42,10 +43,31 @@ struct Lane {
     bj_ticket *job = nullptr;      // submitted, not finished
     bool quit = false;
     Lane *sibling = nullptr;
+    // when the proof in flight started, how long the last one took, and for which setup (for the stagger below)
+    std::chrono::steady_clock::time_point started;
+    double last_ms = 0;
+    const bj_setup *running = nullptr, *last_setup = nullptr;
 
     bool busy() {
         std::lock_guard<std::mutex> lk(m);
         return job != nullptr;
+    }
+    // Two lanes that prove the same circuit take the same time, so whatever offset they start with stays: started together they stay in
+    // phase — both hash at once, both sit in their latency-bound tails at once — and the second proof in flight fills nothing.  A lane
+    // that is about to start within a quarter period of its sibling's start (same setup, period known from the last proof) therefore
+    // waits until half a period after it; the device is busy with the sibling meanwhile, and from then on the lanes alternate.
+    void stagger(const bj_setup *setup) {
+        if (!sibling || !bj::env().async_stagger) return;
+        double wait_ms = 0;
+        {
+            std::lock_guard<std::mutex> lk(sibling->m);
+            const double period = sibling->last_setup == setup && sibling->last_ms > 0 ? sibling->last_ms : (last_setup == setup ? last_ms : 0);
+            if (sibling->job && sibling->running == setup && period > 0) {
+                const double off = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sibling->started).count();
+                if (off < 0.25 * period) wait_ms = 0.5 * period - off;
+            }
+        }
+        if (wait_ms > 0) std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(wait_ms));
     }
 
     void run() {
@@ -57,15 +79,33 @@ struct Lane {
                 if (quit) return;
                 t = job;
             }
+            // What a lane does while its sibling proves, by witness size (measured, tools/async_small.py; BJ_ASYNC_MODE overrides):
+            //   below 1 GiB (<= 2^20 rows of the bench geometry): bj_prove as is — the group-wise transfer hides behind the lane's own
+            //   transforms — with the lanes STAGGERED half a period apart: 2^16 / 2^18 / 2^20 rows 1.10 / 1.18 / 1.09 x the serial rate
+            //   (0.91 x at 2^20 when both lanes start together);
+            //   from 1 GiB on: the whole witness first (55 ms of PCIe at 2^22 rows, under the sibling's kernels — which also sets the
+            //   lanes apart), then the proof as on a resident witness: one leaf kernel instead of group-wise absorption; 1.03 x serial.
+            unsigned v = 0, w = 0, ln = 0;
+            (void)bj_setup_shape(t->setup, &ln, &v, &w, nullptr);
+            const size_t witness_bytes = ((size_t)(v + w + 1) << ln) * 8;
+            int mode = bj::env().async_mode;
+            if (mode < 0) mode = witness_bytes >= ((size_t)1 << 30) ? 1 : 0;
+            if (mode == 0) stagger(t->setup);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                started = std::chrono::steady_clock::now();
+                running = t->setup;
+            }
             bj_proof *p = nullptr;
             const uint64_t *pub = t->has_public ? t->public_values.data() : nullptr;
-            // the other lane is proving: let the whole witness cross PCIe under ITS kernels and prove as on a resident witness;
-            // alone on the device: bj_prove's own overlap of the transfer with the hashing of the columns that have landed
-            const bool overlapped = sibling && sibling->busy() && !bj::env().async_no_copy_first;
-            const int rc = overlapped ? prove_host_copy_first(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p)
+            const bool overlapped = sibling && sibling->busy() && mode != 0;
+            const int rc = overlapped ? prove_host_copy_first(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p, mode)
                                       : bj_prove(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p);
             {
                 std::lock_guard<std::mutex> lk(m);
+                last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - started).count();
+                last_setup = t->setup;
+                running = nullptr;
                 t->rc = rc;
                 t->proof = p;
                 if (rc) t->err = sub->err;

@@ -598,6 +598,7 @@ namespace {
 struct HostWitness {
     const uint64_t *h_variables, *h_multiplicities;
     unsigned group;        // columns per group
+    bool no_absorb;        // transfer and transform in groups, hash once at the end (a lane of bj_prove_async whose sibling is proving)
 };
 int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, const uint64_t *d_multiplicities,
                const uint64_t *h_public_values, bj_proof **out, const HostWitness *hw);
@@ -748,7 +749,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
         // kernel — runs under the transfer of the later groups instead of after the last one has landed.
         unsigned G = hw->group;
         if ((nW + G - 1) / G > 64) G = (nW + 63) / 64;
-        const bool absorb = ctx->hasher == BJ_HASHER_POSEIDON2 && !bj::env().prove_no_absorb;
+        const bool absorb = ctx->hasher == BJ_HASHER_POSEIDON2 && !bj::env().prove_no_absorb && !hw->no_absorb;
         if (absorb) G = (G + 7) / 8 * 8;
         // The plan: transfer / transform groups [c0, c1) with one event each, and after some of them one absorption run over the
         // columns extended since the last one.  Nothing can be hashed before the first G columns have crossed PCIe, so those go in
@@ -1464,7 +1465,7 @@ int bj_prove(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const 
     if (int rc = stage_witness(ctx, S)) return rc;
     const size_t n = (size_t)1 << S->log_n;
     const unsigned group = bj::env().prove_h2d_group;
-    const HostWitness hw{h_variables, h_multiplicities, group};
+    const HostWitness hw{h_variables, h_multiplicities, group, false};
     // the copies are queued inside the proof (after the workspace is reserved); a previous proof on this context has drained
     return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + (size_t)(S->V + S->Wc) * n, h_public_values, out, &hw);
 }
@@ -1476,12 +1477,17 @@ namespace bj {
 // stream, while the other lane's proof has the CUs), then the proof runs as on a resident witness — one leaf kernel instead of
 // the group-wise absorption that bj_prove uses to hide the transfer behind its own hashing.  Same bytes either way.
 int prove_host_copy_first(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_variables, const uint64_t *h_multiplicities,
-                          const uint64_t *h_public_values, bj_proof **out) {
+                          const uint64_t *h_public_values, bj_proof **out, int mode) {
     if (int rc = bind(ctx)) return rc;
     if (!S || !h_variables || !out) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: null argument");
     if (S->lookup_reps && !h_multiplicities) return fail(ctx, BJ_ERR_INVALID_ARG, "bj_prove: multiplicities required");
     if (int rc = stage_witness(ctx, S)) return rc;
     const size_t n = (size_t)1 << S->log_n, vw = (size_t)(S->V + S->Wc) * n;
+    if (mode == 2) {   // transfer and transform in groups as bj_prove does, but ONE leaf kernel at the end: the sibling lane's kernels
+                       // cover the transfer, so nothing is gained by absorbing group by group (extra launches, capacity round trips)
+        const HostWitness hw{h_variables, h_multiplicities, env().prove_h2d_group, true};
+        return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, &hw);
+    }
     BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage, h_variables, vw * 8, hipMemcpyHostToDevice, ctx->stream));
     if (S->lookup_reps) BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage + vw, h_multiplicities, n * 8, hipMemcpyHostToDevice, ctx->stream));
     const int rc = prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, nullptr);
