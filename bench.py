@@ -451,7 +451,7 @@ def main():
 
         th2 = threading.Thread(target=other_leg, daemon=True)
         th2.start()
-        th2.join(float(os.environ.get("BJ_BENCH_OTHER_BULK_TIMEOUT_S", "180")))
+        th2.join(float(os.environ.get("BJ_BENCH_OTHER_BULK_TIMEOUT_S", "60")))
         if th2.is_alive():
             res2 = {"error": "did not finish within the watchdog"}
         if "error" not in res2 and not res2.get("same"):
