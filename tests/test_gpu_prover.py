@@ -398,6 +398,41 @@ def test_two_contexts_on_two_host_threads_prove_concurrently():
         c.close()
 
 
+def test_monomial_layouts_at_2p22_rows_give_the_same_proof():
+    """At 2^22 rows bj_prove keeps monomials in the tiled layout (inverse transforms without a bit-reversal pass, front-pass tiles read
+    contiguously; csrc/ntt_r16.hip).  BJ_MONO_TILED=0 keeps them in natural order (the path every other trace length takes) and
+    BJ_NTT_TWO_PASS=0 goes back to the three-pass plan: setup caps and proofs are the same bytes under all three, resident and
+    host-witness entry points alike."""
+    import os
+    ctx()                                  # PyTorch's HIP runtime first (tests/gpu_util.py), then the library
+    lib = E.load_library()
+    c = S.sha_shaped_circuit(22, seed=42, table_bits=4)
+    d_vars, d_mult = ctx().upload(c.variables), ctx().upload(c.multiplicities)
+    got = {}
+    try:
+        for name, env in (("tiled", {}), ("natural", {"BJ_MONO_TILED": "0"}), ("three_pass", {"BJ_NTT_TWO_PASS": "0"})):
+            os.environ.update(env)
+            lib.bj_env_reload()
+            assert ctx().monomials_tiled(22) == (name == "tiled")
+            setup = E.ProverSetup(ctx(), c, 8, 16, 100)
+            buf, _ = setup.prove_dev(d_vars, d_mult)
+            got[name] = (buf.copy(), setup.cap().copy())
+            if name != "three_pass":
+                assert np.array_equal(setup.prove()[0], buf), name + ": host-witness entry point"
+            setup.close()
+            for k in env:
+                os.environ.pop(k)
+    finally:
+        for k in ("BJ_MONO_TILED", "BJ_NTT_TWO_PASS"):
+            os.environ.pop(k, None)
+        lib.bj_env_reload()
+    for name in ("natural", "three_pass"):
+        assert np.array_equal(got[name][0], got["tiled"][0]) and np.array_equal(got[name][1], got["tiled"][1]), name
+    ctx().free(d_vars)
+    ctx().free(d_mult)
+    ctx().release_workspace()
+
+
 def test_pipelined_drop_in_call_gives_the_serial_proofs():
     """bj_prove_async / bj_proof_wait (csrc/prove_async.hip): the host loop over witnesses around prove_cpu_basic
     (prover.rs:153-168, convenience.rs:119-196) with two proofs in flight from ONE host thread.  Two setups of different sizes share
