@@ -478,6 +478,23 @@ def test_pipelined_drop_in_call_gives_the_serial_proofs():
     ts = [s3.prove_async(), s3.prove_async(), s3.prove_async(), s3.prove_async()]
     for t in ts:
         assert np.array_equal(s3.wait(t)[0], ref3)
+    # the other lane policies (by default chosen by witness size, csrc/prove_async.hip): whole witness first (1), groups transferred and
+    # transformed as they land but hashed once (2), bj_prove as is without the stagger — same bytes
+    import os
+    lib = E.load_library()
+    try:
+        for env in ({"BJ_ASYNC_MODE": "1"}, {"BJ_ASYNC_MODE": "2"}, {"BJ_ASYNC_MODE": "0", "BJ_ASYNC_STAGGER": "0"}):
+            os.environ.update(env)
+            lib.bj_env_reload()
+            ts = [s1.prove_async(), s2.prove_async(), s1.prove_async(), s1.prove_async(), s2.prove_async()]
+            for t, (st, ref) in zip(ts, ((s1, ref1), (s2, ref2), (s1, ref1), (s1, ref1), (s2, ref2))):
+                assert np.array_equal(st.wait(t)[0], ref), env
+            for k in env:
+                os.environ.pop(k)
+    finally:
+        for k in ("BJ_ASYNC_MODE", "BJ_ASYNC_STAGGER"):
+            os.environ.pop(k, None)
+        lib.bj_env_reload()
     s1.close(); s2.close(); s3.close()
     ctx().release_workspace()          # frees the lanes' arenas and witness staging too
 
