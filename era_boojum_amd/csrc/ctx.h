@@ -69,6 +69,12 @@ struct bj_ctx {
     } probes[BJ_MAX_KERNEL_PROBES];
     unsigned probe_n = 0;
     bj::Pipeline *pipe = nullptr;   // bj_prove_async: created on first use, destroyed with the context
+    // lanes of bj_prove_async: host-to-device transfers of the two lanes are kept from overlapping — two witness transfers at once
+    // halve each other's PCIe rate, and the runtime was seen to fall back to a shader copy for the second one, which crawls under a
+    // saturated device (a 3 GB copy took 1.8 s instead of 55 ms in one of three bench runs).  h2d_done is recorded behind a lane's last
+    // witness copy; the sibling's copies wait for it on the device (hipStreamWaitEvent: no host blocking).
+    hipEvent_t h2d_done = nullptr;
+    bj_ctx *sibling_lane = nullptr;
 };
 
 namespace bj {

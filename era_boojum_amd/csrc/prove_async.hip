@@ -132,6 +132,11 @@ static int lane_start(bj_ctx *ctx, Lane &L) {
     }
     L.sub->stream = L.stream;
     L.sub->hasher = ctx->hasher;
+    if (hipEventCreateWithFlags(&L.sub->h2d_done, hipEventDisableTiming) != hipSuccess) L.sub->h2d_done = nullptr;
+    if (L.sibling && L.sibling->sub) {          // the second lane: from now on the lanes' witness transfers take turns
+        L.sub->sibling_lane = L.sibling->sub;
+        L.sibling->sub->sibling_lane = L.sub;
+    }
     L.worker = std::thread([&L] { L.run(); });
     return BJ_OK;
 }
@@ -139,7 +144,7 @@ static int lane_start(bj_ctx *ctx, Lane &L) {
 void pipeline_destroy(bj_ctx *ctx) {
     Pipeline *P = ctx->pipe;
     if (!P) return;
-    for (unsigned i = 0; i < P->created; i++) {
+    for (unsigned i = 0; i < P->created; i++) {      // first every worker ends (the lanes' contexts refer to each other) ...
         Lane &L = P->lanes[i];
         {
             std::unique_lock<std::mutex> lk(L.m);
@@ -148,6 +153,9 @@ void pipeline_destroy(bj_ctx *ctx) {
         }
         L.cv.notify_all();
         if (L.worker.joinable()) L.worker.join();
+    }
+    for (unsigned i = 0; i < P->created; i++) {      // ... then the contexts go
+        Lane &L = P->lanes[i];
         if (L.sub) bj_ctx_destroy(L.sub);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }

@@ -791,6 +791,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             if ((rc = capacity.alloc(ctx, 4 * N))) return rc;
             hashed_in_groups = true;
         }
+        if (ctx->sibling_lane && ctx->sibling_lane->h2d_done)   // the other lane's witness transfer first (ctx.h)
+            BJ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->sibling_lane->h2d_done, 0));
         for (unsigned g = 0; g < n_groups; g++) {
             if (!ctx->copy_ev[g]) BJ_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[g], hipEventDisableTiming));
             const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
@@ -803,6 +805,7 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                                            ctx->copy_stream));
             BJ_HIP(ctx, hipEventRecord(ctx->copy_ev[g], ctx->copy_stream));
         }
+        if (ctx->h2d_done) BJ_HIP(ctx, hipEventRecord(ctx->h2d_done, ctx->copy_stream));
         if (absorb) BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
         for (unsigned g = 0; g < n_groups && !rc; g++) {
             const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
@@ -1488,8 +1491,10 @@ int prove_host_copy_first(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_vari
         const HostWitness hw{h_variables, h_multiplicities, env().prove_h2d_group, true};
         return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, &hw);
     }
+    if (ctx->sibling_lane && ctx->sibling_lane->h2d_done) BJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sibling_lane->h2d_done, 0));
     BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage, h_variables, vw * 8, hipMemcpyHostToDevice, ctx->stream));
     if (S->lookup_reps) BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage + vw, h_multiplicities, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->h2d_done) BJ_HIP(ctx, hipEventRecord(ctx->h2d_done, ctx->stream));
     const int rc = prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, nullptr);
     (void)hipStreamSynchronize(ctx->stream);   // no queued copy may read the caller's witness after this returns
     return rc;
