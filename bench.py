@@ -642,6 +642,7 @@ def main():
                     bufs[which], _ = st.prove_dev(d_vars.data_ptr(), d_mult.data_ptr())
 
             run(1, setup2)                      # warm-up of the second context (arena, twiddles)
+            setup.prove_dev(d_vars.data_ptr(), d_mult.data_ptr())      # and of the first one: its workspace was released above (a 63 GB hipMalloc takes 0.4 ms .. 1.8 s)
             torch.cuda.synchronize()
             th = [threading.Thread(target=run, args=(0, setup), daemon=True), threading.Thread(target=run, args=(1, setup2), daemon=True)]
             c0 = time.perf_counter()

@@ -293,7 +293,6 @@ void bj_ctx_destroy(bj_ctx *ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     for (auto &sl : ctx->arena_slabs) (void)hipFree(sl.first);
     if (ctx->h_ring) (void)hipHostFree(ctx->h_ring);
-    if (ctx->h2d_done) (void)hipEventDestroy(ctx->h2d_done);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -69,12 +69,10 @@ struct bj_ctx {
     } probes[BJ_MAX_KERNEL_PROBES];
     unsigned probe_n = 0;
     bj::Pipeline *pipe = nullptr;   // bj_prove_async: created on first use, destroyed with the context
-    // lanes of bj_prove_async: host-to-device transfers of the two lanes are kept from overlapping — two witness transfers at once
-    // halve each other's PCIe rate, and the runtime was seen to fall back to a shader copy for the second one, which crawls under a
-    // saturated device (a 3 GB copy took 1.8 s instead of 55 ms in one of three bench runs).  h2d_done is recorded behind a lane's last
-    // witness copy; the sibling's copies wait for it on the device (hipStreamWaitEvent: no host blocking).
-    hipEvent_t h2d_done = nullptr;
-    bj_ctx *sibling_lane = nullptr;
+    // A lane proves through two plans (host witness hashed in groups; whole witness first, then as on a resident witness) whose
+    // workspaces differ by the leaves' capacity words.  It reserves for the larger one always: a lane whose first proof took the smaller
+    // plan re-allocated its 64 GB arena on the first proof of the other kind — 1.85 s, with the device synchronised under the sibling.
+    bool reserve_host_plan = false;
 };
 
 namespace bj {

@@ -13,6 +13,8 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -90,6 +92,8 @@ struct Lane {
             const size_t witness_bytes = ((size_t)(v + w + 1) << ln) * 8;
             int mode = bj::env().async_mode;
             if (mode < 0) mode = witness_bytes >= ((size_t)1 << 30) ? 1 : 0;
+            static const bool dbg = getenv("BJ_ASYNC_DEBUG") != nullptr;
+            const auto t_pick = std::chrono::steady_clock::now();
             if (mode == 0) stagger(t->setup);
             {
                 std::lock_guard<std::mutex> lk(m);
@@ -101,6 +105,10 @@ struct Lane {
             const bool overlapped = sibling && sibling->busy() && mode != 0;
             const int rc = overlapped ? prove_host_copy_first(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p, mode)
                                       : bj_prove(sub, t->setup, t->h_variables, t->h_multiplicities, pub, &p);
+            if (dbg)
+                fprintf(stderr, "[lane %p] mode %d overlapped %d: picked up, ran %.1f ms (stagger %.1f ms)\n", (void *)this, mode, (int)overlapped,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - started).count(),
+                        std::chrono::duration<double, std::milli>(started - t_pick).count());
             {
                 std::lock_guard<std::mutex> lk(m);
                 last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - started).count();
@@ -132,11 +140,7 @@ static int lane_start(bj_ctx *ctx, Lane &L) {
     }
     L.sub->stream = L.stream;
     L.sub->hasher = ctx->hasher;
-    if (hipEventCreateWithFlags(&L.sub->h2d_done, hipEventDisableTiming) != hipSuccess) L.sub->h2d_done = nullptr;
-    if (L.sibling && L.sibling->sub) {          // the second lane: from now on the lanes' witness transfers take turns
-        L.sub->sibling_lane = L.sibling->sub;
-        L.sibling->sub->sibling_lane = L.sub;
-    }
+    L.sub->reserve_host_plan = true;
     L.worker = std::thread([&L] { L.run(); });
     return BJ_OK;
 }
@@ -144,7 +148,7 @@ static int lane_start(bj_ctx *ctx, Lane &L) {
 void pipeline_destroy(bj_ctx *ctx) {
     Pipeline *P = ctx->pipe;
     if (!P) return;
-    for (unsigned i = 0; i < P->created; i++) {      // first every worker ends (the lanes' contexts refer to each other) ...
+    for (unsigned i = 0; i < P->created; i++) {      // first every worker ends (nothing of a lane may go while a sibling still proves) ...
         Lane &L = P->lanes[i];
         {
             std::unique_lock<std::mutex> lk(L.m);

@@ -661,7 +661,8 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                     + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
                     + 4 * N + (N * sh.world) / 2                                                   // FRI layers + trees, DEEP argument blocks
                     + (sh.world > 1 ? 10 * n : 0)                                                  // sharded DEEP numerators: slices + gather staging
-                    + (hw ? 4 * N : 0)                                                             // host witness hashed in groups: the leaves' capacity words
+                    + (hw || ctx->reserve_host_plan ? 4 * N : 0)                                   // host witness hashed in groups: the leaves' capacity words (a lane of
+                                                                                                   // bj_prove_async reserves them whichever plan the proof takes: the plans alternate)
                     + (size_t)2 * N * (1 + S->pub_cols.size())                                     // DEEP: one extended numerator per large opening set beyond the first
                     + (S->tiled ? 2 * Q : 0);                                                      // the quotient's chunks once more, in the tiled layout
         // `need` is an upper bound by construction of the list above — checked on every proof the test suite makes (the binding
@@ -791,8 +792,6 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
             if ((rc = capacity.alloc(ctx, 4 * N))) return rc;
             hashed_in_groups = true;
         }
-        if (ctx->sibling_lane && ctx->sibling_lane->h2d_done)   // the other lane's witness transfer first (ctx.h)
-            BJ_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->sibling_lane->h2d_done, 0));
         for (unsigned g = 0; g < n_groups; g++) {
             if (!ctx->copy_ev[g]) BJ_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_ev[g], hipEventDisableTiming));
             const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
@@ -805,7 +804,6 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                                            ctx->copy_stream));
             BJ_HIP(ctx, hipEventRecord(ctx->copy_ev[g], ctx->copy_stream));
         }
-        if (ctx->h2d_done) BJ_HIP(ctx, hipEventRecord(ctx->h2d_done, ctx->copy_stream));
         if (absorb) BJ_HIP(ctx, hipEventRecord(ctx->ev0, st));
         for (unsigned g = 0; g < n_groups && !rc; g++) {
             const unsigned c0 = plan[g].c0, c1 = plan[g].c1;
@@ -1491,10 +1489,8 @@ int prove_host_copy_first(bj_ctx *ctx, const bj_setup *S, const uint64_t *h_vari
         const HostWitness hw{h_variables, h_multiplicities, env().prove_h2d_group, true};
         return prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, &hw);
     }
-    if (ctx->sibling_lane && ctx->sibling_lane->h2d_done) BJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->sibling_lane->h2d_done, 0));
     BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage, h_variables, vw * 8, hipMemcpyHostToDevice, ctx->stream));
     if (S->lookup_reps) BJ_HIP(ctx, hipMemcpyAsync(ctx->wit_stage + vw, h_multiplicities, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (ctx->h2d_done) BJ_HIP(ctx, hipEventRecord(ctx->h2d_done, ctx->stream));
     const int rc = prove_impl(ctx, S, ctx->wit_stage, ctx->wit_stage + vw, h_public_values, out, nullptr);
     (void)hipStreamSynchronize(ctx->stream);   // no queued copy may read the caller's witness after this returns
     return rc;

@@ -30,12 +30,16 @@ for log_n in [int(x) for x in sys.argv[1:]] or [14, 16, 18, 20]:
     ok, first = True, None
     for _ in range(k - 1):
         cur = setup.prove_async(variables=hv, multiplicities=hm)
-        ok = ok and np.array_equal(setup.wait(prev)[0], ref)
-        first = first or (time.perf_counter() - t0) * 1e3
+        got, stages = setup.wait(prev)
+        ok = ok and np.array_equal(got, ref)
+        if first is None:
+            first, first_stages = (time.perf_counter() - t0) * 1e3, {k2: round(v, 1) for k2, v in stages.items()}
         prev = cur
     ok = ok and np.array_equal(setup.wait(prev)[0], ref)
     piped = (time.perf_counter() - t0) / k * 1e3
     print("2^%d rows: serial bj_prove %.3f ms, pipelined %.3f ms per proof (x%.2f), first completion %.0f ms, identical: %s"
           % (log_n, serial, piped, serial / piped, first, ok), flush=True)
+    if first > 3.0 * serial:
+        print("   slow first proof, its stages:", first_stages, flush=True)
     setup.close()
     ctx.release_workspace()
