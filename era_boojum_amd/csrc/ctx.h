@@ -69,10 +69,6 @@ struct bj_ctx {
     } probes[BJ_MAX_KERNEL_PROBES];
     unsigned probe_n = 0;
     bj::Pipeline *pipe = nullptr;   // bj_prove_async: created on first use, destroyed with the context
-    // A lane proves through two plans (host witness hashed in groups; whole witness first, then as on a resident witness) whose
-    // workspaces differ by the leaves' capacity words.  It reserves for the larger one always: a lane whose first proof took the smaller
-    // plan re-allocated its 64 GB arena on the first proof of the other kind — 1.85 s, with the device synchronised under the sibling.
-    bool reserve_host_plan = false;
 };
 
 namespace bj {

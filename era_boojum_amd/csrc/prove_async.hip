@@ -140,7 +140,6 @@ static int lane_start(bj_ctx *ctx, Lane &L) {
     }
     L.sub->stream = L.stream;
     L.sub->hasher = ctx->hasher;
-    L.sub->reserve_host_plan = true;
     L.worker = std::thread([&L] { L.run(); });
     return BJ_OK;
 }

@@ -661,8 +661,9 @@ int prove_impl(bj_ctx *ctx, const bj_setup *S, const uint64_t *d_variables, cons
                     + (size_t)4096 * 1024 * (sh.world > 1 ? 1 + sh.world : 1) + 64 * slack        // alphas, query gathers
                     + 4 * N + (N * sh.world) / 2                                                   // FRI layers + trees, DEEP argument blocks
                     + (sh.world > 1 ? 10 * n : 0)                                                  // sharded DEEP numerators: slices + gather staging
-                    + (hw || ctx->reserve_host_plan ? 4 * N : 0)                                   // host witness hashed in groups: the leaves' capacity words (a lane of
-                                                                                                   // bj_prove_async reserves them whichever plan the proof takes: the plans alternate)
+                    + 4 * N                                                                        // host witness hashed in groups: the leaves' capacity words — reserved whichever
+                                                                                                   // entry point the proof came through: a context that alternates between bj_prove and
+                                                                                                   // bj_prove_dev (the lanes of bj_prove_async do) must not re-allocate its arena (1.8 s for 64 GB)
                     + (size_t)2 * N * (1 + S->pub_cols.size())                                     // DEEP: one extended numerator per large opening set beyond the first
                     + (S->tiled ? 2 * Q : 0);                                                      // the quotient's chunks once more, in the tiled layout
         // `need` is an upper bound by construction of the list above — checked on every proof the test suite makes (the binding
